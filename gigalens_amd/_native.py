@@ -1,0 +1,225 @@
+"""ctypes binding of ``lib/libgigalens_hip.so`` (C ABI: ``include/gigalens_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every number on the hot path is
+produced by the HIP kernels behind this ABI.  There is deliberately no fallback -- a missing library
+or a failed call raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+import numpy as np
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgigalens_hip.so")
+_lib = None
+
+GL_FLAG_SHAPELETS_INTERPOLATE = 1
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class gl_component(ctypes.Structure):
+    _fields_ = [("kind", c_int32), ("iparam", c_int32), ("flags", c_uint32), ("reserved", c_int32)]
+
+
+class gl_grid(ctypes.Structure):
+    _fields_ = [
+        ("height", c_int32), ("width", c_int32), ("supersample", c_int32), ("n_region", c_int32),
+        ("grid_x", POINTER(c_float)), ("grid_y", POINTER(c_float)), ("pix_index", POINTER(c_int32)),
+        ("conversion_factor", c_float), ("psf", POINTER(c_float)), ("psf_h", c_int32), ("psf_w", c_int32),
+    ]
+
+
+# every symbol include/gigalens_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "gl_model_create": (c_int, [POINTER(gl_component), c_int, c_int, c_int, POINTER(gl_grid), POINTER(c_void_p)]),
+    "gl_model_destroy": (None, [c_void_p]),
+    "gl_model_num_params": (c_int, [c_void_p]),
+    "gl_model_param_offset": (c_int, [c_void_p, c_int]),
+    "gl_model_num_pixels": (c_int64, [c_void_p]),
+    "gl_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "gl_simulate_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gl_simulate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gl_loglike_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
+    "gl_kind_num_params": (c_int, [POINTER(gl_component)]),
+    "gl_last_error": (c_char_p, []),
+    "gl_version": (c_char_p, []),
+}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load the HIP library or fail loudly (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise NativeLibraryError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). gigalens_amd has no CPU fallback.")
+        try:
+            h = ctypes.CDLL(_LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise NativeLibraryError(f"cannot load {_LIB_PATH}: {e}") from e
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise NativeLibraryError(f"gigalens_hip error {rc}: {lib().gl_last_error().decode()}")
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise NativeLibraryError(f"{what} must live on the GPU (got device {t.device}); gigalens_amd has no CPU path")
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def component_of(profile):
+    kind, iparam, flags = profile._component()
+    return gl_component(kind, iparam, flags, 0)
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise NativeLibraryError("no GPU visible: gigalens_amd's hot path only runs as HIP kernels on gfx950")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+# --------------------------------------------------------------------------------------------------
+# plugin-level point evaluation (MassProfile.deriv / LightProfile.light)
+# --------------------------------------------------------------------------------------------------
+def profile_eval(profile, x, y, kwargs):
+    dev = device()
+    comp = component_of(profile)
+    names = list(profile.params)
+    missing = [n for n in names if n not in kwargs]
+    if missing:
+        raise TypeError(f"{profile.name}: missing parameters {missing}")
+    x = torch.as_tensor(x, dtype=torch.float32, device=dev)
+    y = torch.as_tensor(y, dtype=torch.float32, device=dev)
+    vals = [torch.as_tensor(kwargs[n], dtype=torch.float32, device=dev) for n in names]
+    out_shape = torch.broadcast_shapes(x.shape, y.shape, *[v.shape for v in vals])
+    B = out_shape[-1] if len(out_shape) else 1
+    for n, v in zip(names, vals):
+        if v.dim() > 1 and any(s != 1 for s in v.shape[:-1]):
+            raise NativeLibraryError(f"{profile.name}.{n}: parameters may only vary along the last (batch) axis")
+    P = torch.stack([v.reshape(-1)[-B:].expand(B) if v.numel() > 1 else v.reshape(()).expand(B) for v in vals],
+                    dim=1).contiguous()
+    xb = x.expand(out_shape).reshape(-1, B).contiguous()
+    yb = y.expand(out_shape).reshape(-1, B).contiguous()
+    n_pts = xb.shape[0]
+    out0 = torch.empty_like(xb)
+    is_mass = comp.kind <= 5
+    out1 = torch.empty_like(xb) if is_mass else None
+    _check(lib().gl_profile_eval(ctypes.byref(comp), _ptr(xb), _ptr(yb), n_pts, B, 1, _ptr(P), _ptr(out0),
+                                 _ptr(out1), _stream()))
+    if is_mass:
+        return out0.reshape(out_shape), out1.reshape(out_shape)
+    return (out0.reshape(out_shape),)
+
+
+# --------------------------------------------------------------------------------------------------
+# model handle
+# --------------------------------------------------------------------------------------------------
+class Model:
+    """Owns one ``gl_model`` (immutable descriptor + grid on the current device)."""
+
+    def __init__(self, components, n_lens, n_lens_light, n_src, height, width, supersample, grid_x, grid_y,
+                 pix_index, conversion_factor, psf=None):
+        self.device = device()
+        L = lib()
+        n = len(components)
+        arr = (gl_component * max(n, 1))(*components)
+        gx = np.ascontiguousarray(grid_x, dtype=np.float32)
+        gy = np.ascontiguousarray(grid_y, dtype=np.float32)
+        g = gl_grid()
+        g.height, g.width, g.supersample, g.n_region = int(height), int(width), int(supersample), int(gx.size)
+        g.grid_x = gx.ctypes.data_as(POINTER(c_float))
+        g.grid_y = gy.ctypes.data_as(POINTER(c_float))
+        if pix_index is not None:
+            pi = np.ascontiguousarray(pix_index, dtype=np.int32)
+            g.pix_index = pi.ctypes.data_as(POINTER(c_int32))
+        g.conversion_factor = float(conversion_factor)
+        if psf is not None:
+            pk = np.ascontiguousarray(psf, dtype=np.float32)
+            g.psf = pk.ctypes.data_as(POINTER(c_float))
+            g.psf_h, g.psf_w = pk.shape
+        h = c_void_p()
+        with torch.cuda.device(self.device):
+            _check(L.gl_model_create(arr, n_lens, n_lens_light, n_src, ctypes.byref(g), ctypes.byref(h)))
+        self._h = h
+        self.P = L.gl_model_num_params(h)
+        self.N = L.gl_model_num_pixels(h)
+        self.offsets = [L.gl_model_param_offset(h, i) for i in range(n)]
+        self.out_h, self.out_w = height // supersample, width // supersample
+        self._ws = {}
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.gl_model_destroy(h)
+
+    def _workspace(self, B):
+        ws = self._ws.get(B)
+        if ws is None:
+            nbytes = lib().gl_workspace_bytes(self._h, B)
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self._ws = {B: ws}  # keep only the latest batch size
+        return ws
+
+    def _params(self, params):
+        _require_cuda(params, "params")
+        if params.dtype != torch.float32 or params.dim() != 2 or params.shape[1] != self.P:
+            raise NativeLibraryError(f"params must be float32 [B,{self.P}], got {params.dtype} {tuple(params.shape)}")
+        return params.contiguous()
+
+    def simulate_fwd(self, params):
+        params = self._params(params)
+        B = params.shape[0]
+        ws = self._workspace(B)
+        img = torch.empty((B, self.out_h, self.out_w), dtype=torch.float32, device=params.device)
+        _check(lib().gl_simulate_fwd(self._h, _ptr(params), B, _ptr(img), _ptr(ws), ws.numel(), _stream()))
+        return img
+
+    def simulate_bwd(self, params, grad_img):
+        params = self._params(params)
+        B = params.shape[0]
+        ws = self._workspace(B)
+        grad_img = grad_img.to(torch.float32).expand(B, self.out_h, self.out_w).contiguous()
+        grad = torch.empty_like(params)
+        _check(lib().gl_simulate_bwd(self._h, _ptr(params), _ptr(grad_img), B, _ptr(grad), _ptr(ws), ws.numel(),
+                                     _stream()))
+        return grad
+
+    def loglike(self, params, obs, err, mask, bg_rms, exp_time, want_grad):
+        params = self._params(params)
+        B = params.shape[0]
+        ws = self._workspace(B)
+        ll = torch.empty(B, dtype=torch.float32, device=params.device)
+        chi2 = torch.empty(B, dtype=torch.float32, device=params.device)
+        grad = torch.empty_like(params) if want_grad else None
+        _check(lib().gl_loglike_fwd_bwd(self._h, _ptr(params), _ptr(obs), _ptr(err), _ptr(mask), float(bg_rms),
+                                        float(exp_time), B, _ptr(ll), _ptr(chi2), _ptr(grad), _ptr(ws), ws.numel(),
+                                        _stream()))
+        return ll, chi2, grad

@@ -1,0 +1,418 @@
+// gigalens_hip.hip -- C ABI (include/gigalens_hip.h) over the kernels in gl_kernels.hip.h.
+// gfx950 only.  No per-call allocation, no host synchronisation: every entry point enqueues on
+// the caller's stream and returns (hipGraph-capturable).
+#include "../../include/gigalens_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gl_host_tables.h"
+#include "gl_kernels.hip.h"
+
+using namespace glk;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define GL_HIP(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) return fail(GL_ELAUNCH, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+}  // namespace
+
+struct gl_model {
+  std::vector<CompDesc> comps;
+  int n_lens = 0, n_ll = 0, n_src = 0;
+  int P = 0, D = 0, A = 0, Apad = 0;
+  bool has_shapelets = false, has_table = false;
+  int height = 0, width = 0, supersample = 1, N = 0;
+  float conversion_factor = 1.f;
+  // device-resident, immutable
+  CompDesc* d_comps = nullptr;
+  float* d_gx = nullptr;
+  float* d_gy = nullptr;
+  int* d_pix = nullptr;
+  float* d_shp_tab = nullptr;
+  int shp_stride = 0;
+  float* d_psf = nullptr;
+  int psf_h = 0, psf_w = 0;
+  int tile = 4;          // pixels per thread per tile (template T)
+  int target_wgs = 2048;  // work decomposition target (>= 8 workgroups per CU)
+};
+
+namespace {
+
+// number of pixel chunks per sample: enough workgroups to fill 256 CUs several times over
+// (dynamic load balance: EPL trip counts differ per sample), but whole tiles per chunk.
+void chunking(const gl_model* m, int B, int* chunk, int* n_chunks) {
+  const long long tile_px = (long long)WG * m->tile;
+  long long want = std::max<long long>(1, (m->target_wgs + B - 1) / B);
+  long long per = ((long long)m->N + want - 1) / want;
+  per = std::max(tile_px, (per + tile_px - 1) / tile_px * tile_px);
+  *chunk = (int)per;
+  *n_chunks = (int)(((long long)m->N + per - 1) / per);
+}
+
+struct Workspace {
+  float* derived;
+  float* partial;
+  float* img_ss;   // supersampled / pre-PSF image or its cotangent (PSF path only)
+  float* img_tmp;  // second buffer for conv -> pool
+  size_t bytes;
+};
+
+Workspace carve(const gl_model* m, int B, void* base) {
+  int chunk, n_chunks;
+  chunking(m, B, &chunk, &n_chunks);
+  Workspace w{};
+  size_t off = 0;
+  char* p = (char*)base;
+  w.derived = (float*)(p + off);
+  off += align_up((size_t)B * m->D * sizeof(float), 256);
+  w.partial = (float*)(p + off);
+  off += align_up((size_t)B * n_chunks * m->A * sizeof(float), 256);
+  const bool post = m->d_psf || m->supersample != 1;
+  if (post) {
+    size_t img = align_up((size_t)B * m->height * m->width * sizeof(float), 256);
+    w.img_ss = (float*)(p + off);
+    off += img;
+    w.img_tmp = (float*)(p + off);
+    off += img;
+  }
+  w.bytes = off;
+  return w;
+}
+
+template <int MODE>
+int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream) {
+  dim3 grid(n_chunks, B), block(WG);
+  size_t shmem = (size_t)(((m->D + 3) & ~3) + 4 * m->Apad) * sizeof(float);
+  if (m->has_shapelets) {
+    if (m->tile == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, true>), grid, block, shmem, stream, a);
+    else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true>), grid, block, shmem, stream, a);
+  } else {
+    if (m->tile == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, false>), grid, block, shmem, stream, a);
+    else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, false>), grid, block, shmem, stream, a);
+  }
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
+  MainArgs a{};
+  a.comps = m->d_comps;
+  a.n_lens = m->n_lens;
+  a.n_ll = m->n_ll;
+  a.n_src = m->n_src;
+  a.derived = w.derived;
+  a.D = m->D;
+  a.A = m->A;
+  a.Apad = m->Apad;
+  a.gx = m->d_gx;
+  a.gy = m->d_gy;
+  a.pix = m->d_pix;
+  a.N = m->N;
+  a.chunk = chunk;
+  a.img_stride = (long long)m->height * m->width;
+  a.out_scale = m->conversion_factor;
+  a.partial = w.partial;
+  a.shp_tab = m->d_shp_tab;
+  a.shp_stride = m->shp_stride;
+  return a;
+}
+
+int check_call(const gl_model* m, const void* params, int B, void* ws, size_t ws_bytes) {
+  if (!m) return fail(GL_EINVAL, "model is null");
+  if (!params) return fail(GL_EINVAL, "params is null");
+  if (B <= 0 || B > 65535) return fail(GL_EINVAL, "batch size %d outside [1, 65535]", B);
+  if (!ws) return fail(GL_EINVAL, "workspace is null");
+  size_t need = gl_workspace_bytes(m, B);
+  if (ws_bytes < need) return fail(GL_ENOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+  return GL_OK;
+}
+
+int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, hipStream_t stream) {
+  int n_comp = (int)m->comps.size();
+  int total = B * n_comp;
+  hipLaunchKernelGGL(gl_prep_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, params,
+                     m->P, B, w.derived, m->D);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, const Workspace& w, float* loglike,
+                 float* chi2, float* grad, hipStream_t stream) {
+  hipLaunchKernelGGL(gl_finalize_kernel, dim3(B), dim3(128), (size_t)m->A * sizeof(float), stream, m->d_comps,
+                     (int)m->comps.size(), params, m->P, w.partial, n_chunks, m->A, loglike, chi2, grad);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gl_last_error(void) { return g_err; }
+const char* gl_version(void) { return "gigalens_hip 0.1 (gfx950)"; }
+
+int gl_kind_num_params(const gl_component* comp) {
+  if (!comp) return fail(GL_EINVAL, "component is null");
+  int n = kind_num_params(comp->kind, comp->iparam);
+  if (n < 0) return fail(GL_EINVAL, "unknown profile kind %d", comp->kind);
+  return n;
+}
+
+int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int n_src, const gl_grid* grid,
+                    gl_model** out) {
+  if (!out) return fail(GL_EINVAL, "out is null");
+  *out = nullptr;
+  if (!grid) return fail(GL_EINVAL, "grid is null");
+  if (n_lens < 0 || n_lens_light < 0 || n_src < 0) return fail(GL_EINVAL, "negative component count");
+  int n_comp = n_lens + n_lens_light + n_src;
+  if (n_comp > 0 && !comps) return fail(GL_EINVAL, "comps is null");
+  if (grid->height <= 0 || grid->width <= 0 || grid->n_region <= 0) return fail(GL_EINVAL, "empty grid");
+  if (!grid->grid_x || !grid->grid_y) return fail(GL_EINVAL, "grid_x / grid_y is null");
+  if (grid->supersample < 1) return fail(GL_EINVAL, "supersample must be >= 1");
+  if (grid->height % grid->supersample || grid->width % grid->supersample)
+    return fail(GL_EINVAL, "grid size not a multiple of supersample");
+  if ((long long)grid->n_region > (long long)grid->height * grid->width)
+    return fail(GL_EINVAL, "n_region exceeds height*width");
+  if (!grid->pix_index && (long long)grid->n_region != (long long)grid->height * grid->width)
+    return fail(GL_EINVAL, "pix_index is required when n_region != height*width");
+  if (grid->psf && (grid->psf_h <= 0 || grid->psf_w <= 0)) return fail(GL_EINVAL, "bad PSF shape");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GL_ENODEVICE, "no HIP device available");
+
+  gl_model* m = new (std::nothrow) gl_model();
+  if (!m) return fail(GL_ENOMEM, "host allocation failed");
+  m->n_lens = n_lens;
+  m->n_ll = n_lens_light;
+  m->n_src = n_src;
+  int p_off = 0, d_off = 0, a_off = NSTAT, sh_nmax = -1;
+  for (int i = 0; i < n_comp; ++i) {
+    const gl_component& c = comps[i];
+    const bool mass = i < n_lens;
+    const bool is_mass_kind = c.kind >= GL_EPL && c.kind <= GL_SIS;
+    const bool is_light_kind = c.kind >= GL_SERSIC && c.kind <= GL_SHAPELETS;
+    if ((mass && !is_mass_kind) || (!mass && !is_light_kind)) {
+      delete m;
+      return fail(GL_EINVAL, "component %d: kind %d is not a %s profile", i, c.kind, mass ? "mass" : "light");
+    }
+    int iparam = c.iparam;
+    if (c.kind == GL_EPL) {
+      if (iparam <= 0) iparam = 50;  // epl.py:15
+      if (iparam > 1000) { delete m; return fail(GL_EINVAL, "EPL niter %d too large", iparam); }
+    }
+    if (c.kind == GL_SHAPELETS) {
+      if (iparam < 0 || iparam > GL_SHAPELETS_NMAX_CAP) {
+        delete m;
+        return fail(GL_EUNSUPPORTED, "shapelets n_max=%d outside [0,%d]", iparam, GL_SHAPELETS_NMAX_CAP);
+      }
+      m->has_shapelets = true;
+      if (c.flags & GL_FLAG_SHAPELETS_INTERPOLATE) { m->has_table = true; sh_nmax = std::max(sh_nmax, iparam); }
+    }
+    CompDesc cd{};
+    cd.kind = c.kind;
+    cd.iparam = iparam;
+    cd.flags = c.flags;
+    cd.p_off = p_off;
+    cd.d_off = d_off;
+    cd.a_off = a_off;
+    cd.n_par = kind_num_params(c.kind, iparam);
+    cd.n_acc = kind_num_acc(c.kind, iparam);
+    p_off += cd.n_par;
+    d_off += (kind_num_derived(c.kind, iparam) + 3) & ~3;
+    a_off += cd.n_acc;
+    m->comps.push_back(cd);
+  }
+  m->P = p_off;
+  m->D = std::max(d_off, 4);
+  m->A = a_off;
+  m->Apad = (a_off + 3) & ~3;
+  m->height = grid->height;
+  m->width = grid->width;
+  m->supersample = grid->supersample;
+  m->N = grid->n_region;
+  m->conversion_factor = grid->conversion_factor;
+  m->tile = env_int("GIGALENS_HIP_TILE", m->has_shapelets ? 2 : 4) == 2 ? 2 : 4;
+  m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
+  size_t shmem = (size_t)(((m->D + 3) & ~3) + 4 * m->Apad) * sizeof(float);
+  if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
+
+  auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
+    if (hipMalloc(dst, bytes) != hipSuccess) return false;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  bool ok = true;
+  if (n_comp) ok = ok && up((void**)&m->d_comps, m->comps.data(), sizeof(CompDesc) * n_comp);
+  else ok = ok && (hipMalloc((void**)&m->d_comps, sizeof(CompDesc)) == hipSuccess);
+  ok = ok && up((void**)&m->d_gx, grid->grid_x, sizeof(float) * m->N);
+  ok = ok && up((void**)&m->d_gy, grid->grid_y, sizeof(float) * m->N);
+  if (grid->pix_index) {
+    for (int i = 0; i < m->N && ok; ++i)
+      if (grid->pix_index[i] < 0 || grid->pix_index[i] >= m->height * m->width) {
+        gl_model_destroy(m);
+        return fail(GL_EINVAL, "pix_index[%d]=%d out of range", i, grid->pix_index[i]);
+      }
+    ok = ok && up((void**)&m->d_pix, grid->pix_index, sizeof(int) * m->N);
+  }
+  if (m->has_table) {
+    std::vector<float> tab;
+    glh::build_shapelet_table(sh_nmax, tab, &m->shp_stride);
+    ok = ok && up((void**)&m->d_shp_tab, tab.data(), tab.size() * sizeof(float));
+  }
+  if (grid->psf) {
+    m->psf_h = grid->psf_h;
+    m->psf_w = grid->psf_w;
+    ok = ok && up((void**)&m->d_psf, grid->psf, sizeof(float) * grid->psf_h * grid->psf_w);
+  }
+  if (!ok) {
+    gl_model_destroy(m);
+    return fail(GL_ENOMEM, "device allocation / upload failed in gl_model_create");
+  }
+  *out = m;
+  return GL_OK;
+}
+
+void gl_model_destroy(gl_model* m) {
+  if (!m) return;
+  if (m->d_comps) (void)hipFree(m->d_comps);
+  if (m->d_gx) (void)hipFree(m->d_gx);
+  if (m->d_gy) (void)hipFree(m->d_gy);
+  if (m->d_pix) (void)hipFree(m->d_pix);
+  if (m->d_shp_tab) (void)hipFree(m->d_shp_tab);
+  if (m->d_psf) (void)hipFree(m->d_psf);
+  delete m;
+}
+
+int gl_model_num_params(const gl_model* m) { return m ? m->P : fail(GL_EINVAL, "model is null"); }
+int gl_model_param_offset(const gl_model* m, int component) {
+  if (!m) return fail(GL_EINVAL, "model is null");
+  if (component < 0 || component >= (int)m->comps.size()) return fail(GL_EINVAL, "component index out of range");
+  return m->comps[component].p_off;
+}
+int64_t gl_model_num_pixels(const gl_model* m) { return m ? m->N : fail(GL_EINVAL, "model is null"); }
+
+size_t gl_workspace_bytes(const gl_model* m, int B) {
+  if (!m || B <= 0) return 0;
+  return carve(m, B, nullptr).bytes;
+}
+
+int gl_simulate_fwd(const gl_model* m, const float* params, int B, float* img, void* workspace,
+                    size_t workspace_bytes, void* hip_stream) {
+  int rc = check_call(m, params, B, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!img) return fail(GL_EINVAL, "img is null");
+  if (m->d_psf || m->supersample != 1) return fail(GL_EUNSUPPORTED, "PSF / supersampling path not built yet");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  Workspace w = carve(m, B, workspace);
+  int chunk, n_chunks;
+  chunking(m, B, &chunk, &n_chunks);
+  if ((rc = run_prep(m, params, B, w, stream))) return rc;
+  if (m->d_pix) GL_HIP(hipMemsetAsync(img, 0, sizeof(float) * (size_t)B * m->height * m->width, stream));
+  MainArgs a = base_args(m, w, chunk);
+  a.img = img;
+  return launch_main<IMG_FWD>(m, a, B, n_chunks, stream);
+}
+
+int gl_simulate_bwd(const gl_model* m, const float* params, const float* grad_img, int B, float* grad_params,
+                    void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = check_call(m, params, B, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!grad_img || !grad_params) return fail(GL_EINVAL, "grad_img / grad_params is null");
+  if (m->d_psf || m->supersample != 1) return fail(GL_EUNSUPPORTED, "PSF / supersampling path not built yet");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  Workspace w = carve(m, B, workspace);
+  int chunk, n_chunks;
+  chunking(m, B, &chunk, &n_chunks);
+  if ((rc = run_prep(m, params, B, w, stream))) return rc;
+  MainArgs a = base_args(m, w, chunk);
+  a.gimg = grad_img;
+  if ((rc = launch_main<IMG_BWD>(m, a, B, n_chunks, stream))) return rc;
+  return run_finalize(m, params, B, n_chunks, w, nullptr, nullptr, grad_params, stream);
+}
+
+int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs, const float* err_or_null,
+                       const float* mask_or_null, float bg_rms, float exp_time, int B, float* loglike, float* chi2,
+                       float* grad_params_or_null, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = check_call(m, params, B, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!obs || !loglike || !chi2) return fail(GL_EINVAL, "obs / loglike / chi2 is null");
+  if (m->d_psf || m->supersample != 1) return fail(GL_EUNSUPPORTED, "PSF / supersampling path not built yet");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  Workspace w = carve(m, B, workspace);
+  int chunk, n_chunks;
+  chunking(m, B, &chunk, &n_chunks);
+  if ((rc = run_prep(m, params, B, w, stream))) return rc;
+  MainArgs a = base_args(m, w, chunk);
+  a.obs = obs;
+  a.err = err_or_null;
+  a.mask = mask_or_null;
+  a.bg2 = bg_rms * bg_rms;
+  a.inv_t = 1.0f / exp_time;
+  if (grad_params_or_null) rc = launch_main<LL_GRAD>(m, a, B, n_chunks, stream);
+  else rc = launch_main<LL_FWD>(m, a, B, n_chunks, stream);
+  if (rc) return rc;
+  return run_finalize(m, params, B, n_chunks, w, loglike, chi2, grad_params_or_null, stream);
+}
+
+int gl_profile_eval(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
+                    const float* params, float* out0, float* out1, void* hip_stream) {
+  if (!comp || !x || !y || !params || !out0) return fail(GL_EINVAL, "null argument");
+  if (n_pts <= 0 || B <= 0) return fail(GL_EINVAL, "n_pts and B must be positive");
+  int npar = kind_num_params(comp->kind, comp->iparam);
+  if (npar < 0) return fail(GL_EINVAL, "unknown profile kind %d", comp->kind);
+  const bool mass = comp->kind <= GL_SIS;
+  if (mass && !out1) return fail(GL_EINVAL, "out1 is required for mass profiles");
+  CompDesc cd{};
+  cd.kind = comp->kind;
+  cd.iparam = comp->iparam;
+  cd.flags = comp->flags;
+  cd.n_par = npar;
+  if (cd.kind == GL_EPL && cd.iparam <= 0) cd.iparam = 50;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  static float* s_tab = nullptr;  // process-lifetime table for table-mode shapelets (n_max = cap)
+  static int s_stride = 0;
+  if (cd.kind == GL_SHAPELETS) {
+    if (cd.iparam < 0 || cd.iparam > GL_SHAPELETS_NMAX_CAP)
+      return fail(GL_EUNSUPPORTED, "shapelets n_max=%d outside [0,%d]", cd.iparam, GL_SHAPELETS_NMAX_CAP);
+    if ((cd.flags & GL_FLAG_SHAPELETS_INTERPOLATE) && !s_tab) {
+      std::vector<float> tab;
+      glh::build_shapelet_table(GL_SHAPELETS_NMAX_CAP, tab, &s_stride);
+      GL_HIP(hipMalloc((void**)&s_tab, tab.size() * sizeof(float)));
+      GL_HIP(hipMemcpy(s_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  long long total = (long long)n_pts * B;
+  hipLaunchKernelGGL(gl_point_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, cd, x, y,
+                     (long long)n_pts, B, xy_batched, params, out0, mass ? out1 : nullptr, s_tab, s_stride);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,499 @@
+// gl_kernels.hip.h -- CDNA4 (gfx950) kernels of the lens hot path.
+//
+// Launch geometry (all kernels): one 256-thread workgroup (4 wave64) works on ONE sample's chunk of
+// pixels; grid = (n_chunks, B).  The sample's derived constants (gl_profiles.h) are staged in LDS
+// once per workgroup and read by broadcast; pixels are thread-strided so that every global access
+// (grid x/y, observed image, image rows) is a contiguous 256-float run per wave-instruction group.
+// Reductions (chi^2, normalisation, parameter gradients) are wave64 DPP reductions into per-wave LDS
+// slots, then one deterministic pass over the 4 waves, then one row of partials per (sample, chunk)
+// in the caller's workspace; gl_finalize_kernel sums chunks in a fixed order (bitwise reproducible,
+// no float atomics) and applies the per-sample chain rule to the raw parameters.
+// MFMA is deliberately unused: the path is elementwise + transcendental (VALU-bound).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl_profiles.h"
+
+namespace glk {
+using namespace glp;
+
+struct CompDesc {
+  int kind, iparam;
+  unsigned flags;
+  int p_off;  // first column in the packed parameter row
+  int d_off;  // offset of the derived block (floats, multiple of 4)
+  int a_off;  // offset of the accumulators inside the per-sample accumulator row
+  int n_acc;
+  int n_par;
+};
+
+enum Mode : int { IMG_FWD = 0, IMG_BWD = 1, LL_FWD = 2, LL_GRAD = 3 };
+constexpr int WG = 256;
+constexpr int NSTAT = 4;  // accumulator row starts with [chi2, norm, pad, pad]
+
+struct MainArgs {
+  const CompDesc* comps;
+  int n_lens, n_ll, n_src;
+  const float* derived;  // [B][D]
+  int D, A, Apad;
+  const float* gx;
+  const float* gy;
+  const int* pix;  // may be null
+  int N, chunk;
+  float* img;         // IMG_FWD out  [B][img_stride]
+  const float* gimg;  // IMG_BWD in   [B][img_stride]
+  long long img_stride;
+  float out_scale;  // multiplies the image (conversion factor when no PSF / pooling follows)
+  const float* obs;
+  const float* err;
+  const float* mask;
+  float bg2, inv_t;
+  float* partial;  // [B][n_chunks][A]
+  const float* shp_tab;
+  int shp_stride;
+};
+
+// ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
+__device__ __forceinline__ float dpp_add(float v, int ctrl, int row_mask) {
+  int r;
+  switch (ctrl) {  // ctrl must be an immediate
+    case 0x111: r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true); break;
+    case 0x112: r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true); break;
+    case 0x114: r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true); break;
+    case 0x118: r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true); break;
+    case 0x142: r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false); break;
+    default: r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false); break;
+  }
+  (void)row_mask;
+  return v + __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float wave_sum63(float v) {
+  v = dpp_add(v, 0x111, 0xF);  // row_shr:1
+  v = dpp_add(v, 0x112, 0xF);  // row_shr:2
+  v = dpp_add(v, 0x114, 0xF);  // row_shr:4
+  v = dpp_add(v, 0x118, 0xF);  // row_shr:8   -> lane 15 of each row holds the row sum
+  v = dpp_add(v, 0x142, 0xA);  // row_bcast:15 into rows 1,3
+  v = dpp_add(v, 0x143, 0xC);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
+  return v;
+}
+template <int G> __device__ __forceinline__ void wave_acc(float (&acc)[G], float* s_row, int lane) {
+#pragma unroll
+  for (int k = 0; k < G; ++k) acc[k] = wave_sum63(acc[k]);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < G; ++k) s_row[k] += acc[k];
+  }
+}
+
+// ---- per-sample prep: raw parameter rows -> derived constants --------------------------------
+__global__ void __launch_bounds__(128) gl_prep_kernel(const CompDesc* __restrict__ comps, int n_comp,
+                                                      const float* __restrict__ params, int P, int B,
+                                                      float* __restrict__ derived, int D) {
+  int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= B * n_comp) return;
+  int b = i / n_comp, c = i - b * n_comp;
+  CompDesc cd = comps[c];
+  const float* p = params + (size_t)b * P + cd.p_off;
+  float* d = derived + (size_t)b * D + cd.d_off;
+  switch (cd.kind) {
+    case K_EPL: epl_prep<float>(p, cd.iparam, d); break;
+    case K_SIE: sie_prep<float>(p, d); break;
+    case K_NFW: nfw_prep<float>(p, d); break;
+    case K_SHEAR: shear_prep<float>(p, d); break;
+    case K_SIS: sis_prep<float>(p, d); break;
+    case K_SERSIC: sersic_prep<float>(p, false, d); break;
+    case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
+    case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, d); break;
+  }
+}
+
+// ---- T-pixel EPL: series loop outermost so one LDS table read serves T pixels -------------------
+template <int T> __device__ __forceinline__ void epl_fwd_T(const float* d, const float (&x)[T], const float (&y)[T],
+                                                            float (&bx)[T], float (&by)[T]) {
+  float Cs[T], Ss[T], E2x[T], E2y[T], Ex[T], Ey[T], Ox[T], Oy[T], Rc[T];
+  const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float dx = x[t] - d[EPL_CX], dy = y[t] - d[EPL_CY];
+    float xr = dx * c + dy * s, yr = dy * c - dx * s;
+    float X = q * xr;
+    float R0 = sqrt_(X * X + yr * yr);
+    bool pos = R0 > 0.f;
+    float inv = pos ? rcp(R0) : 0.f;
+    Cs[t] = pos ? X * inv : 1.f;
+    Ss[t] = yr * inv;
+    Rc[t] = clamp_(R0, 1e-10f, 1e10f);
+    E2x[t] = Cs[t] * Cs[t] - Ss[t] * Ss[t];
+    E2y[t] = 2.f * Cs[t] * Ss[t];
+    Ex[t] = Cs[t]; Ey[t] = Ss[t]; Ox[t] = Cs[t]; Oy[t] = Ss[t];
+  }
+  const int K = (int)d[EPL_K];
+  const float* tab = d + EPL_TAB;
+  for (int n = 1; n <= K; ++n) {
+    float cn = tab[4 * n];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float tx = E2x[t] * Ex[t] - E2y[t] * Ey[t];
+      Ey[t] = E2y[t] * Ex[t] + E2x[t] * Ey[t];
+      Ex[t] = tx;
+      Ox[t] += cn * Ex[t];
+      Oy[t] += cn * Ey[t];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float L2 = log2_(d[EPL_B] * rcp(Rc[t]));
+    float P = d[EPL_P0] * exp2_(d[EPL_TM1] * L2);
+    float arx = P * Ox[t], ary = P * Oy[t];
+    bx[t] -= arx * c - ary * s;
+    by[t] -= arx * s + ary * c;
+  }
+}
+
+template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const float (&x)[T], const float (&y)[T],
+                                                            const float (&gx)[T], const float (&gy)[T], float* acc) {
+  float Cs[T], Ss[T], E2x[T], E2y[T], Ex[T], Ey[T], Ox[T], Oy[T], Sx[T], Sy[T], Fx[T], Fy[T], Tx[T], Ty[T];
+  float xr[T], yr[T], inv[T], R0[T];
+  const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float dx = x[t] - d[EPL_CX], dy = y[t] - d[EPL_CY];
+    xr[t] = dx * c + dy * s;
+    yr[t] = dy * c - dx * s;
+    float X = q * xr[t];
+    R0[t] = sqrt_(X * X + yr[t] * yr[t]);
+    bool pos = R0[t] > 0.f;
+    inv[t] = pos ? rcp(R0[t]) : 0.f;
+    Cs[t] = pos ? X * inv[t] : 1.f;
+    Ss[t] = yr[t] * inv[t];
+    E2x[t] = Cs[t] * Cs[t] - Ss[t] * Ss[t];
+    E2y[t] = 2.f * Cs[t] * Ss[t];
+    Ex[t] = Cs[t]; Ey[t] = Ss[t];
+    Ox[t] = Cs[t]; Oy[t] = Ss[t];
+    Sx[t] = Cs[t]; Sy[t] = Ss[t];
+    Fx[t] = 0.f; Fy[t] = 0.f; Tx[t] = 0.f; Ty[t] = 0.f;
+  }
+  const int K = (int)d[EPL_K];
+  const float4* tab = reinterpret_cast<const float4*>(d + EPL_TAB);
+  for (int n = 1; n <= K; ++n) {
+    float4 cc = tab[n];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float tx = E2x[t] * Ex[t] - E2y[t] * Ey[t];
+      Ey[t] = E2y[t] * Ex[t] + E2x[t] * Ey[t];
+      Ex[t] = tx;
+      Ox[t] += cc.x * Ex[t]; Oy[t] += cc.x * Ey[t];
+      Sx[t] += cc.y * Ex[t]; Sy[t] += cc.y * Ey[t];
+      Fx[t] += cc.z * Ex[t]; Fy[t] += cc.z * Ey[t];
+      Tx[t] += cc.w * Ex[t]; Ty[t] += cc.w * Ey[t];
+    }
+  }
+  const float tm1 = d[EPL_TM1], P0 = d[EPL_P0];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    bool inclamp = (R0[t] >= 1e-10f) && (R0[t] <= 1e10f);
+    float iRc = rcp(clamp_(R0[t], 1e-10f, 1e10f));
+    float L2 = log2_(d[EPL_B] * iRc);
+    float W = exp2_(tm1 * L2);
+    float P = P0 * W;
+    float arx = P * Ox[t], ary = P * Oy[t];
+    float ax = arx * c - ary * s, ay = arx * s + ary * c;
+    float grx = gx[t] * c + gy[t] * s, gry = gy[t] * c - gx[t] * s;
+    float g_phi = gy[t] * ax - gx[t] * ay;
+    float gP = grx * Ox[t] + gry * Oy[t];
+    float gOx = P * grx, gOy = P * gry;
+    float g_ang = gOy * Sx[t] - gOx * Sy[t];
+    float g_t = gOx * Tx[t] + gOy * Ty[t];
+    float g_f = gOx * Fx[t] + gOy * Fy[t];
+    float gW_W = gP * P;
+    g_t += gW_W * (L2 * (float)kLn2);
+    float g_b = gW_W * tm1 * d[EPL_INVB];
+    float gR0 = inclamp ? -gW_W * tm1 * iRc : 0.f;
+    float gX = gR0 * Cs[t] - g_ang * Ss[t] * inv[t];
+    float gyr = gR0 * Ss[t] + g_ang * Cs[t] * inv[t];
+    float g_q = gX * xr[t];
+    float gxr = gX * q;
+    float gdx = gxr * c - gyr * s, gdy = gxr * s + gyr * c;
+    g_phi += gxr * yr[t] - gyr * xr[t];
+    acc[EPLA_CX] -= gdx;
+    acc[EPLA_CY] -= gdy;
+    acc[EPLA_PHI] += g_phi;
+    acc[EPLA_Q] += g_q;
+    acc[EPLA_B] += g_b;
+    acc[EPLA_T] += g_t;
+    acc[EPLA_F] += g_f;
+    acc[EPLA_P0] += gP * W;
+  }
+}
+
+// ---- the main kernel ----------------------------------------------------------------------------
+template <int MODE, int T, bool SHP>
+__global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
+  extern __shared__ float smem[];
+  float* s_d = smem;
+  float* s_acc = smem + ((a.D + 3) & ~3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const CompDesc* __restrict__ comps = a.comps;
+  {
+    const float* src = a.derived + (size_t)b * a.D;
+    for (int i = tid; i < a.D; i += WG) s_d[i] = src[i];
+    if (MODE != IMG_FWD)
+      for (int i = tid; i < 4 * a.Apad; i += WG) s_acc[i] = 0.f;
+  }
+  __syncthreads();
+  float* s_row = s_acc + wave * a.Apad;
+  const int n_lens = a.n_lens, n_light = a.n_ll + a.n_src, n_ll = a.n_ll;
+  const int p0 = chunk * a.chunk;
+  const int p1 = min(p0 + a.chunk, a.N);
+  float st[2] = {0.f, 0.f};  // chi2, norm
+
+  for (int base = p0; base < p1; base += WG * T) {
+    float x[T], y[T], bx[T], by[T], m[T];
+    int pidx[T];
+    bool valid[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      int j = base + t * WG + tid;
+      valid[t] = j < p1;
+      int jj = valid[t] ? j : p1 - 1;
+      x[t] = a.gx[jj];
+      y[t] = a.gy[jj];
+      pidx[t] = a.pix ? a.pix[jj] : jj;
+      bx[t] = x[t]; by[t] = y[t]; m[t] = 0.f;
+    }
+    // ---- phase 1: ray-shoot  beta = (x,y) - sum_i alpha_i(x,y)   (tf/simulator.py:72-78) ----
+    for (int l = 0; l < n_lens; ++l) {
+      const int kind = comps[l].kind;
+      const float* d = s_d + comps[l].d_off;
+      switch (kind) {
+        case K_EPL: epl_fwd_T<T>(d, x, y, bx, by); break;
+        case K_SIE:
+#pragma unroll
+          for (int t = 0; t < T; ++t) { float ax, ay; sie_fwd(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          break;
+        case K_NFW:
+#pragma unroll
+          for (int t = 0; t < T; ++t) { float ax, ay; nfw_fwd(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          break;
+        case K_SHEAR:
+#pragma unroll
+          for (int t = 0; t < T; ++t) { float ax, ay; shear_fwd(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          break;
+        case K_SIS:
+#pragma unroll
+          for (int t = 0; t < T; ++t) { float ax, ay; sis_fwd(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          break;
+      }
+    }
+    // ---- phase 2: render lens light at the grid, sources at beta (tf/simulator.py:128-138) ----
+    for (int ci = 0; ci < n_light; ++ci) {
+      const CompDesc& cd = comps[n_lens + ci];
+      const float* d = s_d + cd.d_off;
+      const bool src = ci >= n_ll;
+      if (cd.kind == K_SHAPELETS) {
+        if (SHP) {
+          const bool interp = cd.flags & 1u;
+#pragma unroll 1
+          for (int t = 0; t < T; ++t)
+            m[t] += shapelets_fwd<float, SH_CAP>(d, a.shp_tab, a.shp_stride, interp, src ? bx[t] : x[t], src ? by[t] : y[t]);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) m[t] += sersic_fwd(d, src ? bx[t] : x[t], src ? by[t] : y[t]);
+      }
+    }
+    bool nanp[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      nanp[t] = isnan_(m[t]);
+      m[t] = (nanp[t] ? 0.f : m[t]) * a.out_scale;  // NaN -> 0 (tf/simulator.py:140), then x det(T) (:156)
+    }
+    if (MODE == IMG_FWD) {
+      float* row = a.img + (size_t)b * a.img_stride;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (valid[t]) row[pidx[t]] = m[t];
+      continue;
+    }
+    float gm[T];
+    if (MODE == IMG_BWD) {
+      const float* row = a.gimg + (size_t)b * a.img_stride;
+#pragma unroll
+      for (int t = 0; t < T; ++t) gm[t] = (valid[t] && !nanp[t]) ? row[pidx[t]] * a.out_scale : 0.f;
+    } else {
+      const bool has_err = a.err != nullptr;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        float o = a.obs[pidx[t]];
+        float w = a.mask ? a.mask[pidx[t]] : 1.f;
+        float e = has_err ? a.err[pidx[t]] : 1.f;
+        float c2, nm;
+        chi2_terms(m[t], o, w, has_err, e, a.bg2, a.inv_t, c2, nm);
+        if (valid[t]) { st[0] += c2; st[1] += nm; }
+        if (MODE == LL_GRAD)
+          gm[t] = (valid[t] && !nanp[t]) ? chi2_gm(m[t], o, w, has_err, e, a.bg2, a.inv_t) * a.out_scale : 0.f;
+      }
+    }
+    if (MODE == IMG_BWD || MODE == LL_GRAD) {
+      float gbx[T], gby[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) { gbx[t] = 0.f; gby[t] = 0.f; }
+      // ---- phase 3: light VJPs -> parameter gradients and the cotangent of beta ----
+      for (int ci = 0; ci < n_light; ++ci) {
+        const CompDesc& cd = comps[n_lens + ci];
+        const float* d = s_d + cd.d_off;
+        const bool src = ci >= n_ll;
+        if (cd.kind == K_SHAPELETS) {
+          if (SHP) {
+            const bool interp = cd.flags & 1u;
+            float acc[SHPA_AMP + SH_MAXL];
+#pragma unroll
+            for (int k = 0; k < SHPA_AMP + SH_MAXL; ++k) acc[k] = 0.f;
+#pragma unroll 1
+            for (int t = 0; t < T; ++t) {
+              float dgx = 0.f, dgy = 0.f;
+              shapelets_vjp<float, SH_CAP>(d, a.shp_tab, a.shp_stride, interp, src ? bx[t] : x[t],
+                                           src ? by[t] : y[t], gm[t], acc, dgx, dgy);
+              if (src) { gbx[t] += dgx; gby[t] += dgy; }
+            }
+            wave_acc<SHPA_AMP + SH_MAXL>(acc, s_row + cd.a_off, lane);
+          }
+        } else {
+          float acc[SER_NACC];
+#pragma unroll
+          for (int k = 0; k < SER_NACC; ++k) acc[k] = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            float dgx = 0.f, dgy = 0.f;
+            sersic_vjp(d, src ? bx[t] : x[t], src ? by[t] : y[t], gm[t], acc, dgx, dgy);
+            if (src) { gbx[t] += dgx; gby[t] += dgy; }
+          }
+          wave_acc<SER_NACC>(acc, s_row + cd.a_off, lane);
+        }
+      }
+      // ---- phase 4: lens VJPs with cotangent -g_beta (beta = x - sum alpha) ----
+#pragma unroll
+      for (int t = 0; t < T; ++t) { gbx[t] = -gbx[t]; gby[t] = -gby[t]; }
+      for (int l = 0; l < n_lens; ++l) {
+        const CompDesc& cd = comps[l];
+        const float* d = s_d + cd.d_off;
+        switch (cd.kind) {
+          case K_EPL: {
+            float acc[EPL_NACC];
+#pragma unroll
+            for (int k = 0; k < EPL_NACC; ++k) acc[k] = 0.f;
+            epl_vjp_T<T>(d, x, y, gbx, gby, acc);
+            wave_acc<EPL_NACC>(acc, s_row + cd.a_off, lane);
+          } break;
+          case K_SIE: {
+            float acc[SIE_NACC];
+#pragma unroll
+            for (int k = 0; k < SIE_NACC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) sie_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
+            wave_acc<SIE_NACC>(acc, s_row + cd.a_off, lane);
+          } break;
+          case K_NFW: {
+            float acc[NFW_NACC];
+#pragma unroll
+            for (int k = 0; k < NFW_NACC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) nfw_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
+            wave_acc<NFW_NACC>(acc, s_row + cd.a_off, lane);
+          } break;
+          case K_SHEAR: {
+            float acc[SHR_NACC];
+            acc[0] = 0.f; acc[1] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) shear_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
+            wave_acc<SHR_NACC>(acc, s_row + cd.a_off, lane);
+          } break;
+          case K_SIS: {
+            float acc[SIS_NACC];
+            acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) sis_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
+            wave_acc<SIS_NACC>(acc, s_row + cd.a_off, lane);
+          } break;
+        }
+      }
+    }
+  }
+  if (MODE == IMG_FWD) return;
+  if (MODE == LL_FWD || MODE == LL_GRAD) wave_acc<2>(st, s_row, lane);
+  __syncthreads();
+  float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
+  for (int k = tid; k < a.A; k += WG)
+    out[k] = (s_acc[k] + s_acc[a.Apad + k]) + (s_acc[2 * a.Apad + k] + s_acc[3 * a.Apad + k]);
+}
+
+// ---- finalize: sum chunk partials (fixed order), chain rule to raw parameters -------------------
+__global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __restrict__ comps, int n_comp,
+                                                          const float* __restrict__ params, int P,
+                                                          const float* __restrict__ partial, int n_chunks, int A,
+                                                          float* __restrict__ loglike, float* __restrict__ chi2,
+                                                          float* __restrict__ grad) {
+  extern __shared__ float s[];
+  const int b = blockIdx.x;
+  const float* src = partial + (size_t)b * n_chunks * A;
+  for (int k = threadIdx.x; k < A; k += 128) {
+    float v = 0.f;
+    for (int ch = 0; ch < n_chunks; ++ch) v += src[(size_t)ch * A + k];
+    s[k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && loglike) {
+    loglike[b] = -0.5f * (s[0] + s[1]);  // tf/model.py:99
+    chi2[b] = s[0];
+  }
+  if (!grad) return;
+  for (int c = threadIdx.x; c < n_comp; c += 128) {
+    CompDesc cd = comps[c];
+    const float* p = params + (size_t)b * P + cd.p_off;
+    float* g = grad + (size_t)b * P + cd.p_off;
+    const float* acc = s + cd.a_off;
+    switch (cd.kind) {
+      case K_EPL: epl_finalize<float>(p, acc, g); break;
+      case K_SIE: sie_finalize<float>(p, acc, g); break;
+      case K_NFW: nfw_finalize<float>(p, acc, g); break;
+      case K_SHEAR: shear_finalize<float>(p, acc, g); break;
+      case K_SIS: sis_finalize<float>(p, acc, g); break;
+      case K_SERSIC: sersic_finalize<float>(p, false, acc, g); break;
+      case K_SERSIC_ELLIPSE: sersic_finalize<float>(p, true, acc, g); break;
+      case K_SHAPELETS: shapelets_finalize<float>(p, cd.iparam, acc, g); break;
+    }
+  }
+}
+
+// ---- plugin-level point evaluation (MassProfile.deriv / LightProfile.light on arbitrary points) ----
+__global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float* __restrict__ x,
+                                                       const float* __restrict__ y, long long n_pts, int B,
+                                                       int xy_batched, const float* __restrict__ params,
+                                                       float* __restrict__ out0, float* __restrict__ out1,
+                                                       const float* __restrict__ shp_tab, int shp_stride) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pts * B) return;
+  long long pt = i / B;
+  int b = (int)(i - pt * B);
+  float px = xy_batched ? x[i] : x[pt], py = xy_batched ? y[i] : y[pt];
+  const float* p = params + (size_t)b * cd.n_par;
+  float o0 = 0.f, o1 = 0.f;
+  switch (cd.kind) {
+    case K_EPL: epl_point<float>(p, cd.iparam, px, py, o0, o1); break;
+    case K_SIE: { float d[SIE_ND + 1]; sie_prep<float>(p, d); sie_fwd(d, px, py, o0, o1); } break;
+    case K_NFW: { float d[NFW_ND]; nfw_prep<float>(p, d); nfw_fwd(d, px, py, o0, o1); } break;
+    case K_SHEAR: { float d[4]; shear_prep<float>(p, d); shear_fwd(d, px, py, o0, o1); } break;
+    case K_SIS: { float d[4]; sis_prep<float>(p, d); sis_fwd(d, px, py, o0, o1); } break;
+    case K_SERSIC: { float d[SER_ND + 2]; sersic_prep<float>(p, false, d); o0 = sersic_fwd(d, px, py); } break;
+    case K_SERSIC_ELLIPSE: { float d[SER_ND + 2]; sersic_prep<float>(p, true, d); o0 = sersic_fwd(d, px, py); } break;
+    case K_SHAPELETS: {
+      float d[SHP_AMP + 68];
+      shapelets_prep<float>(p, cd.iparam, d);
+      o0 = shapelets_fwd<float, SH_CAP>(d, shp_tab, shp_stride, cd.flags & 1u, px, py);
+    } break;
+  }
+  out0[i] = o0;
+  if (out1) out1[i] = o1;
+}
+
+}  // namespace glk

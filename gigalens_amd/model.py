@@ -1,0 +1,265 @@
+"""``PhysicalModel`` and ``ForwardProbModel`` with the reference's surface
+(src/gigalens/model.py:7-73, src/gigalens/tf/model.py:12-194,276-306).
+
+``ForwardProbModel.log_prob(simulator, z)`` returns ``(log_prob, red_chi2)`` exactly like the reference;
+the pixel log-likelihood and its gradient w.r.t. every profile parameter come from ONE fused HIP launch
+sequence (prep -> main -> finalize, see csrc/gl_kernels.hip.h); prior densities and bijectors are a few
+elementwise torch ops on ``(B, d)``.
+"""
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from gigalens_amd import _native
+from gigalens_amd import prior as _prior
+
+_GROUPS = ("lens_mass", "lens_light", "source_light")
+
+
+class _Packing:
+    """Map between the reference's nested parameter structure and the native ``[B, P]`` rows
+    (component-major: lenses, lens light, source light; inside a component the reference's
+    ``params`` order).  Fixed parameters come from the ``*_constants`` dicts (model.py:29-44)."""
+
+    def __init__(self, phys_model):
+        self.slots = []  # (group, index, name, const_value_or_None)
+        groups = ((phys_model.lenses, phys_model.lenses_constants),
+                  (phys_model.lens_light, phys_model.lens_light_constants),
+                  (phys_model.source_light, phys_model.source_light_constants))
+        for gname, (profiles, consts) in zip(_GROUPS, groups):
+            for i, (prof, c) in enumerate(zip(profiles, consts)):
+                for name in prof.params:
+                    self.slots.append((gname, i, name, c.get(name)))
+        self.P = len(self.slots)
+
+    def pack(self, params: Dict[str, List[Dict]], bs: int, device):
+        cols = []
+        for gname, i, name, const in self.slots:
+            grp = params.get(gname)
+            v = grp[i].get(name) if grp is not None and i < len(grp) else None
+            if v is None:
+                v = const
+            if v is None:
+                raise KeyError(f"parameter {gname}[{i}]['{name}'] is neither given nor a model constant")
+            v = torch.as_tensor(v, dtype=torch.float32, device=device)
+            cols.append(v.reshape(-1).expand(bs) if v.numel() != bs else v.reshape(bs))
+        if not cols:
+            return torch.zeros((bs, 0), dtype=torch.float32, device=device)
+        return torch.stack(cols, dim=1)
+
+
+class PhysicalModelBase:
+    """src/gigalens/model.py:7-44."""
+
+    def __init__(self, lenses, lens_light, source_light, lenses_constants: List[Dict] = None,
+                 lens_light_constants: List[Dict] = None, source_light_constants: List[Dict] = None):
+        self.lenses = lenses
+        self.lens_light = lens_light
+        self.source_light = source_light
+        if lenses_constants is None:
+            lenses_constants = [dict() for _ in range(len(lenses))]
+        if lens_light_constants is None:
+            lens_light_constants = [dict() for _ in range(len(lens_light))]
+        if source_light_constants is None:
+            source_light_constants = [dict() for _ in range(len(source_light))]
+        self.lenses_constants = lenses_constants
+        self.lens_light_constants = lens_light_constants
+        self.source_light_constants = source_light_constants
+
+
+class PhysicalModel(PhysicalModelBase):
+    """src/gigalens/tf/model.py:276-306: constants are cast to float32."""
+
+    def __init__(self, lenses, lens_light, source_light, lenses_constants: List[Dict] = None,
+                 lens_light_constants: List[Dict] = None, source_light_constants: List[Dict] = None):
+        super().__init__(lenses, lens_light, source_light, lenses_constants, lens_light_constants,
+                         source_light_constants)
+        cast = lambda ds: [{k: np.asarray(v, dtype=np.float32) for k, v in d.items()} for d in ds]
+        self.lenses_constants = cast(self.lenses_constants)
+        self.lens_light_constants = cast(self.lens_light_constants)
+        self.source_light_constants = cast(self.source_light_constants)
+
+    def _packing(self):
+        return _Packing(self)
+
+
+class ProbabilisticModel:
+    """src/gigalens/model.py:47-73."""
+
+    def __init__(self, prior, bij=None, *args):
+        self.prior = prior
+        self.bij = bij
+
+    def log_prob(self, simulator, z):
+        raise NotImplementedError
+
+
+class _LogLikeFn(torch.autograd.Function):
+    """autograd glue around gl_loglike_fwd_bwd: the gradient w.r.t. the packed parameters is produced
+    by the same fused pass as the value and kept for ``backward``."""
+
+    @staticmethod
+    def forward(ctx, packed, model, obs, err, mask, bg_rms, exp_time):
+        want = packed.requires_grad
+        ll, chi2, grad = model.loglike(packed.detach(), obs, err, mask, bg_rms, exp_time, want)
+        ctx.has_grad = want
+        if want:
+            ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(chi2)
+        return ll, chi2
+
+    @staticmethod
+    def backward(ctx, g_ll, g_chi2):
+        (grad,) = ctx.saved_tensors
+        return g_ll[:, None] * grad, None, None, None, None, None, None
+
+
+class _PackBijector:
+    """``pack_bij`` (tf/model.py:78-85): ``(B, d)`` <-> nested structure, column k = k-th nest leaf."""
+
+    def __init__(self, template):
+        self.template = template
+        self.d = len(_prior.nest_flatten(template))
+
+    def forward(self, z):
+        return _prior.nest_pack(self.template, [z[..., k] for k in range(self.d)])
+
+    def inverse(self, struct):
+        leaves = [torch.as_tensor(v, dtype=torch.float32) for v in _prior.nest_flatten(struct)]
+        dev = next((v.device for v in leaves if v.is_cuda), leaves[0].device)
+        return torch.stack(torch.broadcast_tensors(*[v.to(dev) for v in leaves]), dim=-1)
+
+
+class _ChainBijector:
+    """``bij = Chain([unconstraining_bij, pack_bij])`` (tf/model.py:87)."""
+
+    def __init__(self, unconstraining, pack):
+        self.unconstraining, self.pack = unconstraining, pack
+
+    def forward(self, z):
+        return self.unconstraining.forward(self.pack.forward(z))
+
+    def inverse(self, x_struct):
+        return self.pack.inverse(self.unconstraining.inverse(x_struct))
+
+
+class ForwardProbModel(ProbabilisticModel):
+    """Drop-in for ``gigalens.tf.model.ForwardProbModel`` (tf/model.py:12-194), pixel branch.
+
+    The image-position branch (``stats_positions``) is a later row: constructing with
+    ``include_positions=True`` *and* centroids raises ``NotImplementedError``; with the reference's
+    default ``include_positions=True`` and no centroids the reference itself fails (it iterates ``None``,
+    tf/model.py:69-70), so that combination raises ``TypeError`` here too.
+    """
+
+    def __init__(self, prior, observed_image=None, background_rms=None, exp_time=None, error_map=None,
+                 centroids_x=None, centroids_y=None, centroids_errors_x=None, centroids_errors_y=None,
+                 include_pixels=True, include_positions=True):
+        super().__init__(prior)
+        self.include_pixels = include_pixels
+        self.include_positions = include_positions
+        # host logic (prior, bijectors) also runs without a GPU; the likelihood itself never does
+        self.device = _native.device() if torch.cuda.is_available() else torch.device("cpu")
+        self.observed_image = None
+        self.error_map = None
+        self.background_rms = None
+        self.exp_time = None
+        if self.include_pixels:
+            self.observed_image = torch.as_tensor(np.asarray(observed_image, dtype=np.float32), device=self.device).contiguous()
+            if error_map is not None:
+                self.error_map = torch.as_tensor(np.asarray(error_map, dtype=np.float32), device=self.device).contiguous()
+            else:
+                self.background_rms = float(np.float32(background_rms))
+                self.exp_time = float(np.float32(exp_time))
+        if self.include_positions:
+            if centroids_x is None:
+                raise TypeError("include_positions=True needs centroids_x/centroids_y (the reference iterates them, "
+                                "tf/model.py:69-70); pass include_positions=False for a pixel-only model")
+            raise NotImplementedError("image-position likelihood (stats_positions) is not built yet (SURVEY 8f-2)")
+        self._flat = prior.flat(self.device)
+        example = prior.sample(seed=0)
+        self.pack_bij = _PackBijector(example)
+        self.unconstraining_bij = _prior.JointBijector(self._flat)
+        self.bij = _ChainBijector(self.unconstraining_bij, self.pack_bij)
+        self._paths = _prior.nest_paths(example)
+        self._perm_cache = {}
+
+    # ---- z columns -> native packed rows, without materialising the nested structure ----------------
+    def _perm(self, simulator):
+        key = id(simulator._layout)
+        hit = self._perm_cache.get(key)
+        if hit is None:
+            index = {}
+            for k, path in enumerate(self._paths):
+                if len(path) != 3 or path[0] not in _GROUPS:
+                    raise ValueError(f"prior leaf {path} does not follow {{group: [ {{name: dist}} ]}}")
+                index[path] = k
+            d = len(self._paths)
+            cols, consts = [], []
+            for gname, i, name, const in simulator._layout.slots:
+                k = index.get((gname, i, name))
+                if k is not None:
+                    cols.append(k)
+                elif const is not None:
+                    cols.append(d + len(consts))
+                    consts.append(float(np.asarray(const, dtype=np.float32).reshape(-1)[0]))
+                else:
+                    raise KeyError(f"{gname}[{i}]['{name}'] has neither a prior nor a constant")
+            hit = (torch.tensor(cols, dtype=torch.int64, device=self.device),
+                   torch.tensor(consts, dtype=torch.float32, device=self.device))
+            self._perm_cache = {key: hit}
+        return hit
+
+    def _packed_from_x(self, simulator, x):
+        cols, consts = self._perm(simulator)
+        if consts.numel():
+            x = torch.cat([x, consts.expand(x.shape[0], -1)], dim=1)
+        return x.index_select(1, cols)
+
+    def _pixel_stats_packed(self, simulator, packed):
+        if simulator.supersample != 1 or simulator.kernel is not None:
+            raise NotImplementedError("pixel likelihood with PSF / supersampling is not built yet")
+        ll, chi2 = _LogLikeFn.apply(packed, simulator._model, self.observed_image, self.error_map,
+                                    simulator.img_region if simulator.sim_config.pix_region is not None else None,
+                                    self.background_rms or 0.0, self.exp_time or 1.0)
+        n_eff = torch.count_nonzero(simulator.img_region).to(torch.float32)
+        return ll, chi2 / n_eff  # tf/model.py:100
+
+    def stats_pixels(self, simulator, params):
+        """tf/model.py:89-101: ``params`` is the nested constrained structure."""
+        return self._pixel_stats_packed(simulator, simulator.pack(params))
+
+    def log_prob(self, simulator, z):
+        """tf/model.py:126-167: ``z`` is ``(bs, d)`` unconstrained; returns ``(log_prob, red_chi2)``."""
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        x = self._flat.forward(z)
+        log_like = torch.zeros(z.shape[0], dtype=torch.float32, device=self.device)
+        red_chi2 = torch.zeros_like(log_like)
+        n_chi = 0
+        if self.include_pixels:
+            ll, rc = self._pixel_stats_packed(simulator, self._packed_from_x(simulator, x))
+            log_like = log_like + ll
+            red_chi2 = red_chi2 + rc
+            n_chi += 1
+        red_chi2 = red_chi2 / max(n_chi, 1)
+        log_prior = self._flat.log_prob(x) + self._flat.fldj_columns(z).sum(-1)
+        return log_like + log_prior, red_chi2
+
+    def log_like(self, simulator, z):
+        """tf/model.py:169-180."""
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        x = self._flat.forward(z)
+        ll = torch.zeros(z.shape[0], dtype=torch.float32, device=self.device)
+        if self.include_pixels:
+            ll = ll + self._pixel_stats_packed(simulator, self._packed_from_x(simulator, x))[0]
+        return ll
+
+    def log_prior(self, z):
+        """tf/model.py:182-185."""
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        return self._flat.log_prob(self._flat.forward(z)) + self._flat.fldj_columns(z).sum(-1)
+
+    def init_centroids(self, bs):
+        """tf/model.py:187-194 (no-op without the position branch)."""
+        return None

@@ -1,0 +1,61 @@
+"""Plugin ABCs with the reference's names and attribute semantics (src/gigalens/profile.py:5-83).
+
+A profile here is a *descriptor* -- a kind id plus the reference's parameter-name list -- that the
+native library interprets; ``deriv`` / ``light`` keep the reference's call signature and evaluate on
+the GPU through ``gl_profile_eval`` (include/gigalens_hip.h).
+"""
+from abc import ABC
+from typing import List
+
+from gigalens_amd import _native
+
+
+class Parameterized(ABC):
+    """src/gigalens/profile.py:5-21."""
+
+    _name: str
+    _params: List[str]
+    _kind: int = 0  # gl_kind
+
+    def __init__(self, *args, **kwargs):
+        self.name = self._name
+        self.params = list(self._params)
+
+    def __str__(self):
+        return self.name
+
+    # descriptor consumed by gl_model_create / gl_profile_eval
+    def _component(self):
+        return (self._kind, 0, 0)
+
+
+class LightProfile(Parameterized, ABC):
+    """src/gigalens/profile.py:24-60.  ``use_lstsq`` removes the amplitude from ``params``
+    (profile.py:40-41); the least-squares solve itself is a later row."""
+
+    _amp = ""
+
+    def __init__(self, use_lstsq=False, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._use_lstsq = use_lstsq
+        self.depth = 1
+        if not self.use_lstsq:
+            self.params.append(self._amp)
+
+    @property
+    def use_lstsq(self):
+        return self._use_lstsq
+
+    def light(self, x, y, **kwargs):
+        """Surface brightness at ``(x, y)``; parameters broadcast on the last axis like the reference."""
+        if self.use_lstsq:
+            raise NotImplementedError("use_lstsq=True (linear amplitude solve) is not built yet")
+        return _native.profile_eval(self, x, y, kwargs)[0]
+
+
+class MassProfile(Parameterized, ABC):
+    """src/gigalens/profile.py:63-82."""
+
+    def deriv(self, x, y, **kwargs):
+        """Deflection ``(alpha_x, alpha_y)`` at ``(x, y)``."""
+        return _native.profile_eval(self, x, y, kwargs)

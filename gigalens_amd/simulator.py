@@ -1,0 +1,165 @@
+"""``SimulatorConfig`` / ``LensWCS`` / ``LensSimulator`` with the reference's surface
+(src/gigalens/simulator.py:11-127, src/gigalens/tf/simulator.py:13-156), executing on HIP kernels.
+
+Differences in HOW (not WHAT): the pixel grid is stored once as two ``(N,)`` device arrays instead of
+``(N, bs)`` replicas (the reference's own ``# TODO: no need for batched grid``, tf/simulator.py:11);
+ray-shooting, rendering, NaN->0 and the det(T) scale are one fused kernel; gradients come from
+hand-written VJP kernels wrapped in a ``torch.autograd.Function``.
+"""
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from gigalens_amd import _native
+
+
+@dataclass
+class SimulatorConfig:
+    """src/gigalens/simulator.py:11-29 (field for field)."""
+
+    delta_pix: float
+    num_pix: int
+    supersample: Optional[int] = 1
+    kernel: Optional[Any] = None
+    transform_pix2angle: Optional[np.array] = None
+    pix_region: Optional[np.array] = None
+
+
+class LensWCS:
+    """Pixel <-> angle transform, src/gigalens/simulator.py:32-64, quirks included: ``pix2angle``
+    applies T^T while the origin uses T (:50,53); ``transform_angle2pix`` inverts the un-supersampled
+    T (:37-38); ``pixel_grid`` uses ``n_y`` for both axes (:62)."""
+
+    def __init__(self, n, supersample=1, transform_pix2angle=None, pix_scale=1.0):
+        if transform_pix2angle is None:
+            transform_pix2angle = np.eye(2) * pix_scale
+        transform_pix2angle = np.asarray(transform_pix2angle, dtype=np.float64)
+        self.transform_pix2angle = transform_pix2angle / supersample
+        self.transform_angle2pix = np.linalg.inv(transform_pix2angle)
+        if isinstance(n, (int, np.integer)):
+            self.n_x, self.n_y = int(n), int(n)
+        else:
+            self.n_x, self.n_y = n
+        self.supersample = supersample
+        low_x = -(self.n_x * self.supersample - 1) / 2
+        low_y = -(self.n_y * self.supersample - 1) / 2
+        self.radec_at_xy_0 = np.squeeze(self.transform_pix2angle @ np.array([[low_x], [low_y]]))
+
+    def pix2angle(self, x, y):
+        xy = np.stack([np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)])
+        radec = np.tensordot(self.transform_pix2angle.T, xy, axes=1)
+        ra = radec[0] + self.radec_at_xy_0[0]
+        dec = radec[1] + self.radec_at_xy_0[1]
+        return ra.astype(np.float32), dec.astype(np.float32)
+
+    def angle2pix(self, ra, dec):
+        radec = np.stack([np.asarray(ra, dtype=np.float64) - self.radec_at_xy_0[0],
+                          np.asarray(dec, dtype=np.float64) - self.radec_at_xy_0[1]])
+        return np.tensordot(self.transform_angle2pix.T, radec, axes=1).astype(np.float32)
+
+    def pixel_grid(self):
+        x = np.arange(self.n_y * self.supersample)
+        X, Y = np.meshgrid(x, x)
+        return self.pix2angle(X, Y)
+
+
+class LensSimulatorInterface:
+    """src/gigalens/simulator.py:67-127."""
+
+    def __init__(self, phys_model, sim_config: SimulatorConfig, bs: int):
+        self.phys_model = phys_model
+        self.sim_config = sim_config
+        self.bs = bs
+        self.wcs = LensWCS(n=sim_config.num_pix, supersample=sim_config.supersample,
+                           transform_pix2angle=sim_config.transform_pix2angle, pix_scale=sim_config.delta_pix)
+
+
+class _SimulateFn(torch.autograd.Function):
+    """autograd glue: forward = gl_simulate_fwd, backward = gl_simulate_bwd (both HIP)."""
+
+    @staticmethod
+    def forward(ctx, params, model):
+        ctx.model = model
+        ctx.save_for_backward(params)
+        return model.simulate_fwd(params)
+
+    @staticmethod
+    def backward(ctx, grad_img):
+        (params,) = ctx.saved_tensors
+        return ctx.model.simulate_bwd(params, grad_img), None
+
+
+class LensSimulator(LensSimulatorInterface):
+    """Drop-in for ``gigalens.tf.simulator.LensSimulator`` (tf/simulator.py:13-156).
+
+    Attributes kept from the reference: ``img_X``, ``img_Y`` (here ``(N,)``, not ``(N, bs)``), ``img_region``,
+    ``region``, ``bs``, ``wcs``, ``supersample``, ``conversion_factor``.
+    """
+
+    def __init__(self, phys_model, sim_config: SimulatorConfig, bs: int):
+        super().__init__(phys_model, sim_config, bs)
+        self.device = _native.device()
+        self.supersample = int(sim_config.supersample)
+        T = (np.eye(2) * sim_config.delta_pix if sim_config.transform_pix2angle is None
+             else np.asarray(sim_config.transform_pix2angle, dtype=np.float64))
+        # tf/simulator.py:27-29: det of the un-supersampled transform, in float32
+        self.conversion_factor = float(np.float32(np.linalg.det(T.astype(np.float32))))
+        ss = self.supersample
+        Hs, Ws = self.wcs.n_x * ss, self.wcs.n_y * ss
+        if sim_config.pix_region is None:  # tf/simulator.py:34-42
+            region = np.ones((Hs, Ws), dtype=bool)
+            img_region = np.ones((self.wcs.n_x, self.wcs.n_y))
+        else:
+            img_region = np.asarray(sim_config.pix_region)
+            region = np.repeat(np.repeat(img_region, ss, axis=0), ss, axis=1).astype(bool)
+        self._region_np = np.argwhere(region)  # == tf.where: row-major [row, col]
+        img_X, img_Y = self.wcs.pix2angle(self._region_np[:, 1], self._region_np[:, 0])
+        full = self._region_np.shape[0] == Hs * Ws
+        pix_index = None if full else (self._region_np[:, 0] * Ws + self._region_np[:, 1]).astype(np.int32)
+        self.region = torch.from_numpy(self._region_np).to(self.device)
+        self.img_region = torch.from_numpy(img_region.astype(np.float32)).to(self.device)
+        self.img_X = torch.from_numpy(img_X).to(self.device)
+        self.img_Y = torch.from_numpy(img_Y).to(self.device)
+        self.numPix = sim_config.num_pix
+        self.depth = len(phys_model.lens_light) + len(phys_model.source_light)
+        psf = None
+        if sim_config.kernel is not None:
+            psf = np.asarray(sim_config.kernel, dtype=np.float32)
+            if ss != 1:
+                raise NotImplementedError(
+                    "supersample > 1 with a PSF needs lenstronomy's subgrid_kernel (third party, not restated); "
+                    "pass a kernel already sampled on the supersampled grid via LensSimulator.from_supersampled_kernel")
+        self.kernel = psf
+        comps = ([_native.component_of(p) for p in phys_model.lenses]
+                 + [_native.component_of(p) for p in phys_model.lens_light]
+                 + [_native.component_of(p) for p in phys_model.source_light])
+        self._model = _native.Model(comps, len(phys_model.lenses), len(phys_model.lens_light),
+                                    len(phys_model.source_light), Hs, Ws, ss, img_X, img_Y, pix_index,
+                                    self.conversion_factor, psf)
+        self._layout = phys_model._packing()
+        assert self._layout.P == self._model.P
+
+    # -- packing between the reference's nested parameter dicts and the native [B, P] rows ---------
+    def pack(self, params: Dict[str, List[Dict]]):
+        return self._layout.pack(params, self.bs, self.device)
+
+    def beta(self, x, y, lens_params: List[Dict]):
+        """tf/simulator.py:72-78 on arbitrary points (plugin-level kernels, one per lens)."""
+        beta_x, beta_y = x, y
+        for lens, p, c in zip(self.phys_model.lenses, lens_params, self.phys_model.lenses_constants):
+            f_xi, f_yi = lens.deriv(x, y, **p, **c)
+            beta_x, beta_y = beta_x - f_xi, beta_y - f_yi
+        return beta_x, beta_y
+
+    def simulate(self, params, no_deflection=False):
+        """tf/simulator.py:109-156.  Returns ``(bs, H, W)`` squeezed like ``tf.squeeze``."""
+        if no_deflection:
+            raise NotImplementedError("no_deflection=True is not built yet")
+        packed = params if torch.is_tensor(params) else self.pack(params)
+        img = _SimulateFn.apply(packed, self._model)
+        return torch.squeeze(img)
+
+    def lstsq_simulate(self, params, observed_image, err_map, **kw):
+        raise NotImplementedError("lstsq_simulate (linear amplitude solve) is a later row (SURVEY 8f-4)")

@@ -1,0 +1,132 @@
+/* gigalens_hip.h -- C ABI of the MI355X-native gigalens hot path.
+ *
+ * Plain pointers and sizes only: no torch / C++ types cross this boundary.
+ * Every device buffer is owned by the caller (PyTorch in this repo); the
+ * library allocates device memory only inside gl_model_create (the immutable
+ * model descriptor, grid and PSF) and never per call, so every entry point is
+ * hipGraph-capturable.  All arithmetic is fp32, as in the reference
+ * (every constant there is tf.float32: tf/simulator.py:27-32,46-51;
+ * tf/model.py:63-68,301-306).
+ *
+ * The reference (furcelay/gigalens) has no FFI -- its plugin boundary is a set
+ * of Python ABCs.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference repo root).  INTEGRATION.md shows
+ * the ctypes stub a reference maintainer would add.
+ */
+#ifndef GIGALENS_HIP_H
+#define GIGALENS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error convention: 0 on success, negative gl_status otherwise; the message is
+ * available through gl_last_error() (thread local).  Numerical NaN is data,
+ * not an error (mirrors the reference: tf/simulator.py:140, tf/inference.py:44). */
+typedef enum gl_status {
+  GL_OK = 0,
+  GL_EINVAL = -1,       /* bad argument (null pointer, negative size, unknown kind) */
+  GL_EUNSUPPORTED = -2, /* valid request this build cannot serve */
+  GL_ELAUNCH = -3,      /* HIP runtime / launch failure */
+  GL_ENOMEM = -4,       /* allocation failure in gl_model_create, or workspace too small */
+  GL_ENODEVICE = -5     /* no HIP device */
+} gl_status;
+
+/* Profile kinds.  Parameter order inside the packed parameter row is the
+ * reference's `_params` list (+ `_amp` for light profiles, profile.py:40-41). */
+typedef enum gl_kind {
+  /* mass profiles: MassProfile.deriv (profile.py:63-82) */
+  GL_EPL = 1,   /* tf/profiles/mass/epl.py:13   [theta_E,gamma,e1,e2,center_x,center_y] */
+  GL_SIE = 2,   /* tf/profiles/mass/sie.py:8    [theta_E,e1,e2,center_x,center_y] */
+  GL_NFW = 3,   /* tf/profiles/mass/nfw.py:8    [Rs,alpha_Rs,center_x,center_y] */
+  GL_SHEAR = 4, /* tf/profiles/mass/shear.py:8  [gamma1,gamma2] */
+  GL_SIS = 5,   /* tf/profiles/mass/sis.py:7    [theta_E,center_x,center_y] */
+  /* light profiles: LightProfile.light (profile.py:24-60) */
+  GL_SERSIC = 16,         /* tf/profiles/light/sersic.py:23-24 [R_sersic,n_sersic,center_x,center_y,Ie] */
+  GL_SERSIC_ELLIPSE = 17, /* sersic.py:68-69 [R_sersic,n_sersic,e1,e2,center_x,center_y,Ie] */
+  GL_SHAPELETS = 18       /* tf/profiles/light/shapelets.py:18,34-36 [beta,center_x,center_y,amp0..amp{L-1}] */
+} gl_kind;
+
+#define GL_SHAPELETS_NMAX_CAP 10 /* largest n_max the register-resident shapelet path serves */
+#define GL_SHAPELETS_TABLE_NODES 6000
+#define GL_FLAG_SHAPELETS_INTERPOLATE 1u /* shapelets.py:20 interpolate=True (table mode) */
+
+typedef struct gl_component {
+  int32_t kind;   /* gl_kind */
+  int32_t iparam; /* EPL: niter cap (epl.py:15, default 50); SHAPELETS: n_max; else 0 */
+  uint32_t flags; /* GL_FLAG_* */
+  int32_t reserved;
+} gl_component;
+
+/* Pixel grid and camera set-up == what LensSimulator.__init__ precomputes
+ * (tf/simulator.py:14-70).  All pointers are HOST pointers, copied at create. */
+typedef struct gl_grid {
+  int32_t height;      /* rows of the supersampled image  (wcs.n_x * supersample) */
+  int32_t width;       /* cols of the supersampled image  (wcs.n_y * supersample) */
+  int32_t supersample; /* simulator.py:27 */
+  int32_t n_region;    /* N = number of evaluated pixels (rows of tf.where(region), tf/simulator.py:43) */
+  const float* grid_x; /* [N] img_X, f64 arithmetic cast to f32 (simulator.py:52-55) */
+  const float* grid_y; /* [N] img_Y */
+  const int32_t* pix_index; /* [N] row*width+col of each evaluated pixel, or NULL == full grid in row-major order */
+  float conversion_factor;  /* det(transform_pix2angle) of the un-supersampled transform (tf/simulator.py:27-29) */
+  const float* psf;    /* [psf_h*psf_w] PSF already sampled on the supersampled grid and NOT flipped, or NULL
+                          (tf/simulator.py:62-70 flips it and cross-correlates, i.e. a true convolution) */
+  int32_t psf_h, psf_w;
+} gl_grid;
+
+typedef struct gl_model gl_model; /* opaque, immutable after create; safe to share between host threads */
+
+/* Build the model descriptor for PhysicalModel(lenses, lens_light, source_light)
+ * (model.py:24-44, tf/model.py:290-306) on LensSimulator's grid.  `comps` lists the
+ * n_lens mass profiles, then n_lens_light, then n_src light profiles. */
+int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int n_src,
+                    const gl_grid* grid, gl_model** out);
+void gl_model_destroy(gl_model* m);
+
+int gl_model_num_params(const gl_model* m);    /* P: packed constrained parameters per sample */
+int gl_model_param_offset(const gl_model* m, int component); /* column of the component's first parameter */
+int64_t gl_model_num_pixels(const gl_model* m); /* N */
+
+/* Bytes of caller-owned scratch the calls below need for a batch of B samples. */
+size_t gl_workspace_bytes(const gl_model* m, int B);
+
+/* LensSimulator.simulate (tf/simulator.py:109-156): params [B,P] -> img [B,H,W]
+ * (H = height/supersample, W = width/supersample), NaN->0, PSF, average-pool, x conversion_factor. */
+int gl_simulate_fwd(const gl_model* m, const float* params, int B, float* img,
+                    void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Vector-Jacobian product of the above (what tf.GradientTape supplies, tf/inference.py:33-39):
+ * grad_img [B,H,W] -> grad_params [B,P]. */
+int gl_simulate_bwd(const gl_model* m, const float* params, const float* grad_img, int B,
+                    float* grad_params, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ForwardProbModel.stats_pixels (tf/model.py:89-101) fused with simulate() and, when
+ * grad_params != NULL, with its gradient d loglike / d params [B,P].
+ *   obs [H,W]; err_or_null [H,W] (error_map, wins over bg_rms/exp_time, tf/model.py:92-95);
+ *   mask_or_null [H,W] (simulator.img_region weights); loglike [B]; chi2 [B] (= chi^2, NOT reduced);
+ *   red_chi2 = chi2 / count_nonzero(mask) is returned through chi2_count (host scalar, may be NULL). */
+int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs, const float* err_or_null,
+                       const float* mask_or_null, float bg_rms, float exp_time, int B, float* loglike,
+                       float* chi2, float* grad_params_or_null, void* workspace, size_t workspace_bytes,
+                       void* hip_stream);
+
+/* Plugin-level point evaluation, the reference's MassProfile.deriv / LightProfile.light called on
+ * arbitrary coordinates (tests/test_profiles.py calls exactly these):
+ *   x, y [n_pts, B] when xy_batched, else [n_pts] shared by every sample (pixel-major, batch-minor
+ *   like the reference, tf/simulator.py:45-51); params [B, n_params(kind)];
+ *   out0/out1 [n_pts, B]: (alpha_x, alpha_y) for mass kinds; out0 = light for light kinds (out1 unused). */
+int gl_profile_eval(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B,
+                    int xy_batched, const float* params, float* out0, float* out1, void* hip_stream);
+
+int gl_kind_num_params(const gl_component* comp); /* length of the reference's params list for this profile */
+
+const char* gl_last_error(void);
+const char* gl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIGALENS_HIP_H */

@@ -1,0 +1,452 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Op-for-op CPU restatement, in torch, of the reference's TF substrate for the
+hot path: grid -> ray-shoot -> light render -> NaN->0 -> [PSF, pool] -> chi^2
+log-likelihood.  It keeps the reference's *unfused* tensor algebra: every
+intermediate is an ``(N_pix, B)`` tensor, the grid is replicated per batch
+element, the EPL series is a data-dependent loop with a batch-max trip count,
+and gradients come from ``torch.autograd`` (the stand-in for ``tf.GradientTape``).
+
+It is dtype-generic: ``float64`` is the parity oracle, ``float32`` is the
+"reference algorithm restated on torch-CPU" baseline that ``bench.py`` times.
+
+All citations are ``path:line`` relative to ``/root/reference/``.
+Profiles are dispatched by duck-typing on ``profile.name`` (the reference's
+``_name`` strings), so any object carrying ``name`` (+ ``n_max``/``interpolate``/
+``niter`` where relevant) works -- including the product's profile classes.
+"""
+import math
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+LN2 = math.log(2.0)
+
+
+def _t(v, like):
+    """Broadcast helper: python scalars / tensors -> tensor of like's dtype."""
+    if torch.is_tensor(v):
+        return v.to(like.dtype)
+    return torch.as_tensor(v, dtype=like.dtype)
+
+
+# --------------------------------------------------------------------------
+# grid  (src/gigalens/simulator.py:32-64)
+# --------------------------------------------------------------------------
+class LensWCS:
+    """src/gigalens/simulator.py:32-64, incl. its quirks: ``pix2angle`` applies
+    T^T (einsum 'ij,i...->...j', :53) while the origin uses T (:50);
+    ``transform_angle2pix`` inverts the un-supersampled T (:37-38)."""
+
+    def __init__(self, n, supersample=1, transform_pix2angle=None, pix_scale=1.0):
+        if transform_pix2angle is None:
+            transform_pix2angle = np.eye(2) * pix_scale
+        transform_pix2angle = np.asarray(transform_pix2angle, dtype=np.float64)
+        self.transform_pix2angle = transform_pix2angle / supersample
+        self.transform_angle2pix = np.linalg.inv(transform_pix2angle)
+        if isinstance(n, int):
+            self.n_x, self.n_y = n, n
+        else:
+            self.n_x, self.n_y = n
+        self.supersample = supersample
+        low_x = -(self.n_x * supersample - 1) / 2
+        low_y = -(self.n_y * supersample - 1) / 2
+        self.radec_at_xy_0 = np.squeeze(self.transform_pix2angle @ np.array([[low_x], [low_y]]))
+
+    def pix2angle(self, x, y):
+        v = np.stack([np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)])
+        T = self.transform_pix2angle
+        ra = T[0, 0] * v[0] + T[1, 0] * v[1] + self.radec_at_xy_0[0]
+        dec = T[0, 1] * v[0] + T[1, 1] * v[1] + self.radec_at_xy_0[1]
+        return ra.astype(np.float32), dec.astype(np.float32)
+
+
+def build_grid(sim_config):
+    """tf/simulator.py:34-51.  Returns (region (N,2) [row,col], img_region (H,W),
+    img_X (N,), img_Y (N,)) with the grid as float32 numpy (f64 arithmetic, then cast)."""
+    ss = int(sim_config.supersample)
+    wcs = LensWCS(n=sim_config.num_pix, supersample=ss,
+                  transform_pix2angle=sim_config.transform_pix2angle,
+                  pix_scale=sim_config.delta_pix)
+    if sim_config.pix_region is None:
+        region = np.ones((wcs.n_x * ss, wcs.n_y * ss), dtype=bool)
+        img_region = np.ones((wcs.n_x, wcs.n_y))
+    else:
+        img_region = np.asarray(sim_config.pix_region)
+        region = np.repeat(img_region, ss, axis=0).reshape(wcs.n_x * ss, wcs.n_y)
+        region = np.repeat(region, ss, axis=1).reshape(wcs.n_x * ss, wcs.n_y * ss)
+    region = np.argwhere(region)  # == tf.where: row-major (N,2) [row, col]
+    img_X, img_Y = wcs.pix2angle(region[:, 1], region[:, 0])
+    return wcs, region, img_region.astype(np.float32), img_X, img_Y
+
+
+def conversion_factor(sim_config):
+    """tf/simulator.py:22-29: det of the UN-supersampled transform."""
+    T = (np.eye(2) * sim_config.delta_pix if sim_config.transform_pix2angle is None
+         else np.asarray(sim_config.transform_pix2angle, dtype=np.float64))
+    return float(np.float32(np.linalg.det(T.astype(np.float32))))
+
+
+# --------------------------------------------------------------------------
+# mass profiles
+# --------------------------------------------------------------------------
+def _rotate(x, y, phi):
+    """tf/profiles/mass/epl.py:59-64 (identical in sie.py:45-49)."""
+    c, s = torch.cos(phi), torch.sin(phi)
+    return x * c + y * s, -x * s + y * c
+
+
+def epl_deriv(x, y, theta_E, gamma, e1, e2, center_x, center_y, niter_cap=50):
+    """tf/profiles/mass/epl.py:19-57."""
+    theta_E, gamma, e1, e2, center_x, center_y = (_t(v, x) for v in (theta_E, gamma, e1, e2, center_x, center_y))
+    phi = torch.atan2(e2, e1) / 2
+    c = torch.clamp(torch.sqrt(e1 ** 2 + e2 ** 2), 0, 1)
+    q = (1 - c) / (1 + c)
+    theta_E_conv = theta_E / torch.sqrt((1.0 + q ** 2) / (2.0 * q))
+    b = theta_E_conv * torch.sqrt((1 + q ** 2) / 2)
+    t = gamma - 1
+    x, y = x - center_x, y - center_y
+    x, y = _rotate(x, y, phi)
+    R = torch.clamp(torch.sqrt((q * x) ** 2 + y ** 2), 1e-10, 1e10)
+    angle = torch.atan2(y, q * x)
+    f = (1 - q) / (1 + q)
+    Cs, Ss = torch.cos(angle), torch.sin(angle)
+    Cs2, Ss2 = torch.cos(2 * angle), torch.sin(2 * angle)
+    # :37  stop_gradient(log(1e-12)/log(reduce_max(f)) + 2); max over the WHOLE batch
+    with torch.no_grad():
+        fmax = torch.max(f.detach())
+        niter = (torch.log(torch.as_tensor(1e-12, dtype=x.dtype)) / torch.log(fmax) + 2).item()
+    last_x, last_y, f_x, f_y = Cs, Ss, Cs, Ss
+    n = 1.0
+    it = 0
+    while n < niter and it < niter_cap:  # :47-54 (maximum_iterations=self.niter)
+        prefac_ = -f * (2 * n - (2 - t)) / (2 * n + (2 - t))
+        last_x, last_y = prefac_ * (Cs2 * last_x - Ss2 * last_y), prefac_ * (Ss2 * last_x + Cs2 * last_y)
+        f_x, f_y = f_x + last_x, f_y + last_y
+        n += 1.0
+        it += 1
+    prefac = (2 * b) / (1 + q) * torch.pow(b / R, t - 1)
+    f_x, f_y = f_x * prefac, f_y * prefac
+    return _rotate(f_x, f_y, -phi)
+
+
+def sie_deriv(x, y, theta_E, e1, e2, center_x, center_y):
+    """tf/profiles/mass/sie.py:13-42.  s_scale is the LOCAL 0 (sie.py:15), so s==0."""
+    theta_E, e1, e2, center_x, center_y = (_t(v, x) for v in (theta_E, e1, e2, center_x, center_y))
+    s_scale = 0
+    phi = torch.atan2(e2, e1) / 2
+    c = torch.clamp(torch.sqrt(e1 ** 2 + e2 ** 2), max=0.9999)
+    q = (1 - c) / (1 + c)
+    theta_E_conv = theta_E / torch.sqrt((1.0 + q ** 2) / (2.0 * q))
+    b = theta_E_conv * torch.sqrt((1 + q ** 2) / 2)
+    s = s_scale * torch.sqrt((1 + q ** 2) / (2 * q ** 2))
+    x, y = x - center_x, y - center_y
+    x, y = _rotate(x, y, phi)
+    psi = torch.sqrt(q ** 2 * (s ** 2 + x ** 2) + y ** 2)
+    fx = b / torch.sqrt(1.0 - q ** 2) * torch.atan(torch.sqrt(1.0 - q ** 2) * x / (psi + s))
+    fy = b / torch.sqrt(1.0 - q ** 2) * torch.atanh(torch.sqrt(1.0 - q ** 2) * y / (psi + q ** 2 * s))
+    return _rotate(fx, fy, -phi)
+
+
+def _nfw_g(x):
+    """tf/profiles/mass/nfw.py:33-52: gather/scatter on the x<1 / x>1 index sets;
+    entries with x==1 keep the initial 1.0 (:38)."""
+    shape = x.shape
+    x = x.reshape(-1)
+    x = torch.clamp(x, min=1e-6)
+    a = torch.ones_like(x)
+    m1, m2 = x < 1, x > 1
+    x1, x2 = x[m1], x[m2]
+    a = a.masked_scatter(m1, torch.log(x1 / 2.0) + 1 / torch.sqrt(1 - x1 ** 2) * torch.acosh(1.0 / x1))
+    a = a.masked_scatter(m2, torch.log(x2 / 2.0) + 1 / torch.sqrt(x2 ** 2 - 1) * torch.acos(1.0 / x2))
+    return a.reshape(shape)
+
+
+def nfw_deriv(x, y, Rs, alpha_Rs, center_x, center_y):
+    """tf/profiles/mass/nfw.py:15-31."""
+    Rs, alpha_Rs, center_x, center_y = (_t(v, x) for v in (Rs, alpha_Rs, center_x, center_y))
+    rho0 = alpha_Rs / (4.0 * Rs ** 2 * (1.0 - LN2))
+    x, y = x - center_x, y - center_y
+    R = torch.sqrt(x ** 2 + y ** 2)
+    R = torch.clamp(R, min=1e-7)
+    Rs = torch.clamp(Rs, min=1e-7)
+    X = R / Rs
+    X, _ = torch.broadcast_tensors(X, x)
+    gx = _nfw_g(X)
+    a = 4 * rho0 * Rs * gx / X ** 2
+    return a * x, a * y
+
+
+def shear_deriv(x, y, gamma1, gamma2):
+    """tf/profiles/mass/shear.py:14-16."""
+    gamma1, gamma2 = _t(gamma1, x), _t(gamma2, x)
+    return gamma1 * x + gamma2 * y, gamma2 * x - gamma1 * y
+
+
+def sis_deriv(x, y, theta_E, center_x, center_y):
+    """tf/profiles/mass/sis.py:12-17."""
+    theta_E, center_x, center_y = (_t(v, x) for v in (theta_E, center_x, center_y))
+    x, y = x - center_x, y - center_y
+    R = torch.sqrt(x ** 2 + y ** 2)
+    a = torch.where(R == 0, torch.zeros_like(R), theta_E / R)
+    return a * x, a * y
+
+
+# --------------------------------------------------------------------------
+# light profiles
+# --------------------------------------------------------------------------
+def sersic_distance(x, y, cx, cy, e1=None, e2=None):
+    """tf/profiles/light/sersic.py:37-63."""
+    cx, cy = _t(cx, x), _t(cy, x)
+    e1 = torch.zeros_like(cx) if e1 is None else _t(e1, x)
+    e2 = torch.zeros_like(cx) if e2 is None else _t(e2, x)
+    phi = torch.atan2(e2, e1) / 2
+    c = torch.clamp(torch.sqrt(e1 ** 2 + e2 ** 2), max=0.9999)
+    q = (1 - c) / (1 + c)
+    dx, dy = x - cx, y - cy
+    cos_phi, sin_phi = torch.cos(phi), torch.sin(phi)
+    xt1 = (cos_phi * dx + sin_phi * dy) * torch.sqrt(q)
+    xt2 = (-sin_phi * dx + cos_phi * dy) / torch.sqrt(q)
+    return torch.sqrt(xt1 ** 2 + xt2 ** 2)
+
+
+def sersic_light(x, y, R_sersic, n_sersic, center_x, center_y, Ie, e1=None, e2=None):
+    """tf/profiles/light/sersic.py:29-35 (Sersic) and :74-80 (SersicEllipse)."""
+    R_sersic, n_sersic, Ie = _t(R_sersic, x), _t(n_sersic, x), _t(Ie, x)
+    R = sersic_distance(x, y, center_x, center_y, e1, e2)
+    bn = 1.9992 * n_sersic - 0.3271
+    return Ie * torch.exp(-bn * ((R / R_sersic) ** (1 / n_sersic) - 1.0))
+
+
+def shapelet_index_order(n_max):
+    """tf/profiles/light/shapelets.py:26-46: (n1,n2) = (0,0),(1,0),(0,1),(2,0),(1,1),(0,2),..."""
+    n_layers = int((n_max + 1) * (n_max + 2) / 2)
+    N1, N2 = [], []
+    n1 = n2 = 0
+    for _ in range(n_layers):
+        N1.append(n1)
+        N2.append(n2)
+        if n1 == 0:
+            n1 = n2 + 1
+            n2 = 0
+        else:
+            n1 -= 1
+            n2 += 1
+    return N1, N2
+
+
+def shapelet_amp_names(n_max):
+    """tf/profiles/light/shapelets.py:32-36: amp{i:0w}, w=len(str(n_layers))."""
+    n_layers = int((n_max + 1) * (n_max + 2) / 2)
+    w = len(str(n_layers))
+    return [f"amp{str(i).zfill(w)}" for i in range(n_layers)]
+
+
+def phi_n_f64(n, x):
+    """lenstronomy (README pins ==1.9.3) ``Shapelets.phi_n``: H_n(x) e^{-x^2/2} /
+    sqrt(2^n sqrt(pi) n!) -- third-party algorithm restated from its published
+    definition (Refregier 2003 eq. 1-2); used at shapelets.py:39-40 to build tables."""
+    x = np.asarray(x, dtype=np.float64)
+    coef = np.zeros(n + 1)
+    coef[n] = 1.0
+    pref = 1.0 / np.sqrt(2.0 ** n * np.sqrt(np.pi) * math.factorial(n))
+    return pref * np.polynomial.hermite.hermval(x, coef) * np.exp(-x ** 2 / 2.0)
+
+
+def shapelet_tables(n_max, n_nodes=6000):
+    """shapelets.py:39-40,50-51: phi_n(linspace(-5,5,6000)) stored as float32, (n_max+1, 6000)."""
+    grid = np.linspace(-5.0, 5.0, n_nodes)
+    return np.stack([phi_n_f64(n, grid) for n in range(n_max + 1)]).astype(np.float32)
+
+
+def interp_regular_1d_grid(x, x_ref_min, x_ref_max, y_ref):
+    """tensorflow-probability >=0.19 ``tfp.math.interp_regular_1d_grid`` (setup.py:44),
+    restated from its published algorithm (linear, fill 0 below/above) -- third-party,
+    "parity unpinned".  y_ref: (K, ny); x: any shape -> (K, *x.shape)."""
+    ny = y_ref.shape[-1]
+    idx_unclipped = (x - x_ref_min) / (x_ref_max - x_ref_min) * (ny - 1)
+    idx = torch.clamp(idx_unclipped, 0, ny - 1)
+    below = torch.floor(idx)
+    above = torch.clamp(below + 1, max=ny - 1)
+    below = torch.clamp(above - 1, min=0)
+    tt = idx - below
+    yb = y_ref[:, below.long().reshape(-1)].reshape(y_ref.shape[0], *x.shape)
+    ya = y_ref[:, above.long().reshape(-1)].reshape(y_ref.shape[0], *x.shape)
+    y = tt * ya + (1 - tt) * yb
+    zero = torch.zeros_like(y)
+    y = torch.where(idx_unclipped < 0, zero, y)
+    y = torch.where(idx_unclipped > ny - 1, zero, y)
+    return y
+
+
+_TABLE_CACHE: Dict = {}
+
+
+def shapelets_light(x, y, center_x, center_y, beta, amps, n_max, interpolate=True):
+    """tf/profiles/light/shapelets.py:53-85.  ``amps``: list of n_layers tensors (B,)
+    in amp-name order (== tf.nest.flatten of the **amp kwargs, keys sorted)."""
+    center_x, center_y, beta = _t(center_x, x), _t(center_y, x), _t(beta, x)
+    N1, N2 = shapelet_index_order(n_max)
+    A = torch.stack([_t(a, x) * torch.ones(x.shape[-1], dtype=x.dtype) if _t(a, x).dim() == 0 else _t(a, x)
+                     for a in amps])  # (n_layers, B)
+    u = (x - center_x) / beta
+    v = (y - center_y) / beta
+    if interpolate:
+        key = (n_max, x.dtype)
+        if key not in _TABLE_CACHE:
+            tab = torch.from_numpy(shapelet_tables(n_max)).to(x.dtype)  # f32 values (shapelets.py:50-51)
+            _TABLE_CACHE[key] = tab
+        tab = _TABLE_CACHE[key]
+        X = interp_regular_1d_grid(u, -5.0, 5.0, tab)  # (n_max+1, N, B)
+        Y = interp_regular_1d_grid(v, -5.0, 5.0, tab)
+        ret = X[N1] * Y[N2]  # (n_layers, N, B) -- the reference interpolates 66 duplicated rows
+        return torch.einsum('inj,ij->nj', ret, A)
+    # direct mode :66-85
+    herm = [torch.ones_like(u), 2 * u]
+    hermv = [torch.ones_like(v), 2 * v]
+    for i in range(2, n_max + 1):
+        herm.append(2 * (u * herm[-1] - (i - 1) * herm[-2]))
+        hermv.append(2 * (v * hermv[-1] - (i - 1) * hermv[-2]))
+    N = torch.arange(0, n_max + 1, dtype=x.dtype)
+    pref = 1.0 / torch.sqrt(2 ** N * math.sqrt(math.pi) * torch.exp(torch.lgamma(N + 1)))
+    XX = torch.stack(herm[: n_max + 1]) * pref[:, None, None]
+    YY = torch.stack(hermv[: n_max + 1]) * pref[:, None, None]
+    fac = torch.exp(-(u ** 2 + v ** 2) / 2)
+    return fac * torch.einsum('ij,inj->nj', A, XX[N1] * YY[N2])
+
+
+# --------------------------------------------------------------------------
+# dispatch by the reference's profile names
+# --------------------------------------------------------------------------
+def mass_deriv(profile, x, y, **kw):
+    name = profile.name
+    if name == "EPL":
+        return epl_deriv(x, y, niter_cap=getattr(profile, "niter", 50), **kw)
+    if name == "SIE":
+        return sie_deriv(x, y, **kw)
+    if name == "NFW":
+        return nfw_deriv(x, y, **kw)
+    if name == "SHEAR":
+        return shear_deriv(x, y, **kw)
+    if name == "SIS":
+        return sis_deriv(x, y, **kw)
+    raise NotImplementedError(name)
+
+
+def light_eval(profile, x, y, **kw):
+    name = profile.name
+    if name in ("SERSIC", "SERSIC_ELLIPSE"):
+        return sersic_light(x, y, **kw)
+    if name == "SHAPELETS":
+        names = shapelet_amp_names(profile.n_max)
+        amps = [kw[k] for k in sorted(k for k in kw if k.startswith("amp"))]
+        assert len(amps) == len(names)
+        return shapelets_light(x, y, kw["center_x"], kw["center_y"], kw["beta"], amps,
+                               profile.n_max, getattr(profile, "interpolate", True))
+    raise NotImplementedError(name)
+
+
+# --------------------------------------------------------------------------
+# PSF helper (third party, "parity unpinned" for supersample>1)
+# --------------------------------------------------------------------------
+def subgrid_kernel(kernel, subgrid_res, odd=True, num_iter=100):
+    """lenstronomy ``kernel_util.subgrid_kernel`` (used at tf/simulator.py:62-65).
+    Identity for subgrid_res==1.  For subgrid_res>1 lenstronomy interpolates the
+    PSF onto the finer grid and iteratively corrects it so that re-averaging gives
+    back the input kernel; that third-party routine is NOT restated here (parity
+    unpinned) -- callers must pass an already-supersampled kernel."""
+    if subgrid_res == 1:
+        return np.asarray(kernel)
+    raise NotImplementedError("subgrid_kernel for supersample>1 is an unpinned third-party routine; "
+                              "pass a PSF already sampled on the supersampled grid")
+
+
+# --------------------------------------------------------------------------
+# simulator (tf/simulator.py)
+# --------------------------------------------------------------------------
+class RefSimulator:
+    """tf/simulator.py:13-156 (``__init__``, ``beta``, ``simulate``)."""
+
+    def __init__(self, phys_model, sim_config, bs, dtype=torch.float64, supersampled_kernel=None):
+        self.phys_model = phys_model
+        self.sim_config = sim_config
+        self.bs = bs
+        self.dtype = dtype
+        self.supersample = int(sim_config.supersample)
+        self.wcs, self.region, img_region, img_X, img_Y = build_grid(sim_config)
+        self.img_region = torch.from_numpy(img_region).to(dtype)
+        # :46-51 -- the grid replicated per batch element, (N, bs)
+        self.img_X = torch.from_numpy(img_X).to(dtype)[:, None].repeat(1, bs)
+        self.img_Y = torch.from_numpy(img_Y).to(dtype)[:, None].repeat(1, bs)
+        self.conversion_factor = conversion_factor(sim_config)
+        self.flat_kernel = None
+        k = supersampled_kernel
+        if k is None and sim_config.kernel is not None:
+            k = subgrid_kernel(sim_config.kernel, self.supersample, odd=True)
+        if k is not None:
+            # :62-70 kernel[::-1, ::-1] then tf.nn.conv2d (a cross-correlation) => true convolution
+            self.flat_kernel = torch.from_numpy(np.ascontiguousarray(np.asarray(k)[::-1, ::-1]).astype(np.float32)).to(dtype)
+
+    def _consts(self, attr, n):
+        c = getattr(self.phys_model, attr, None)
+        if c is None:
+            return [dict() for _ in range(n)]
+        return [{k: torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.dtype) for k, v in d.items()} for d in c]
+
+    def beta(self, x, y, lens_params: List[Dict]):
+        """:72-78."""
+        beta_x, beta_y = x, y
+        consts = self._consts("lenses_constants", len(self.phys_model.lenses))
+        for lens, p, c in zip(self.phys_model.lenses, lens_params, consts):
+            f_xi, f_yi = mass_deriv(lens, x, y, **p, **c)
+            beta_x, beta_y = beta_x - f_xi, beta_y - f_yi
+        return beta_x, beta_y
+
+    def simulate(self, params, no_deflection=False):
+        """:109-156."""
+        pm = self.phys_model
+        lens_params = params.get('lens_mass', [{} for _ in pm.lenses])
+        lens_light_params = params.get('lens_light', [{} for _ in pm.lens_light])
+        source_light_params = params.get('source_light', [{} for _ in pm.source_light])
+        beta_x, beta_y = self.beta(self.img_X, self.img_Y, lens_params)
+        if no_deflection:
+            beta_x, beta_y = self.img_X, self.img_Y
+        Hs, Ws = self.wcs.n_x * self.supersample, self.wcs.n_y * self.supersample
+        img = torch.zeros((Hs, Ws, self.bs), dtype=self.dtype)
+        rr, cc = torch.from_numpy(self.region[:, 0]), torch.from_numpy(self.region[:, 1])
+        for lm, p, c in zip(pm.lens_light, lens_light_params, self._consts("lens_light_constants", len(pm.lens_light))):
+            img = img.index_put((rr, cc), light_eval(lm, self.img_X, self.img_Y, **p, **c), accumulate=True)
+        for lm, p, c in zip(pm.source_light, source_light_params, self._consts("source_light_constants", len(pm.source_light))):
+            img = img.index_put((rr, cc), light_eval(lm, beta_x, beta_y, **p, **c), accumulate=True)
+        img = torch.where(torch.isnan(img), torch.zeros_like(img), img)  # :140
+        img = img.permute(2, 0, 1)  # :141
+        ret = img[:, None]
+        if self.flat_kernel is not None:  # :145-147 conv2d SAME, stride 1
+            kh, kw = self.flat_kernel.shape
+            # TF 'SAME' pads (k-1)//2 before and k//2 after (extra goes to the end)
+            ret = torch.nn.functional.pad(ret, ((kw - 1) // 2, kw // 2, (kh - 1) // 2, kh // 2))
+            ret = torch.nn.functional.conv2d(ret, self.flat_kernel[None, None])
+        if self.supersample != 1:  # :149-155
+            ret = torch.nn.functional.avg_pool2d(ret, kernel_size=self.supersample, stride=self.supersample)
+        return torch.squeeze(ret) * self.conversion_factor  # :156
+
+
+def stats_pixels(simulator: RefSimulator, params, observed_image, background_rms=None, exp_time=None,
+                 error_map=None):
+    """tf/model.py:89-101."""
+    dt = simulator.dtype
+    im_sim = simulator.simulate(params)
+    if error_map is not None:
+        err_map = torch.as_tensor(np.asarray(error_map, dtype=np.float32)).to(dt)
+    else:
+        bg = torch.as_tensor(np.float32(background_rms)).to(dt)
+        et = torch.as_tensor(np.float32(exp_time)).to(dt)
+        err_map = torch.sqrt(bg ** 2 + im_sim / et)
+    obs = torch.as_tensor(np.asarray(observed_image, dtype=np.float32)).to(dt)
+    reg = simulator.img_region
+    chi2 = torch.sum(((im_sim - obs) / err_map) ** 2 * reg, dim=(-2, -1))
+    normalization = torch.sum(torch.log(2 * np.pi * err_map ** 2) * reg, dim=(-2, -1))
+    log_like = -1 / 2 * (chi2 + normalization)
+    red_chi2 = chi2 / torch.count_nonzero(reg).to(dt)
+    return log_like, red_chi2

@@ -1,0 +1,117 @@
+// TEST HARNESS ONLY -- never linked into the product library.
+// Instantiates the per-profile templates of gigalens_amd/csrc/gl_profiles.h on the host (double and
+// float) so that the CPU test-suite can check the hand-written prep / fwd / vjp / finalize chain
+// against autograd of the oracle without a GPU.  The product evaluates these same templates only
+// inside its HIP kernels.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../gigalens_amd/csrc/gl_host_tables.h"
+#include "../../gigalens_amd/csrc/gl_profiles.h"
+
+using namespace glp;
+
+namespace {
+
+template <class R> struct Tab {
+  std::vector<float> tab;
+  int stride = 0;
+};
+
+template <class R>
+void run_mass(int kind, int iparam, const R* p, int n, const R* x, const R* y, const R* gx, const R* gy, R* ax,
+              R* ay, R* grad) {
+  std::vector<R> d(kind_num_derived(kind, iparam) + 8, (R)0);
+  R acc[16] = {0};
+  switch (kind) {
+    case K_EPL: epl_prep<R>(p, iparam, d.data()); break;
+    case K_SIE: sie_prep<R>(p, d.data()); break;
+    case K_NFW: nfw_prep<R>(p, d.data()); break;
+    case K_SHEAR: shear_prep<R>(p, d.data()); break;
+    case K_SIS: sis_prep<R>(p, d.data()); break;
+  }
+  for (int i = 0; i < n; ++i) {
+    switch (kind) {
+      case K_EPL: epl_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); epl_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
+      case K_SIE: sie_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); sie_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
+      case K_NFW: nfw_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); nfw_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
+      case K_SHEAR: shear_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); shear_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
+      case K_SIS: sis_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); sis_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
+    }
+  }
+  switch (kind) {
+    case K_EPL: epl_finalize<R>(p, acc, grad); break;
+    case K_SIE: sie_finalize<R>(p, acc, grad); break;
+    case K_NFW: nfw_finalize<R>(p, acc, grad); break;
+    case K_SHEAR: shear_finalize<R>(p, acc, grad); break;
+    case K_SIS: sis_finalize<R>(p, acc, grad); break;
+  }
+}
+
+template <class R>
+void run_light(int kind, int iparam, unsigned flags, const R* p, int n, const R* x, const R* y, const R* gI, R* I,
+               R* grad, R* gpx, R* gpy) {
+  std::vector<R> d(kind_num_derived(kind, iparam) + 8, (R)0);
+  std::vector<R> acc(kind_num_acc(kind, iparam) + 8, (R)0);
+  static std::vector<float> tab;
+  static int stride = 0;
+  if (kind == K_SHAPELETS && tab.empty()) glh::build_shapelet_table(SH_CAP, tab, &stride);
+  const bool interp = flags & 1u;
+  switch (kind) {
+    case K_SERSIC: sersic_prep<R>(p, false, d.data()); break;
+    case K_SERSIC_ELLIPSE: sersic_prep<R>(p, true, d.data()); break;
+    case K_SHAPELETS: shapelets_prep<R>(p, iparam, d.data()); break;
+  }
+  for (int i = 0; i < n; ++i) {
+    gpx[i] = 0;
+    gpy[i] = 0;
+    if (kind == K_SHAPELETS) {
+      I[i] = shapelets_fwd<R, SH_CAP>(d.data(), tab.data(), stride, interp, x[i], y[i]);
+      shapelets_vjp<R, SH_CAP>(d.data(), tab.data(), stride, interp, x[i], y[i], gI[i], acc.data(), gpx[i], gpy[i]);
+    } else {
+      I[i] = sersic_fwd<R>(d.data(), x[i], y[i]);
+      sersic_vjp<R>(d.data(), x[i], y[i], gI[i], acc.data(), gpx[i], gpy[i]);
+    }
+  }
+  switch (kind) {
+    case K_SERSIC: sersic_finalize<R>(p, false, acc.data(), grad); break;
+    case K_SERSIC_ELLIPSE: sersic_finalize<R>(p, true, acc.data(), grad); break;
+    case K_SHAPELETS: shapelets_finalize<R>(p, iparam, acc.data(), grad); break;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+void hm_mass_f64(int kind, int iparam, const double* p, int n, const double* x, const double* y, const double* gx,
+                 const double* gy, double* ax, double* ay, double* grad) {
+  run_mass<double>(kind, iparam, p, n, x, y, gx, gy, ax, ay, grad);
+}
+void hm_mass_f32(int kind, int iparam, const float* p, int n, const float* x, const float* y, const float* gx,
+                 const float* gy, float* ax, float* ay, float* grad) {
+  run_mass<float>(kind, iparam, p, n, x, y, gx, gy, ax, ay, grad);
+}
+void hm_light_f64(int kind, int iparam, unsigned flags, const double* p, int n, const double* x, const double* y,
+                  const double* gI, double* I, double* grad, double* gpx, double* gpy) {
+  run_light<double>(kind, iparam, flags, p, n, x, y, gI, I, grad, gpx, gpy);
+}
+void hm_light_f32(int kind, int iparam, unsigned flags, const float* p, int n, const float* x, const float* y,
+                  const float* gI, float* I, float* grad, float* gpx, float* gpy) {
+  run_light<float>(kind, iparam, flags, p, n, x, y, gI, I, grad, gpx, gpy);
+}
+void hm_chi2_f64(int n, const double* m, const double* o, const double* w, int has_err, const double* err, double bg2,
+                 double inv_t, double* chi2, double* norm, double* gm) {
+  double c = 0, nm = 0;
+  for (int i = 0; i < n; ++i) {
+    double c2, n2;
+    chi2_terms<double>(m[i], o[i], w[i], has_err, has_err ? err[i] : 1.0, bg2, inv_t, c2, n2);
+    c += c2;
+    nm += n2;
+    gm[i] = chi2_gm<double>(m[i], o[i], w[i], has_err, has_err ? err[i] : 1.0, bg2, inv_t);
+  }
+  *chi2 = c;
+  *norm = nm;
+}
+int hm_num_params(int kind, int iparam) { return kind_num_params(kind, iparam); }
+}
