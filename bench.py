@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- forward+grad lens simulations per second on BASELINE.json's configs[1]:
+EPL+shear lens, Sersic source, 128x128 px, batch 1024, fp32, per MI355X (weak scaling over GPUs).
+
+One "step" = one pass of the hot path over one batch: ``ForwardProbModel.log_prob(simulator, z)`` forward
+AND its gradient w.r.t. ``z`` (bijector -> fused HIP prep/main/finalize kernels -> prior), i.e. exactly what
+one MAP / SVI / HMC-leapfrog step of the reference evaluates (tf/inference.py:33-39).  With N > 1 ranks each
+rank owns its own 1024 samples and a step also carries the one SVI collective of the path: an all-reduce of
+the fused [ELBO, grad] buffer (1 + d + d(d+1)/2 floats; jax/inference.py:126-128).
+
+Prints ONE JSON line on rank 0 (contract in the round prompt) with two extra objects:
+  roofline     -- dominant kernel (gl_main_kernel, fused fwd+grad), HIP-event timed on its launch stream
+  cpu_baseline -- the oracle (reference algorithm restated op-for-op on torch-CPU, float32 + autograd) timed on
+                  a bounded sample of the same workload on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3
+
+
+def host_cores():
+    """Host threads this process may really use: affinity, capped by the cgroup CPU quota and by the
+    GPU box's per-GPU share (16), overridable with GIGALENS_CPU_THREADS."""
+    if os.environ.get("GIGALENS_CPU_THREADS"):
+        return max(1, int(os.environ["GIGALENS_CPU_THREADS"]))
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, 16)
+
+
+def cpu_baseline(wl, obs, seconds=12.0, sample_batch=16):
+    """Time the oracle (float32, torch autograd) on `sample_batch` samples of the same workload."""
+    import numpy as np
+    from oracle import ref_torch as ref
+    from tests.helpers import struct_from_packed
+    from gigalens_amd import workloads
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    rs = ref.RefSimulator(wl.phys_model, wl.sim_config, sample_batch, dtype=torch.float32)
+    x = wl.prior.sample(sample_batch, seed=11)
+    from gigalens_amd.model import _Packing
+    packed = _Packing(wl.phys_model).pack(x, sample_batch, "cpu")
+    obs_np = obs.cpu().numpy()
+
+    def one():
+        p = packed.clone().requires_grad_(True)
+        ll, _ = ref.stats_pixels(rs, struct_from_packed(wl.phys_model, p), obs_np, wl.background_rms, wl.exp_time)
+        ll.sum().backward()
+        return p.grad
+
+    one()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 200:
+            break
+    return {"value": round(sample_batch * n / dt, 3), "unit": "sims/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+grad passes over {sample_batch} of the {wl.batch} samples "
+                      f"({wl.sim_config.num_pix}x{wl.sim_config.num_pix} px, float32 torch-CPU restatement of the TF graph)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
+    ap.add_argument("--num-pix", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    from gigalens_amd import dist as gdist
+    rank, local_rank, world = gdist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as ge
+    from gigalens_amd import _native, workloads
+    from gigalens_amd.model import ForwardProbModel
+    from gigalens_amd.simulator import LensSimulator
+    if not os.path.exists(_native.lib_path()):
+        ge.build()
+
+    wl = workloads.make(args.workload, num_pix=args.num_pix, batch=args.batch)
+    obs, err, _ = workloads.synthetic_observation(wl, LensSimulator)
+    pm = ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time,
+                          error_map=None if err is None else err.cpu().numpy(), include_positions=False)
+    sim = LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    B, N, P = wl.batch, sim._model.N, sim._model.P
+    x = wl.prior.sample(B, generator=gdist.rank_generator(0, rank))
+    z = pm.bij.inverse(x).to(dev).contiguous()
+    d = z.shape[1]
+    coll = torch.zeros(1 + d + d * (d + 1) // 2, dtype=torch.float32, device=dev)
+
+    def step():
+        zz = z.detach().requires_grad_(True)
+        lp, red = pm.log_prob(sim, zz)
+        (g,) = torch.autograd.grad(lp.sum(), zz)
+        if world > 1:
+            coll[0] = lp.mean()
+            coll[1:1 + d] = g.mean(0)
+            gdist.allreduce_mean_(coll)
+        return lp, g
+
+    for _ in range(args.warmup):
+        step()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    gdist.barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    gdist.allreduce_max_(tmax)
+    elapsed = float(tmax.item())
+
+    # ---- dominant kernel: HIP events around gl_main_kernel on its own launch stream ----
+    packed = sim.pack(pm.bij.forward(z)).contiguous()
+    sim._model.set_timing(True)
+    ms = []
+    for i in range(args.warmup + args.steps):
+        sim._model.loglike(packed, pm.observed_image, pm.error_map, None, pm.background_rms or 0.0,
+                           pm.exp_time or 1.0, True)
+        if i >= args.warmup:
+            ms.append(sim._model.last_main_ms())
+    sim._model.set_timing(False)
+    main_ms = sum(ms) / len(ms)
+    # native call alone (prep + main + finalize), event-timed on the current stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.steps):
+        sim._model.loglike(packed, pm.observed_image, pm.error_map, None, pm.background_rms or 0.0,
+                           pm.exp_time or 1.0, True)
+    e1.record()
+    torch.cuda.synchronize()
+    native_ms = e0.elapsed_time(e1) / args.steps
+
+    if rank == 0:
+        sims = B * world * args.steps / elapsed
+        # algorithmic bytes per sim: B1 = simulate() boundary (image out + cotangent in + params/grads),
+        # B2 = fused log_prob boundary (what this kernel actually has to move)
+        n_planes = 1 + (1 if err is not None else 0)
+        bytes_b1 = 2 * 4 * N + 2 * 4 * P
+        bytes_b2 = 4 * (2 * P + 2) + 4 * N * n_planes / B
+        achieved = bytes_b1 * B / (main_ms * 1e-3) / 1e9
+        out = {
+            "metric": "forward+grad lens sims/sec, 128x128 px batch 1024; achieved HBM GB/s vs peak",
+            "value": round(sims, 1), "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{wl.name}: {wl.description}, {wl.sim_config.num_pix}x{wl.sim_config.num_pix} px, "
+                                   f"batch {B} per GPU, fp32 (BASELINE.json configs[1])",
+                       "samples_per_gpu": B, "pixels": N, "params_per_sample": P, "z_dim": d,
+                       "parallelism": f"dp{world} (sample shards, one {coll.numel()}-float all-reduce per step)"
+                                      if world > 1 else "single GPU",
+                       "step": "ForwardProbModel.log_prob forward + gradient w.r.t. z"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "gl_main_kernel<LL_GRAD> (fused ray-shoot + render + chi2 + VJP)",
+                         "kernel_ms": round(main_ms, 4), "native_call_ms": round(native_ms, 4),
+                         "algorithmic_bytes_per_sim_B1": bytes_b1, "algorithmic_bytes_per_sim_B2": round(bytes_b2, 1),
+                         "kernel_sims_per_s": round(B / (main_ms * 1e-3), 1),
+                         "note": "path is VALU/transcendental-bound (SURVEY 8d): HBM fraction is reported as the "
+                                 "metric asks, the binding bound is fp32 VALU issue"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, obs, seconds=args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    gdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

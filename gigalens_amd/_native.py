@@ -48,6 +48,8 @@ SYMBOLS = {
     "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     "gl_kind_num_params": (c_int, [POINTER(gl_component)]),
+    "gl_model_set_timing": (c_int, [c_void_p, c_int]),
+    "gl_model_last_main_ms": (c_int, [c_void_p, POINTER(c_float)]),
     "gl_last_error": (c_char_p, []),
     "gl_version": (c_char_p, []),
 }
@@ -179,6 +181,14 @@ class Model:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.gl_model_destroy(h)
+
+    def set_timing(self, enabled=True):
+        _check(lib().gl_model_set_timing(self._h, int(enabled)))
+
+    def last_main_ms(self):
+        ms = c_float()
+        _check(lib().gl_model_last_main_ms(self._h, ctypes.byref(ms)))
+        return ms.value
 
     def _workspace(self, B):
         ws = self._ws.get(B)

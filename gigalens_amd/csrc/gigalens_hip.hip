@@ -61,6 +61,8 @@ struct gl_model {
   int shp_stride = 0;
   float* d_psf = nullptr;
   int psf_h = 0, psf_w = 0;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int tile = 4;          // pixels per thread per tile (template T)
   int target_wgs = 2048;  // work decomposition target (>= 8 workgroups per CU)
 };
@@ -112,6 +114,7 @@ template <int MODE>
 int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream) {
   dim3 grid(n_chunks, B), block(WG);
   size_t shmem = (size_t)(((m->D + 3) & ~3) + 4 * m->Apad) * sizeof(float);
+  if (m->timing) GL_HIP(hipEventRecord(m->ev0, stream));
   if (m->has_shapelets) {
     if (m->tile == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, true>), grid, block, shmem, stream, a);
     else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true>), grid, block, shmem, stream, a);
@@ -119,6 +122,7 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
     if (m->tile == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, false>), grid, block, shmem, stream, a);
     else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, false>), grid, block, shmem, stream, a);
   }
+  if (m->timing) GL_HIP(hipEventRecord(m->ev1, stream));
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -259,7 +263,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   m->supersample = grid->supersample;
   m->N = grid->n_region;
   m->conversion_factor = grid->conversion_factor;
-  m->tile = env_int("GIGALENS_HIP_TILE", m->has_shapelets ? 2 : 4) == 2 ? 2 : 4;
+  m->tile = env_int("GIGALENS_HIP_TILE", 2) == 4 ? 4 : 2;
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   size_t shmem = (size_t)(((m->D + 3) & ~3) + 4 * m->Apad) * sizeof(float);
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
@@ -299,8 +303,28 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   return GL_OK;
 }
 
+int gl_model_set_timing(gl_model* m, int enabled) {
+  if (!m) return fail(GL_EINVAL, "model is null");
+  if (enabled && !m->ev0) {
+    GL_HIP(hipEventCreate(&m->ev0));
+    GL_HIP(hipEventCreate(&m->ev1));
+  }
+  m->timing = enabled != 0;
+  return GL_OK;
+}
+
+int gl_model_last_main_ms(gl_model* m, float* ms) {
+  if (!m || !ms) return fail(GL_EINVAL, "null argument");
+  if (!m->ev0) return fail(GL_EINVAL, "timing was never enabled on this model");
+  GL_HIP(hipEventSynchronize(m->ev1));
+  GL_HIP(hipEventElapsedTime(ms, m->ev0, m->ev1));
+  return GL_OK;
+}
+
 void gl_model_destroy(gl_model* m) {
   if (!m) return;
+  if (m->ev0) (void)hipEventDestroy(m->ev0);
+  if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->d_comps) (void)hipFree(m->d_comps);
   if (m->d_gx) (void)hipFree(m->d_gx);
   if (m->d_gy) (void)hipFree(m->d_gy);

@@ -1,0 +1,77 @@
+"""Data-parallel sharding of the sample batch: one process per GPU, ``torch.distributed`` (backend
+``nccl`` == RCCL over xGMI on ROCm; ``gloo`` for CPU rehearsal).
+
+What the path needs (reference: src/gigalens/jax/inference.py:32-80,91-144,157-208):
+samples are independent, so MAP and HMC shard with NO data-path collective (only a final gather);
+SVI needs exactly one all-reduce per step of ``[ELBO, d ELBO/d mu (d), d ELBO/d L_packed (d(d+1)/2)]``
+-- the equivalent of ``jax.lax.pmean`` at jax/inference.py:126-128.  At d = 132 that is 8 911 floats
+(35 KB): latency-bound, so value and gradient travel in ONE fused buffer and nothing is bucketed.
+"""
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract). Returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, local_rank, world
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shard_bounds(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rank r owns samples [r*n/W, (r+1)*n/W) of a batch divisible by W (jax/inference.py:33-38 uses n // dev_cnt)."""
+    per = n_total // world
+    return rank * per, (rank + 1) * per
+
+
+def rank_generator(seed: int, rank: int, device="cpu") -> torch.Generator:
+    """Independent per-rank RNG stream (the JAX driver splits its key per device, jax/inference.py:92,136)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) * 1000003 + int(rank))
+    return g
+
+
+def allreduce_mean_(buf: torch.Tensor) -> torch.Tensor:
+    """In-place mean over ranks (== lax.pmean). One collective for the whole fused buffer."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        buf.div_(dist.get_world_size())
+    return buf
+
+
+def allreduce_max_(buf: torch.Tensor) -> torch.Tensor:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+    return buf
+
+
+def gather_rows(local: torch.Tensor) -> torch.Tensor:
+    """Final gather of per-rank rows (MAP solutions, HMC chains): concatenation in rank order."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    out = [torch.empty_like(local) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, local.contiguous())
+    return torch.cat(out, dim=0)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,114 @@
+"""Synthetic workloads C1-C4 of BASELINE.json / SURVEY.md 8(d): physical model, prior, camera and batch.
+
+All inputs are synthetic (there is no network for data): priors borrowed from the reference's
+``tests/conftest.py:26-66`` and ``shapelets-demo.ipynb`` cell 4; the "observed" image of a workload is
+the forward simulation of one fixed truth draw plus Gaussian noise with the model's own sigma.
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from gigalens_amd import prior as tfd
+from gigalens_amd.model import PhysicalModel
+from gigalens_amd.profiles.light.sersic import Sersic, SersicEllipse
+from gigalens_amd.profiles.light.shapelets import Shapelets
+from gigalens_amd.profiles.mass.epl import EPL
+from gigalens_amd.profiles.mass.nfw import NFW
+from gigalens_amd.profiles.mass.shear import Shear
+from gigalens_amd.profiles.mass.sie import SIE
+from gigalens_amd.simulator import SimulatorConfig
+
+
+@dataclass
+class Workload:
+    name: str
+    phys_model: PhysicalModel
+    prior: tfd.JointDistributionNamed
+    sim_config: SimulatorConfig
+    batch: int
+    background_rms: float = 0.2
+    exp_time: float = 100.0
+    use_error_map: bool = False
+    description: str = ""
+
+
+def _epl_prior():
+    return tfd.JointDistributionNamed(dict(
+        theta_E=tfd.LogNormal(math.log(1.25), 0.25), gamma=tfd.TruncatedNormal(2, 0.25, 1, 3),
+        e1=tfd.Normal(0, 0.1), e2=tfd.Normal(0, 0.1), center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05)))
+
+
+def _shear_prior():
+    return tfd.JointDistributionNamed(dict(gamma1=tfd.Normal(0, 0.05), gamma2=tfd.Normal(0, 0.05)))
+
+
+def _sersic_src_prior(center_sigma=0.25, uniform_center=None):
+    if uniform_center is None:
+        cx, cy = tfd.Normal(0, center_sigma), tfd.Normal(0, center_sigma)
+    else:
+        cx, cy = tfd.Uniform(-uniform_center, uniform_center), tfd.Uniform(-uniform_center, uniform_center)
+    return tfd.JointDistributionNamed(dict(
+        R_sersic=tfd.LogNormal(math.log(0.25), 0.15), n_sersic=tfd.Uniform(0.5, 4), center_x=cx, center_y=cy,
+        Ie=tfd.LogNormal(math.log(150.0), 0.5)))
+
+
+def make(name: str, num_pix: Optional[int] = None, batch: Optional[int] = None, interpolate: bool = True,
+         n_max: int = 10, n_halos: int = 8, n_sources: int = 20) -> Workload:
+    name = name.upper()
+    if name == "C1":  # SIE + Sersic source, 64x64, B=1
+        phys = PhysicalModel([SIE()], [], [Sersic()])
+        prior = tfd.JointDistributionNamed(dict(
+            lens_mass=tfd.JointDistributionSequential([tfd.JointDistributionNamed(dict(
+                theta_E=tfd.LogNormal(math.log(1.25), 0.25), e1=tfd.Normal(0, 0.1), e2=tfd.Normal(0, 0.1),
+                center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05)))]),
+            source_light=tfd.JointDistributionSequential([_sersic_src_prior()])))
+        return Workload("C1", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 64), batch or 1,
+                        description="SIE lens + Sersic source")
+    if name == "C2":  # EPL + Shear + Sersic source, 128x128, B=1024
+        phys = PhysicalModel([EPL(), Shear()], [], [Sersic()])
+        prior = tfd.JointDistributionNamed(dict(
+            lens_mass=tfd.JointDistributionSequential([_epl_prior(), _shear_prior()]),
+            source_light=tfd.JointDistributionSequential([_sersic_src_prior()])))
+        return Workload("C2", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 128), batch or 1024,
+                        description="EPL+shear lens, Sersic source")
+    if name == "C3":  # EPL + Shear + Shapelets(n_max) source, error_map
+        shp = Shapelets(n_max=n_max, interpolate=interpolate)
+        phys = PhysicalModel([EPL(), Shear()], [], [shp])
+        amps = {nm: tfd.Normal(0, 500.0 / math.sqrt(i + 1)) for i, nm in enumerate(shp._amp_names)}
+        src = tfd.JointDistributionNamed(dict(beta=tfd.LogNormal(math.log(0.1), 0.15), center_x=tfd.Normal(0, 0.01),
+                                              center_y=tfd.Normal(0, 0.01), **amps))
+        prior = tfd.JointDistributionNamed(dict(
+            lens_mass=tfd.JointDistributionSequential([_epl_prior(), _shear_prior()]),
+            source_light=tfd.JointDistributionSequential([src])))
+        return Workload("C3", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 128), batch or 1024,
+                        use_error_map=True, description=f"EPL+shear lens, Shapelets n_max={n_max} source "
+                        f"({'table' if interpolate else 'direct'} mode)")
+    if name == "C4":  # cluster: 8 NFW + 20 Sersic sources, 256x256, B=512
+        phys = PhysicalModel([NFW() for _ in range(n_halos)], [], [Sersic() for _ in range(n_sources)])
+        halo = lambda: tfd.JointDistributionNamed(dict(
+            Rs=tfd.LogNormal(math.log(5.0), 0.3), alpha_Rs=tfd.LogNormal(math.log(1.0), 0.3),
+            center_x=tfd.Uniform(-6, 6), center_y=tfd.Uniform(-6, 6)))
+        prior = tfd.JointDistributionNamed(dict(
+            lens_mass=tfd.JointDistributionSequential([halo() for _ in range(n_halos)]),
+            source_light=tfd.JointDistributionSequential([_sersic_src_prior(uniform_center=4.0) for _ in range(n_sources)])))
+        return Workload("C4", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 256), batch or 512,
+                        description=f"cluster: {n_halos} NFW halos + {n_sources} Sersic sources")
+    raise ValueError(f"unknown workload {name}")
+
+
+def synthetic_observation(wl: Workload, simulator_cls, seed_truth=1, seed_noise=2):
+    """Observed image = simulate(truth) + N(0, sigma_model); returns (obs, err_map_or_None, truth)."""
+    truth = wl.prior.sample(1, seed=seed_truth)
+    sim1 = simulator_cls(wl.phys_model, wl.sim_config, bs=1)
+    img = sim1.simulate(truth).reshape(wl.sim_config.num_pix, wl.sim_config.num_pix)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed_noise)
+    noise = torch.randn(img.shape, generator=g, dtype=torch.float32).to(img.device)
+    if wl.use_error_map:
+        sigma = torch.full_like(img, float(0.05 * img.abs().max().clamp_min(1e-3) + wl.background_rms))
+        return (img + sigma * noise).contiguous(), sigma.contiguous(), truth
+    sigma = torch.sqrt(wl.background_rms ** 2 + img.clamp_min(0) / wl.exp_time)
+    return (img + sigma * noise).contiguous(), None, truth

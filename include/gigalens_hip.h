@@ -106,8 +106,8 @@ int gl_simulate_bwd(const gl_model* m, const float* params, const float* grad_im
 /* ForwardProbModel.stats_pixels (tf/model.py:89-101) fused with simulate() and, when
  * grad_params != NULL, with its gradient d loglike / d params [B,P].
  *   obs [H,W]; err_or_null [H,W] (error_map, wins over bg_rms/exp_time, tf/model.py:92-95);
- *   mask_or_null [H,W] (simulator.img_region weights); loglike [B]; chi2 [B] (= chi^2, NOT reduced);
- *   red_chi2 = chi2 / count_nonzero(mask) is returned through chi2_count (host scalar, may be NULL). */
+ *   mask_or_null [H,W] (simulator.img_region weights); loglike [B]; chi2 [B] (= chi^2, NOT reduced:
+ *   the caller divides by count_nonzero(img_region), tf/model.py:100). */
 int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs, const float* err_or_null,
                        const float* mask_or_null, float bg_rms, float exp_time, int B, float* loglike,
                        float* chi2, float* grad_params_or_null, void* workspace, size_t workspace_bytes,
@@ -122,6 +122,12 @@ int gl_profile_eval(const gl_component* comp, const float* x, const float* y, in
                     int xy_batched, const float* params, float* out0, float* out1, void* hip_stream);
 
 int gl_kind_num_params(const gl_component* comp); /* length of the reference's params list for this profile */
+
+/* Measurement hooks (bench.py / rocprof cross-check): when enabled, every subsequent call records a pair of
+ * HIP events on the CALLER'S stream around its dominant ("main") kernel launch; gl_model_last_main_ms
+ * synchronises on the second event and returns the elapsed milliseconds of the most recent main launch. */
+int gl_model_set_timing(gl_model* m, int enabled);
+int gl_model_last_main_ms(gl_model* m, float* ms);
 
 const char* gl_last_error(void);
 const char* gl_version(void);

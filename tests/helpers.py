@@ -1,0 +1,44 @@
+"""Shared helpers for the parity tests (oracle <-> product plumbing)."""
+import numpy as np
+import torch
+
+GROUPS = ("lens_mass", "lens_light", "source_light")
+
+
+def struct_from_packed(phys, packed):
+    """[B,P] component-major packed rows -> the reference's nested {'lens_mass': [{name: (B,)}], ...}."""
+    k = 0
+    out = {}
+    for g, profs in zip(GROUPS, (phys.lenses, phys.lens_light, phys.source_light)):
+        lst = []
+        for p in profs:
+            d = {}
+            for n in p.params:
+                d[n] = packed[:, k]
+                k += 1
+            lst.append(d)
+        out[g] = lst
+    assert k == packed.shape[1]
+    return out
+
+
+def sample_packed(wl, sim, seed):
+    """Draw B parameter sets from the workload prior and pack them (float32, on sim.device)."""
+    x = wl.prior.sample(sim.bs, seed=seed)
+    return sim.pack(x)
+
+
+def oracle_loglike_and_grad(wl, packed64, obs, err, bs, dtype=torch.float64):
+    from oracle import ref_torch as ref
+    rs = ref.RefSimulator(wl.phys_model, wl.sim_config, bs, dtype=dtype)
+    p = packed64.clone().to(dtype).requires_grad_(True)
+    params = struct_from_packed(wl.phys_model, p)
+    ll, red = ref.stats_pixels(rs, params, obs, wl.background_rms, wl.exp_time, error_map=err)
+    (g,) = torch.autograd.grad(ll.sum(), p)
+    img = rs.simulate(struct_from_packed(wl.phys_model, packed64.to(dtype)))
+    return ll.detach().numpy(), red.detach().numpy(), g.numpy(), img.detach().numpy()
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)

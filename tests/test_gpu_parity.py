@@ -1,0 +1,336 @@
+"""GPU parity tests: the HIP path, called through the product API (ctypes -> C ABI), against the oracle.
+
+Tolerances (fp32 kernels vs the float64 restatement of the reference, BASELINE.json north_star):
+  * image pixels        rtol 2e-5 of the image maximum
+  * chi^2 / log-like    rtol 1e-5
+  * parameter gradients rtol 2e-3 of the per-sample gradient maximum (fp32 sums of ~N terms with cancellation)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+IMG_RTOL = 2e-5
+LL_RTOL = 1e-5
+GRAD_RTOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def gl():
+    import __graft_entry__ as ge
+    from gigalens_amd import _native
+    if not __import__("os").path.exists(_native.lib_path()):
+        ge.build()
+    _native.lib()
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from gigalens_amd import workloads
+    from gigalens_amd.model import ForwardProbModel
+    from gigalens_amd.simulator import LensSimulator
+
+    class NS:
+        pass
+    ns = NS()
+    ns.workloads, ns.ForwardProbModel, ns.LensSimulator = workloads, ForwardProbModel, LensSimulator
+    return ns
+
+
+# ---------------------------------------------------------------------------------------------------
+# plugin level: the reference's own test recipes (tests/test_profiles.py), through MassProfile.deriv /
+# LightProfile.light on the GPU, against the published closed forms and the oracle
+# ---------------------------------------------------------------------------------------------------
+def _pts(n, seed=0):
+    r = np.random.default_rng(seed)
+    return r.normal(size=n).astype(np.float32), r.normal(size=n).astype(np.float32)
+
+
+def test_sersic_ellipse_known_answer(gl):
+    from gigalens_amd.profiles.light.sersic import SersicEllipse
+    from oracle import ref_torch as ref
+    se = SersicEllipse(use_lstsq=False)
+    lp = dict(R_sersic=1.0, n_sersic=2.0, center_x=0.0, center_y=0.0, e1=0.0, e2=0.0, Ie=5.0)
+    a = se.light(x=0.0, y=1.0, **lp)
+    assert math.isclose(float(a), 5.0, rel_tol=1e-6)  # tests/test_profiles.py:25-26
+    x, y = _pts(1000)
+    a = se.light(x=x, y=y, **lp).cpu().numpy()
+    b = ref.sersic_light(torch.as_tensor(x, dtype=torch.float64), torch.as_tensor(y, dtype=torch.float64),
+                         1.0, 2.0, 0.0, 0.0, 5.0, 0.0, 0.0).numpy()
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kw", [dict(theta_E=1.0, gamma=2.0, e1=0.0, e2=0.0, center_x=0.0, center_y=0.0),
+                                dict(theta_E=1.2, gamma=2.2, e1=-0.1, e2=0.1, center_x=0.0, center_y=0.0)])
+def test_epl_recipe(gl, kw):
+    from gigalens_amd.profiles.mass.epl import EPL
+    from oracle import published as pub
+    x, y = _pts(10000)
+    fx, fy = EPL(100).deriv(x=x, y=y, **kw)
+    px, py = pub.epl_deriv_2f1(x, y, kw["theta_E"], kw["gamma"], kw["e1"], kw["e2"])
+    assert np.allclose(fx.cpu().numpy(), px, rtol=1e-5, atol=1e-4)  # tests/test_profiles.py:57-58
+    assert np.allclose(fy.cpu().numpy(), py, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("kw", [dict(theta_E=1.0, center_x=0.0, center_y=0.0, e1=1e-3, e2=1e-3),
+                                dict(theta_E=1.2, center_x=0.0, center_y=0.0, e1=0.1, e2=-0.1)])
+def test_sie_recipe(gl, kw):
+    from gigalens_amd.profiles.mass.sie import SIE
+    from oracle import published as pub
+    x, y = _pts(10000, 1)
+    fx, fy = SIE().deriv(x=x, y=y, **kw)
+    px, py = pub.epl_deriv_2f1(x, y, kw["theta_E"], 2.0, kw["e1"], kw["e2"])
+    assert np.allclose(fx.cpu().numpy(), px, rtol=1e-5, atol=1e-4)
+    assert np.allclose(fy.cpu().numpy(), py, rtol=1e-5, atol=1e-4)
+
+
+def test_sis_shear_nfw_recipes(gl):
+    from gigalens_amd.profiles.mass.nfw import NFW
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.profiles.mass.sis import SIS
+    from oracle import published as pub
+    from oracle import ref_torch as ref
+    x, y = _pts(10000, 2)
+    for te in (1.0, 1.2):
+        fx, fy = SIS().deriv(x=x, y=y, theta_E=te, center_x=0.0, center_y=0.0)
+        px, py = pub.sis_deriv(x, y, te)
+        assert np.allclose(fx.cpu().numpy(), px, rtol=1e-5, atol=1e-6) and np.allclose(fy.cpu().numpy(), py, rtol=1e-5, atol=1e-6)
+    for g1, g2 in ((0.0, 0.0), (0.1, 0.1)):
+        fx, fy = Shear().deriv(x=x, y=y, gamma1=g1, gamma2=g2)
+        px, py = pub.shear_deriv(x, y, g1, g2)
+        assert np.allclose(fx.cpu().numpy(), px, atol=1e-6) and np.allclose(fy.cpu().numpy(), py, atol=1e-6)
+    fx, fy = NFW().deriv(x=x * 3, y=y * 3, Rs=1.7, alpha_Rs=0.9, center_x=0.1, center_y=-0.2)
+    ox, oy = ref.nfw_deriv(torch.as_tensor(x * 3, dtype=torch.float64), torch.as_tensor(y * 3, dtype=torch.float64),
+                           1.7, 0.9, 0.1, -0.2)
+    assert np.allclose(fx.cpu().numpy(), ox.numpy(), rtol=2e-5, atol=2e-6)
+    assert np.allclose(fy.cpu().numpy(), oy.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("interpolate", [True, False])
+def test_shapelets_recipe(gl, interpolate):
+    from gigalens_amd.profiles.light.shapelets import Shapelets
+    from oracle import published as pub
+    shp = Shapelets(n_max=5, use_lstsq=False, interpolate=interpolate)
+    r = np.random.default_rng(3)
+    amplitudes = r.normal(size=(shp.n_layers, 1)).astype(np.float32)
+    amp = {n: a for n, a in zip(shp._amp_names, amplitudes)}
+    x, y = r.normal(size=(5, 5, 1)).astype(np.float32), r.normal(size=(5, 5, 1)).astype(np.float32)
+    a = shp.light(x=x, y=y, center_x=0, center_y=0, beta=1, **amp).cpu().numpy()
+    b = pub.shapelet_set(x.ravel(), y.ravel(), amplitudes.ravel().astype(np.float64), 5, 1.0)
+    assert a.shape == (5, 5, 1)
+    assert np.allclose(a.ravel(), b, rtol=1e-5, atol=1e-4)  # tests/test_profiles.py:47
+
+
+# ---------------------------------------------------------------------------------------------------
+# simulator + likelihood level vs the oracle at sizes the oracle finishes in seconds
+# ---------------------------------------------------------------------------------------------------
+CASES = [
+    ("C1", dict(num_pix=64, batch=1)),
+    ("C1", dict(num_pix=24, batch=5)),
+    ("C2", dict(num_pix=32, batch=8)),
+    ("C2", dict(num_pix=47, batch=3)),   # ragged: 2209 pixels, not a multiple of the tile
+    ("C3", dict(num_pix=32, batch=4, interpolate=False)),
+    ("C3", dict(num_pix=32, batch=4, interpolate=True)),
+    ("C3", dict(num_pix=20, batch=3, interpolate=True, n_max=4)),
+    ("C4", dict(num_pix=40, batch=4, n_halos=3, n_sources=4)),
+    ("C4", dict(num_pix=32, batch=2)),
+]
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+def test_simulate_loglike_grad_vs_oracle(gl, name, kw):
+    wl = gl.workloads.make(name, **kw)
+    obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    packed = H.sample_packed(wl, sim, seed=11)
+    obs_np = obs.cpu().numpy()
+    err_np = None if err is None else err.cpu().numpy()
+    ll_o, red_o, g_o, img_o = H.oracle_loglike_and_grad(wl, packed.cpu().double(), obs_np, err_np, wl.batch)
+
+    img = sim.simulate(packed).cpu().numpy().reshape(img_o.shape)
+    assert np.abs(img - img_o).max() <= IMG_RTOL * np.abs(img_o).max() + 1e-7
+
+    pm = gl.ForwardProbModel(wl.prior, obs_np, wl.background_rms, wl.exp_time, error_map=err_np, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, red = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    assert np.allclose(ll.detach().cpu().numpy(), ll_o, rtol=LL_RTOL)
+    assert np.allclose(red.detach().cpu().numpy(), red_o, rtol=LL_RTOL)
+    g = p.grad.cpu().numpy()
+    # per-sample gradient scale; a sample whose source misses the field entirely has an all-zero oracle
+    # gradient, so the floor is tied to the batch-wide scale (table-mode shapelets are discontinuous at |u|=5)
+    scale = np.maximum(np.abs(g_o).max(axis=1, keepdims=True), 1e-3 * np.abs(g_o).max())
+    bad = np.abs(g - g_o) > GRAD_RTOL * scale + 1e-6
+    assert not bad.any(), (np.argwhere(bad)[:5], g[bad][:5], g_o[bad][:5], scale.ravel())
+
+    # forward-only entry (grad_params == NULL, a different kernel instantiation) agrees to rounding
+    ll2, _ = pm._pixel_stats_packed(sim, packed)
+    assert torch.allclose(ll2, ll.detach(), rtol=2e-6)
+
+    # image-boundary pair (gl_simulate_fwd / gl_simulate_bwd): same gradient through the materialised image
+    p2 = packed.clone().requires_grad_(True)
+    im = sim.simulate(p2).reshape(wl.batch, wl.sim_config.num_pix, wl.sim_config.num_pix)
+    if err is None:
+        sig2 = wl.background_rms ** 2 + im / wl.exp_time
+    else:
+        sig2 = (err ** 2).expand_as(im)
+    ll3 = -0.5 * (((im - obs) ** 2 / sig2).sum((-2, -1)) + torch.log(2 * math.pi * sig2).sum((-2, -1)))
+    ll3.sum().backward()
+    g3 = p2.grad.cpu().numpy()
+    bad = np.abs(g3 - g_o) > GRAD_RTOL * scale + 1e-6
+    assert not bad.any(), (np.argwhere(bad)[:5], g3[bad][:5], g_o[bad][:5])
+    assert np.allclose(ll3.detach().cpu().numpy(), ll_o, rtol=5e-5)
+
+
+def test_log_prob_layout_and_prior(gl):
+    """z column k == k-th leaf in tf.nest.flatten order; log_prob = log_like + prior + log|J| (tf/model.py:148-167)."""
+    wl = gl.workloads.make("C2", num_pix=24, batch=6)
+    obs, _, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    pm = gl.ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time, include_positions=False)
+    x = wl.prior.sample(wl.batch, seed=3)
+    z = pm.bij.inverse(x)
+    assert z.shape == (wl.batch, 13)
+    # App. B of SURVEY.md: center_x center_y e1 e2 gamma theta_E | gamma1 gamma2 | Ie R_sersic center_x center_y n_sersic
+    assert torch.allclose(z[:, 5].cpu(), torch.log(x["lens_mass"][0]["theta_E"]).cpu(), atol=1e-6)
+    assert torch.allclose(z[:, 6].cpu(), x["lens_mass"][1]["gamma1"].cpu())
+    assert torch.allclose(z[:, 8].cpu(), torch.log(x["source_light"][0]["Ie"]).cpu(), atol=1e-6)
+    back = pm.bij.forward(z)
+    for a, b in zip(__import__("gigalens_amd.prior", fromlist=["x"]).nest_flatten(back),
+                    __import__("gigalens_amd.prior", fromlist=["x"]).nest_flatten(x)):
+        assert torch.allclose(a.cpu(), b.cpu(), rtol=2e-5, atol=1e-6)
+    z = z.to("cuda").requires_grad_(True)
+    lp, red = pm.log_prob(sim, z)
+    ll = pm.log_like(sim, z.detach())
+    lpr = pm.log_prior(z.detach())
+    assert torch.allclose(lp.detach(), ll + lpr, rtol=1e-6)
+    ll_s, red_s = pm.stats_pixels(sim, x)
+    # stats_pixels takes x itself, log_prob takes forward(inverse(x)): equal up to the fp32 bijector round trip
+    assert torch.allclose(ll_s, ll, rtol=1e-4) and torch.allclose(red_s, red.detach(), rtol=1e-4)
+    lp.sum().backward()
+    assert torch.isfinite(z.grad).all() and (z.grad.abs().sum(0) > 0).all()
+    # finite-difference check of d log_prob / dz through bijector + kernels (float32: loose)
+    k, eps = 5, 1e-3
+    zp, zm = z.detach().clone(), z.detach().clone()
+    zp[:, k] += eps
+    zm[:, k] -= eps
+    fd = (pm.log_prob(sim, zp)[0] - pm.log_prob(sim, zm)[0]) / (2 * eps)
+    assert torch.allclose(fd, z.grad[:, k], rtol=5e-2, atol=5e-2 * float(z.grad[:, k].abs().max()))
+
+
+def test_pix_region_and_constants(gl):
+    """pix_region masks pixels out of the render and the likelihood (tf/simulator.py:34-44, tf/model.py:97-100);
+    fixed parameters arrive through *_constants (model.py:29-44)."""
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import SersicEllipse
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.simulator import SimulatorConfig
+    from oracle import ref_torch as ref
+    n = 28
+    yy, xx = np.mgrid[:n, :n]
+    mask = (((xx - 13.5) ** 2 + (yy - 13.5) ** 2) < 11 ** 2).astype(np.float32)
+    phys = PhysicalModel([EPL(), Shear()], [SersicEllipse()], [SersicEllipse()],
+                         lenses_constants=[{"center_x": 0.01, "center_y": -0.02}, {}],
+                         lens_light_constants=[{"n_sersic": 3.0}], source_light_constants=[{}])
+    cfg = SimulatorConfig(delta_pix=0.08, num_pix=n, pix_region=mask)
+    B = 4
+    sim = gl.LensSimulator(phys, cfg, bs=B)
+    r = np.random.default_rng(0)
+    f = lambda lo, hi: torch.tensor(r.uniform(lo, hi, size=B).astype(np.float32))
+    params = {
+        "lens_mass": [dict(theta_E=f(0.8, 1.2), gamma=f(1.8, 2.3), e1=f(-0.2, 0.2), e2=f(-0.2, 0.2)),
+                      dict(gamma1=f(-0.05, 0.05), gamma2=f(-0.05, 0.05))],
+        "lens_light": [dict(R_sersic=f(0.5, 1.0), e1=f(-0.1, 0.1), e2=f(-0.1, 0.1), center_x=f(-0.05, 0.05),
+                            center_y=f(-0.05, 0.05), Ie=f(10, 30))],
+        "source_light": [dict(R_sersic=f(0.1, 0.3), n_sersic=f(1, 3), e1=f(-0.3, 0.3), e2=f(-0.3, 0.3),
+                              center_x=f(-0.2, 0.2), center_y=f(-0.2, 0.2), Ie=f(50, 150))],
+    }
+    img = sim.simulate(params).cpu().numpy()
+    rs = ref.RefSimulator(phys, cfg, B, dtype=torch.float64)
+    img_o = rs.simulate({k: [{n: v.double() for n, v in d.items()} for d in lst] for k, lst in params.items()}).numpy()
+    assert np.abs(img - img_o).max() <= IMG_RTOL * np.abs(img_o).max()
+    assert np.all(img[:, mask == 0] == 0)
+    obs = img_o[0] + 0.05 * r.normal(size=(n, n))
+    pm = gl.ForwardProbModel(_dummy_prior(), obs, 0.2, 100.0, include_positions=False)
+    ll, red = pm.stats_pixels(sim, params)
+    ll_o, red_o = ref.stats_pixels(rs, {k: [{n: v.double() for n, v in d.items()} for d in lst] for k, lst in params.items()},
+                                   obs, 0.2, 100.0)
+    assert np.allclose(ll.cpu().numpy(), ll_o.numpy(), rtol=LL_RTOL)
+    assert np.allclose(red.cpu().numpy(), red_o.numpy(), rtol=LL_RTOL)
+
+
+def _dummy_prior():
+    from gigalens_amd import prior as tfd
+    return tfd.JointDistributionNamed(dict(lens_mass=tfd.JointDistributionSequential(
+        [tfd.JointDistributionNamed(dict(theta_E=tfd.Normal(0, 1)))])))
+
+
+def test_nan_semantics_sie_circular(gl):
+    """SIE with e == 0 is 0/0 in the reference (sie.py:31-40 with s == 0): the image pixel becomes 0
+    (tf/simulator.py:140) and chi^2 is computed on that zero image."""
+    wl = gl.workloads.make("C1", num_pix=16, batch=2)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=2)
+    packed = H.sample_packed(wl, sim, seed=1)
+    packed[0, 1] = 0.0
+    packed[0, 2] = 0.0  # e1 = e2 = 0 for sample 0
+    img = sim.simulate(packed).cpu().numpy()
+    assert np.all(img[0] == 0) and np.all(np.isfinite(img)) and img[1].max() > 0
+
+
+def test_error_conventions(gl):
+    from gigalens_amd import _native
+    wl = gl.workloads.make("C2", num_pix=16, batch=2)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=2)
+    with pytest.raises(_native.NativeLibraryError):
+        sim._model.simulate_fwd(torch.zeros((2, 5), device="cuda"))  # wrong P
+    with pytest.raises(_native.NativeLibraryError):
+        sim._model.simulate_fwd(torch.zeros((2, sim._model.P)))  # CPU tensor: no CPU path
+    with pytest.raises(KeyError):
+        sim.simulate({"lens_mass": [{}, {}], "source_light": [{}]})
+
+
+# ---------------------------------------------------------------------------------------------------
+# full BASELINE sizes: size-independent properties (the oracle would take minutes here)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [("C2", {}), ("C4", dict(batch=64)), ("C3", dict(batch=128, interpolate=False))])
+def test_full_size_properties(gl, name, kw):
+    wl = gl.workloads.make(name, **kw)
+    obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    packed = H.sample_packed(wl, sim, seed=5)
+    pm = gl.ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time,
+                             error_map=None if err is None else err.cpu().numpy(), include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, red = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    # (1) fused log-likelihood == likelihood of the materialised image (independent kernels + torch reductions, f64)
+    im = sim.simulate(packed).double()
+    o = obs.double()
+    sig2 = (wl.background_rms ** 2 + im / wl.exp_time) if err is None else (err.double() ** 2).expand_as(im)
+    ll_img = -0.5 * (((im - o) ** 2 / sig2).sum((-2, -1)) + torch.log(2 * math.pi * sig2).sum((-2, -1)))
+    assert torch.allclose(ll.detach().double(), ll_img, rtol=LL_RTOL)
+    # (2) batch independence / determinism: a sub-batch gives bitwise the same rows
+    sim_small = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=7)
+    ll_small, _ = pm._pixel_stats_packed(sim_small, packed[:7].clone())
+    assert torch.allclose(ll_small, ll.detach()[:7], rtol=1e-6)
+    ll_again, _ = pm._pixel_stats_packed(sim, packed)          # forward-only kernel instantiation
+    assert torch.allclose(ll_again, ll.detach(), rtol=2e-6)
+    p_again = packed.clone().requires_grad_(True)
+    ll_rep, _ = pm._pixel_stats_packed(sim, p_again)             # same instantiation twice: bitwise reproducible
+    ll_rep.sum().backward()
+    assert torch.equal(ll_rep.detach(), ll.detach()) and torch.equal(p_again.grad, p.grad)
+    # (3) linearity of the render in the source amplitudes
+    scaled = packed.clone()
+    last = wl.phys_model.source_light[-1]
+    if last.name.startswith("SERSIC"):
+        scaled[:, -1] *= 2.0
+        only = packed.clone()
+        delta = (sim.simulate(scaled) - sim.simulate(packed))
+        other = packed.clone()
+        other[:, -1] *= 3.0
+        delta2 = (sim.simulate(other) - sim.simulate(packed))
+        assert torch.allclose(2 * delta, delta2, rtol=1e-4, atol=1e-5 * float(delta2.abs().max()))
+    assert torch.isfinite(p.grad).all()
