@@ -25,6 +25,11 @@ class gl_component(ctypes.Structure):
     _fields_ = [("kind", c_int32), ("iparam", c_int32), ("flags", c_uint32), ("reserved", c_int32)]
 
 
+class gl_zcolumn(ctypes.Structure):
+    _fields_ = [("param_col", c_int32), ("bijector", c_int32), ("prior", c_int32), ("a", c_float), ("b", c_float),
+                ("lo", c_float), ("hi", c_float), ("log_norm", c_float)]
+
+
 class gl_grid(ctypes.Structure):
     _fields_ = [
         ("height", c_int32), ("width", c_int32), ("supersample", c_int32), ("n_region", c_int32),
@@ -45,6 +50,9 @@ SYMBOLS = {
     "gl_simulate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gl_loglike_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gl_model_set_prior": (c_int, [c_void_p, POINTER(gl_zcolumn), c_int, POINTER(c_float)]),
+    "gl_logprob_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     "gl_kind_num_params": (c_int, [POINTER(gl_component)]),
@@ -181,6 +189,30 @@ class Model:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.gl_model_destroy(h)
+
+    def set_prior(self, columns, const_row):
+        """columns: list of (param_col, bijector, prior, a, b, lo, hi, log_norm); const_row: [P] floats."""
+        arr = (gl_zcolumn * max(len(columns), 1))(*[gl_zcolumn(*c) for c in columns])
+        cr = np.ascontiguousarray(const_row, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _check(lib().gl_model_set_prior(self._h, arr, len(columns), cr.ctypes.data_as(POINTER(c_float))))
+        self.d_z = len(columns)
+
+    def logprob(self, z, obs, err, mask, bg_rms, exp_time, want_grad):
+        _require_cuda(z, "z")
+        if z.dtype != torch.float32 or z.dim() != 2 or z.shape[1] != self.d_z:
+            raise NativeLibraryError(f"z must be float32 [B,{self.d_z}], got {z.dtype} {tuple(z.shape)}")
+        z = z.contiguous()
+        B = z.shape[0]
+        ws = self._workspace(B)
+        lp = torch.empty(B, dtype=torch.float32, device=z.device)
+        ll = torch.empty_like(lp)
+        chi2 = torch.empty_like(lp)
+        grad = torch.empty_like(z) if want_grad else None
+        _check(lib().gl_logprob_fwd_bwd(self._h, _ptr(z), _ptr(obs), _ptr(err), _ptr(mask), float(bg_rms),
+                                        float(exp_time), B, _ptr(lp), _ptr(ll), _ptr(chi2), _ptr(grad), _ptr(ws),
+                                        ws.numel(), _stream()))
+        return lp, ll, chi2, grad
 
     def set_timing(self, enabled=True):
         _check(lib().gl_model_set_timing(self._h, int(enabled)))

@@ -61,6 +61,13 @@ struct gl_model {
   int shp_stride = 0;
   float* d_psf = nullptr;
   int psf_h = 0, psf_w = 0;
+  // unconstrained-space front end (gl_model_set_prior)
+  int d_z = 0;
+  ZCol* d_zcols = nullptr;
+  int* d_src = nullptr;
+  float* d_const = nullptr;
+  bool has_epl = false;
+  bool use_order = true;
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int tile = 4;          // pixels per thread per tile (template T)
@@ -83,6 +90,8 @@ void chunking(const gl_model* m, int B, int* chunk, int* n_chunks) {
 struct Workspace {
   float* derived;
   float* partial;
+  float* params;  // [B,P] constrained rows produced from z (gl_logprob_fwd_bwd)
+  int* order;     // [B] cost-ordered dispatch
   float* img_ss;   // supersampled / pre-PSF image or its cotangent (PSF path only)
   float* img_tmp;  // second buffer for conv -> pool
   size_t bytes;
@@ -98,6 +107,10 @@ Workspace carve(const gl_model* m, int B, void* base) {
   off += align_up((size_t)B * m->D * sizeof(float), 256);
   w.partial = (float*)(p + off);
   off += align_up((size_t)B * n_chunks * m->A * sizeof(float), 256);
+  w.params = (float*)(p + off);
+  off += align_up((size_t)B * std::max(m->P, 1) * sizeof(float), 256);
+  w.order = (int*)(p + off);
+  off += align_up((size_t)B * sizeof(int), 256);
   const bool post = m->d_psf || m->supersample != 1;
   if (post) {
     size_t img = align_up((size_t)B * m->height * m->width * sizeof(float), 256);
@@ -170,10 +183,24 @@ int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, 
 }
 
 int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, const Workspace& w, float* loglike,
-                 float* chi2, float* grad, hipStream_t stream) {
-  hipLaunchKernelGGL(gl_finalize_kernel, dim3(B), dim3(128), (size_t)m->A * sizeof(float), stream, m->d_comps,
-                     (int)m->comps.size(), params, m->P, w.partial, n_chunks, m->A, loglike, chi2, grad);
+                 float* chi2, float* grad, hipStream_t stream, const float* z = nullptr, float* logprob = nullptr,
+                 float* grad_z = nullptr) {
+  size_t shmem = (size_t)(((m->A + 3) & ~3) + ((m->P + 3) & ~3) + ((m->d_z + 3) & ~3) + 4) * sizeof(float);
+  hipLaunchKernelGGL(gl_finalize_kernel, dim3(B), dim3(128), shmem, stream, m->d_comps, (int)m->comps.size(), params,
+                     m->P, w.partial, n_chunks, m->A, loglike, chi2, grad, z, m->d_z, z ? m->d_zcols : nullptr, logprob,
+                     grad_z);
   GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+// heaviest samples first (only EPL has a data-dependent cost)
+int run_order(const gl_model* m, int B, const Workspace& w, MainArgs* a, hipStream_t stream) {
+  a->order = nullptr;
+  if (!m->has_epl || !m->use_order || B < 2) return GL_OK;
+  hipLaunchKernelGGL(gl_order_kernel, dim3(1), dim3(256), 0, stream, m->d_comps, m->n_lens, w.derived, m->D, B,
+                     w.order);
+  GL_HIP(hipGetLastError());
+  a->order = w.order;
   return GL_OK;
 }
 
@@ -232,6 +259,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
       if (iparam <= 0) iparam = 50;  // epl.py:15
       if (iparam > 1000) { delete m; return fail(GL_EINVAL, "EPL niter %d too large", iparam); }
     }
+    if (c.kind == GL_EPL) m->has_epl = true;
     if (c.kind == GL_SHAPELETS) {
       if (iparam < 0 || iparam > GL_SHAPELETS_NMAX_CAP) {
         delete m;
@@ -265,6 +293,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   m->conversion_factor = grid->conversion_factor;
   m->tile = env_int("GIGALENS_HIP_TILE", 2) == 4 ? 4 : 2;
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
+  m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
   size_t shmem = (size_t)(((m->D + 3) & ~3) + 4 * m->Apad) * sizeof(float);
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
 
@@ -331,6 +360,9 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_pix) (void)hipFree(m->d_pix);
   if (m->d_shp_tab) (void)hipFree(m->d_shp_tab);
   if (m->d_psf) (void)hipFree(m->d_psf);
+  if (m->d_zcols) (void)hipFree(m->d_zcols);
+  if (m->d_src) (void)hipFree(m->d_src);
+  if (m->d_const) (void)hipFree(m->d_const);
   delete m;
 }
 
@@ -361,6 +393,7 @@ int gl_simulate_fwd(const gl_model* m, const float* params, int B, float* img, v
   if (m->d_pix) GL_HIP(hipMemsetAsync(img, 0, sizeof(float) * (size_t)B * m->height * m->width, stream));
   MainArgs a = base_args(m, w, chunk);
   a.img = img;
+  if ((rc = run_order(m, B, w, &a, stream))) return rc;
   return launch_main<IMG_FWD>(m, a, B, n_chunks, stream);
 }
 
@@ -377,6 +410,7 @@ int gl_simulate_bwd(const gl_model* m, const float* params, const float* grad_im
   if ((rc = run_prep(m, params, B, w, stream))) return rc;
   MainArgs a = base_args(m, w, chunk);
   a.gimg = grad_img;
+  if ((rc = run_order(m, B, w, &a, stream))) return rc;
   if ((rc = launch_main<IMG_BWD>(m, a, B, n_chunks, stream))) return rc;
   return run_finalize(m, params, B, n_chunks, w, nullptr, nullptr, grad_params, stream);
 }
@@ -399,10 +433,73 @@ int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs,
   a.mask = mask_or_null;
   a.bg2 = bg_rms * bg_rms;
   a.inv_t = 1.0f / exp_time;
+  if ((rc = run_order(m, B, w, &a, stream))) return rc;
   if (grad_params_or_null) rc = launch_main<LL_GRAD>(m, a, B, n_chunks, stream);
   else rc = launch_main<LL_FWD>(m, a, B, n_chunks, stream);
   if (rc) return rc;
   return run_finalize(m, params, B, n_chunks, w, loglike, chi2, grad_params_or_null, stream);
+}
+
+int gl_model_set_prior(gl_model* m, const gl_zcolumn* cols, int d, const float* const_row) {
+  if (!m) return fail(GL_EINVAL, "model is null");
+  if (d < 0 || (d > 0 && !cols)) return fail(GL_EINVAL, "bad prior column table");
+  std::vector<int> src(std::max(m->P, 1), -1);
+  std::vector<ZCol> zc(std::max(d, 1));
+  for (int k = 0; k < d; ++k) {
+    const gl_zcolumn& c = cols[k];
+    if (c.param_col < 0 || c.param_col >= m->P) return fail(GL_EINVAL, "z column %d: param_col %d out of range", k, c.param_col);
+    if (src[c.param_col] >= 0) return fail(GL_EINVAL, "packed column %d driven by two z columns", c.param_col);
+    if (c.bijector < 0 || c.bijector > 2 || c.prior < 0 || c.prior > 3) return fail(GL_EINVAL, "z column %d: unknown bijector/prior", k);
+    src[c.param_col] = k;
+    zc[k] = ZCol{c.param_col, c.bijector, c.prior, c.a, c.b, c.lo, c.hi, c.log_norm};
+  }
+  std::vector<float> cr(std::max(m->P, 1), 0.f);
+  for (int p = 0; p < m->P; ++p) {
+    if (src[p] < 0) {
+      if (!const_row) return fail(GL_EINVAL, "packed column %d has neither a z column nor a constant", p);
+      cr[p] = const_row[p];
+    }
+  }
+  if (m->d_zcols) { (void)hipFree(m->d_zcols); m->d_zcols = nullptr; }
+  if (m->d_src) { (void)hipFree(m->d_src); m->d_src = nullptr; }
+  if (m->d_const) { (void)hipFree(m->d_const); m->d_const = nullptr; }
+  GL_HIP(hipMalloc((void**)&m->d_zcols, sizeof(ZCol) * zc.size()));
+  GL_HIP(hipMalloc((void**)&m->d_src, sizeof(int) * src.size()));
+  GL_HIP(hipMalloc((void**)&m->d_const, sizeof(float) * cr.size()));
+  GL_HIP(hipMemcpy(m->d_zcols, zc.data(), sizeof(ZCol) * zc.size(), hipMemcpyHostToDevice));
+  GL_HIP(hipMemcpy(m->d_src, src.data(), sizeof(int) * src.size(), hipMemcpyHostToDevice));
+  GL_HIP(hipMemcpy(m->d_const, cr.data(), sizeof(float) * cr.size(), hipMemcpyHostToDevice));
+  m->d_z = d;
+  return GL_OK;
+}
+
+int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, const float* err_or_null,
+                       const float* mask_or_null, float bg_rms, float exp_time, int B, float* logprob, float* loglike,
+                       float* chi2, float* grad_z_or_null, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = check_call(m, z, B, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!m->d_zcols) return fail(GL_EINVAL, "gl_model_set_prior has not been called on this model");
+  if (!obs || !logprob || !loglike || !chi2) return fail(GL_EINVAL, "obs / logprob / loglike / chi2 is null");
+  if (m->d_psf || m->supersample != 1) return fail(GL_EUNSUPPORTED, "PSF / supersampling path not built yet");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  Workspace w = carve(m, B, workspace);
+  int chunk, n_chunks;
+  chunking(m, B, &chunk, &n_chunks);
+  int n_comp = (int)m->comps.size();
+  hipLaunchKernelGGL(gl_zprep_kernel, dim3((B * n_comp + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, z,
+                     m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D);
+  GL_HIP(hipGetLastError());
+  MainArgs a = base_args(m, w, chunk);
+  a.obs = obs;
+  a.err = err_or_null;
+  a.mask = mask_or_null;
+  a.bg2 = bg_rms * bg_rms;
+  a.inv_t = 1.0f / exp_time;
+  if ((rc = run_order(m, B, w, &a, stream))) return rc;
+  if (grad_z_or_null) rc = launch_main<LL_GRAD>(m, a, B, n_chunks, stream);
+  else rc = launch_main<LL_FWD>(m, a, B, n_chunks, stream);
+  if (rc) return rc;
+  return run_finalize(m, w.params, B, n_chunks, w, loglike, chi2, nullptr, stream, z, logprob, grad_z_or_null);
 }
 
 int gl_profile_eval(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,

@@ -50,6 +50,7 @@ struct MainArgs {
   float* partial;  // [B][n_chunks][A]
   const float* shp_tab;
   int shp_stride;
+  const int* order;  // cost-ordered dispatch: blockIdx.y -> sample index (heaviest first), or null
 };
 
 // ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
@@ -75,12 +76,15 @@ __device__ __forceinline__ float wave_sum63(float v) {
   v = dpp_add(v, 0x143, 0xC);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
   return v;
 }
-template <int G> __device__ __forceinline__ void wave_acc(float (&acc)[G], float* s_row, int lane) {
+// n <= G live accumulators (n is wave-uniform): slots beyond n belong to other components / waves
+template <int G> __device__ __forceinline__ void wave_acc(float (&acc)[G], float* s_row, int lane, int n = G) {
 #pragma unroll
-  for (int k = 0; k < G; ++k) acc[k] = wave_sum63(acc[k]);
+  for (int k = 0; k < G; ++k)
+    if (k < n) acc[k] = wave_sum63(acc[k]);
   if (lane == 63) {
 #pragma unroll
-    for (int k = 0; k < G; ++k) s_row[k] += acc[k];
+    for (int k = 0; k < G; ++k)
+      if (k < n) s_row[k] += acc[k];
   }
 }
 
@@ -104,6 +108,112 @@ __global__ void __launch_bounds__(128) gl_prep_kernel(const CompDesc* __restrict
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, d); break;
   }
+}
+
+// ---- unconstrained-space front/back end: bijector + prior fused into prep / finalize -------------
+// One ZCol per column k of z (the k-th leaf of the prior in tf.nest.flatten order, tf/model.py:76-87).
+// Default event-space bijectors and log-densities restate TFP's (Identity / Exp / Sigmoid(lo,hi);
+// Normal / LogNormal / Uniform / TruncatedNormal) -- see gigalens_amd/prior.py for the same maths in torch.
+struct ZCol {
+  int param_col;  // destination column in the packed [B,P] row
+  int bijector;   // 0 identity, 1 exp, 2 sigmoid(lo,hi)
+  int prior;      // 0 normal, 1 lognormal, 2 uniform, 3 truncated normal
+  float a, b, lo, hi, log_norm;
+};
+
+struct ZEval { float x, dxdz, logp_plus_fldj, dlogp_dx, dfldj_dz; };
+
+__device__ __forceinline__ ZEval z_eval(const ZCol& c, float z) {
+  ZEval o;
+  float fldj;
+  float lnx = 0.f;
+  if (c.bijector == 0) {
+    o.x = z; o.dxdz = 1.f; fldj = 0.f; o.dfldj_dz = 0.f;
+  } else if (c.bijector == 1) {
+    o.x = expf(z); o.dxdz = o.x; fldj = z; o.dfldj_dz = 1.f; lnx = z;
+  } else {
+    float sg = 1.f / (1.f + expf(-z));
+    float w = c.hi - c.lo;
+    o.x = c.lo + w * sg;
+    o.dxdz = w * sg * (1.f - sg);
+    // log(hi-lo) - softplus(-z) - softplus(z)
+    float az = fabsf(z);
+    fldj = logf(w) - az - 2.f * log1pf(expf(-az));
+    o.dfldj_dz = 1.f - 2.f * sg;
+  }
+  const float half_log_2pi = 0.91893853320467274178f;
+  float logp;
+  if (c.prior == 0 || c.prior == 3) {
+    float u = (o.x - c.a) / c.b;
+    logp = -0.5f * u * u - logf(c.b) - half_log_2pi - (c.prior == 3 ? c.log_norm : 0.f);
+    o.dlogp_dx = -u / c.b;
+    if (c.prior == 3 && !(o.x >= c.lo && o.x <= c.hi)) { logp = -INFINITY; o.dlogp_dx = 0.f; }
+  } else if (c.prior == 1) {
+    if (c.bijector != 1) lnx = logf(o.x);
+    float u = (lnx - c.a) / c.b;
+    logp = -0.5f * u * u - logf(c.b) - half_log_2pi - lnx;
+    o.dlogp_dx = (-u / c.b - 1.f) / o.x;
+  } else {
+    bool in = (o.x >= c.lo && o.x <= c.hi);
+    logp = in ? -logf(c.hi - c.lo) : -INFINITY;
+    o.dlogp_dx = 0.f;
+  }
+  o.logp_plus_fldj = logp + fldj;
+  return o;
+}
+
+// z [B,d] -> packed constrained rows [B,P] (also kept for finalize) -> derived constants
+__global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restrict__ comps, int n_comp,
+                                                       const float* __restrict__ z, int d_z,
+                                                       const ZCol* __restrict__ zcols, const int* __restrict__ src,
+                                                       const float* __restrict__ const_row, int P, int B,
+                                                       float* __restrict__ params, float* __restrict__ derived, int D) {
+  int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= B * n_comp) return;
+  int b = i / n_comp, c = i - b * n_comp;
+  CompDesc cd = comps[c];
+  float* p = params + (size_t)b * P + cd.p_off;
+  for (int j = 0; j < cd.n_par; ++j) {
+    int col = cd.p_off + j;
+    int k = src[col];
+    p[j] = (k >= 0) ? z_eval(zcols[k], z[(size_t)b * d_z + k]).x : const_row[col];
+  }
+  float* dd = derived + (size_t)b * D + cd.d_off;
+  switch (cd.kind) {
+    case K_EPL: epl_prep<float>(p, cd.iparam, dd); break;
+    case K_SIE: sie_prep<float>(p, dd); break;
+    case K_NFW: nfw_prep<float>(p, dd); break;
+    case K_SHEAR: shear_prep<float>(p, dd); break;
+    case K_SIS: sis_prep<float>(p, dd); break;
+    case K_SERSIC: sersic_prep<float>(p, false, dd); break;
+    case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, dd); break;
+    case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, dd); break;
+  }
+}
+
+// cost-ordered dispatch: samples sorted by descending EPL trip count (the only data-dependent cost on the
+// path), so the heaviest workgroups start first and the tail of the launch is filled with light ones.
+__global__ void __launch_bounds__(256) gl_order_kernel(const CompDesc* __restrict__ comps, int n_lens,
+                                                       const float* __restrict__ derived, int D, int B,
+                                                       int* __restrict__ order) {
+  __shared__ int hist[256];
+  __shared__ int offs[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  auto cost = [&](int b) {
+    int k = 0;
+    for (int l = 0; l < n_lens; ++l)
+      if (comps[l].kind == K_EPL) k += (int)derived[(size_t)b * D + comps[l].d_off + EPL_K];
+    return min(k, 255);
+  };
+  for (int b = threadIdx.x; b < B; b += 256) atomicAdd(&hist[cost(b)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 255; k >= 0; --k) { offs[k] = run; run += hist[k]; }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += 256) order[atomicAdd(&offs[cost(b)], 1)] = b;
 }
 
 // ---- T-pixel EPL: series loop outermost so one LDS table read serves T pixels -------------------
@@ -232,7 +342,7 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
   float* s_d = smem;
   float* s_acc = smem + ((a.D + 3) & ~3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
   const CompDesc* __restrict__ comps = a.comps;
   {
     const float* src = a.derived + (size_t)b * a.D;
@@ -356,7 +466,7 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
                                            src ? by[t] : y[t], gm[t], acc, dgx, dgy);
               if (src) { gbx[t] += dgx; gby[t] += dgy; }
             }
-            wave_acc<SHPA_AMP + SH_MAXL>(acc, s_row + cd.a_off, lane);
+            wave_acc<SHPA_AMP + SH_MAXL>(acc, s_row + cd.a_off, lane, cd.n_acc);
           }
         } else {
           float acc[SER_NACC];
@@ -428,12 +538,18 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
 }
 
 // ---- finalize: sum chunk partials (fixed order), chain rule to raw parameters -------------------
+// With zcols != null the gradient is carried on to the unconstrained vector z and the log-prior
+// + log|J| is added:  log_prob = loglike + sum_k [log p_k(x_k) + fldj_k(z_k)]   (tf/model.py:164-167).
 __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __restrict__ comps, int n_comp,
                                                           const float* __restrict__ params, int P,
                                                           const float* __restrict__ partial, int n_chunks, int A,
                                                           float* __restrict__ loglike, float* __restrict__ chi2,
-                                                          float* __restrict__ grad) {
-  extern __shared__ float s[];
+                                                          float* __restrict__ grad, const float* __restrict__ z,
+                                                          int d_z, const ZCol* __restrict__ zcols,
+                                                          float* __restrict__ logprob, float* __restrict__ grad_z) {
+  extern __shared__ float s[];  // [A] accumulators, then [P] parameter gradients, then [d_z] prior terms
+  float* s_g = s + ((A + 3) & ~3);
+  float* s_t = s_g + ((P + 3) & ~3);
   const int b = blockIdx.x;
   const float* src = partial + (size_t)b * n_chunks * A;
   for (int k = threadIdx.x; k < A; k += 128) {
@@ -442,25 +558,45 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
     s[k] = v;
   }
   __syncthreads();
-  if (threadIdx.x == 0 && loglike) {
-    loglike[b] = -0.5f * (s[0] + s[1]);  // tf/model.py:99
-    chi2[b] = s[0];
+  const bool want_grad = grad != nullptr || grad_z != nullptr;
+  if (want_grad) {
+    for (int c = threadIdx.x; c < n_comp; c += 128) {
+      CompDesc cd = comps[c];
+      const float* p = params + (size_t)b * P + cd.p_off;
+      float* g = s_g + cd.p_off;
+      const float* acc = s + cd.a_off;
+      switch (cd.kind) {
+        case K_EPL: epl_finalize<float>(p, acc, g); break;
+        case K_SIE: sie_finalize<float>(p, acc, g); break;
+        case K_NFW: nfw_finalize<float>(p, acc, g); break;
+        case K_SHEAR: shear_finalize<float>(p, acc, g); break;
+        case K_SIS: sis_finalize<float>(p, acc, g); break;
+        case K_SERSIC: sersic_finalize<float>(p, false, acc, g); break;
+        case K_SERSIC_ELLIPSE: sersic_finalize<float>(p, true, acc, g); break;
+        case K_SHAPELETS: shapelets_finalize<float>(p, cd.iparam, acc, g); break;
+      }
+    }
+    __syncthreads();
+    if (grad)
+      for (int k = threadIdx.x; k < P; k += 128) grad[(size_t)b * P + k] = s_g[k];
   }
-  if (!grad) return;
-  for (int c = threadIdx.x; c < n_comp; c += 128) {
-    CompDesc cd = comps[c];
-    const float* p = params + (size_t)b * P + cd.p_off;
-    float* g = grad + (size_t)b * P + cd.p_off;
-    const float* acc = s + cd.a_off;
-    switch (cd.kind) {
-      case K_EPL: epl_finalize<float>(p, acc, g); break;
-      case K_SIE: sie_finalize<float>(p, acc, g); break;
-      case K_NFW: nfw_finalize<float>(p, acc, g); break;
-      case K_SHEAR: shear_finalize<float>(p, acc, g); break;
-      case K_SIS: sis_finalize<float>(p, acc, g); break;
-      case K_SERSIC: sersic_finalize<float>(p, false, acc, g); break;
-      case K_SERSIC_ELLIPSE: sersic_finalize<float>(p, true, acc, g); break;
-      case K_SHAPELETS: shapelets_finalize<float>(p, cd.iparam, acc, g); break;
+  if (zcols) {
+    for (int k = threadIdx.x; k < d_z; k += 128) {
+      ZCol c = zcols[k];
+      ZEval e = z_eval(c, z[(size_t)b * d_z + k]);
+      s_t[k] = e.logp_plus_fldj;
+      if (grad_z) grad_z[(size_t)b * d_z + k] = (s_g[c.param_col] + e.dlogp_dx) * e.dxdz + e.dfldj_dz;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loglike) {
+    float ll = -0.5f * (s[0] + s[1]);  // tf/model.py:99
+    loglike[b] = ll;
+    chi2[b] = s[0];
+    if (zcols && logprob) {
+      float lp = 0.f;
+      for (int k = 0; k < d_z; ++k) lp += s_t[k];
+      logprob[b] = ll + lp;
     }
   }
 }

@@ -115,6 +115,24 @@ class _LogLikeFn(torch.autograd.Function):
         return g_ll[:, None] * grad, None, None, None, None, None, None
 
 
+class _LogProbFn(torch.autograd.Function):
+    """autograd glue around gl_logprob_fwd_bwd (bijector + kernels + prior in one native launch sequence)."""
+
+    @staticmethod
+    def forward(ctx, z, model, obs, err, mask, bg_rms, exp_time):
+        want = z.requires_grad
+        lp, ll, chi2, grad = model.logprob(z.detach(), obs, err, mask, bg_rms, exp_time, want)
+        if want:
+            ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(ll, chi2)
+        return lp, ll, chi2
+
+    @staticmethod
+    def backward(ctx, g_lp, g_ll, g_chi2):
+        (grad,) = ctx.saved_tensors
+        return g_lp[:, None] * grad, None, None, None, None, None, None
+
+
 class _PackBijector:
     """``pack_bij`` (tf/model.py:78-85): ``(B, d)`` <-> nested structure, column k = k-th nest leaf."""
 
@@ -211,6 +229,32 @@ class ForwardProbModel(ProbabilisticModel):
             self._perm_cache = {key: hit}
         return hit
 
+    def _bind_prior(self, simulator):
+        """Hand the prior / bijector column table to the simulator's native model (once per pairing)."""
+        model = simulator._model
+        if getattr(model, "_prior_owner", None) is not self:
+            slot_of = {(g, i, n): p for p, (g, i, n, _) in enumerate(simulator._layout.slots)}
+            columns = []
+            for k, (path, leaf) in enumerate(zip(self._paths, self._flat.leaves)):
+                if tuple(path) not in slot_of:
+                    raise KeyError(f"prior leaf {path} is not a parameter of the physical model")
+                a, b, lo, hi = leaf._p()
+                columns.append((slot_of[tuple(path)], leaf.bij, leaf.kind, a, b, lo, hi, float(self._flat.logz[k])))
+            const_row = np.zeros(simulator._layout.P, dtype=np.float32)
+            driven = {c[0] for c in columns}
+            for p, (g, i, n, const) in enumerate(simulator._layout.slots):
+                if p not in driven:
+                    if const is None:
+                        raise KeyError(f"{g}[{i}]['{n}'] has neither a prior nor a constant")
+                    const_row[p] = float(np.asarray(const, dtype=np.float32).reshape(-1)[0])
+            model.set_prior(columns, const_row)
+            model._prior_owner = self
+        return model
+
+    def _fused_ok(self, simulator):
+        return (self.include_pixels and not self.include_positions and simulator.supersample == 1
+                and simulator.kernel is None)
+
     def _packed_from_x(self, simulator, x):
         cols, consts = self._perm(simulator)
         if consts.numel():
@@ -223,8 +267,7 @@ class ForwardProbModel(ProbabilisticModel):
         ll, chi2 = _LogLikeFn.apply(packed, simulator._model, self.observed_image, self.error_map,
                                     simulator.img_region if simulator.sim_config.pix_region is not None else None,
                                     self.background_rms or 0.0, self.exp_time or 1.0)
-        n_eff = torch.count_nonzero(simulator.img_region).to(torch.float32)
-        return ll, chi2 / n_eff  # tf/model.py:100
+        return ll, chi2 / self._n_eff(simulator)  # tf/model.py:100
 
     def stats_pixels(self, simulator, params):
         """tf/model.py:89-101: ``params`` is the nested constrained structure."""
@@ -232,6 +275,25 @@ class ForwardProbModel(ProbabilisticModel):
 
     def log_prob(self, simulator, z):
         """tf/model.py:126-167: ``z`` is ``(bs, d)`` unconstrained; returns ``(log_prob, red_chi2)``."""
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        if self._fused_ok(simulator):
+            # bijector -> prep -> fused render/chi2/VJP -> finalize + prior, all inside the native library
+            model = self._bind_prior(simulator)
+            lp, _, chi2 = _LogProbFn.apply(z, model, self.observed_image, self.error_map,
+                                           simulator.img_region if simulator.sim_config.pix_region is not None else None,
+                                           self.background_rms or 0.0, self.exp_time or 1.0)
+            return lp, chi2 / self._n_eff(simulator)
+        return self.log_prob_unfused(simulator, z)
+
+    def _n_eff(self, simulator):
+        n = getattr(simulator, "_n_eff", None)
+        if n is None:
+            n = simulator._n_eff = float(torch.count_nonzero(simulator.img_region))
+        return n
+
+    def log_prob_unfused(self, simulator, z):
+        """Same quantity with the bijector and prior evaluated by torch ops around the likelihood kernels
+        (kept as the cross-check of the fused native path and for configurations it does not cover)."""
         z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
         x = self._flat.forward(z)
         log_like = torch.zeros(z.shape[0], dtype=torch.float32, device=self.device)

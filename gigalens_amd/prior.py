@@ -222,7 +222,10 @@ class FlatPrior:
     # -- bijector z -> x -------------------------------------------------------------------------
     def forward(self, z):
         sig = self.lo + (self.hi - self.lo) * torch.sigmoid(z)
-        return torch.where(self.bij == _ID, z, torch.where(self.bij == _EXP, torch.exp(z), sig))
+        # mask BEFORE exp: an identity column with |z| ~ 500 (shapelet amplitudes) would otherwise give
+        # exp(z) = inf in the unselected branch and 0 * inf = NaN in its backward
+        ze = torch.where(self.bij == _EXP, z, torch.zeros_like(z))
+        return torch.where(self.bij == _ID, z, torch.where(self.bij == _EXP, torch.exp(ze), sig))
 
     def inverse(self, x):
         u = ((x - self.lo) / (self.hi - self.lo)).clamp(1e-12, 1 - 1e-7)

@@ -113,6 +113,27 @@ int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs,
                        float* chi2, float* grad_params_or_null, void* workspace, size_t workspace_bytes,
                        void* hip_stream);
 
+/* Unconstrained-space front end: ForwardProbModel.log_prob (tf/model.py:126-167) in one launch sequence.
+ * Column k of z is the k-th leaf of the prior in tf.nest.flatten order (tf/model.py:76-87); each column
+ * carries its default event-space bijector and its scalar prior (TFP semantics restated):
+ *   bijector 0 Identity | 1 Exp | 2 Sigmoid(lo,hi);  prior 0 Normal(a,b) | 1 LogNormal(a,b) | 2 Uniform(lo,hi)
+ *   | 3 TruncatedNormal(a,b,lo,hi) with log_norm = log(Phi((hi-a)/b) - Phi((lo-a)/b)).
+ * const_row [P] supplies the packed columns no z column drives (the *_constants of PhysicalModel). */
+typedef struct gl_zcolumn {
+  int32_t param_col;
+  int32_t bijector;
+  int32_t prior;
+  float a, b, lo, hi, log_norm;
+} gl_zcolumn;
+int gl_model_set_prior(gl_model* m, const gl_zcolumn* cols, int d, const float* const_row);
+
+/* z [B,d] -> logprob [B] = loglike + log prior(x) + log|dx/dz|, loglike [B], chi2 [B] and, when
+ * grad_z_or_null != NULL, d logprob / d z [B,d] (what tf.GradientTape returns at tf/inference.py:33-39). */
+int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, const float* err_or_null,
+                       const float* mask_or_null, float bg_rms, float exp_time, int B, float* logprob,
+                       float* loglike, float* chi2, float* grad_z_or_null, void* workspace,
+                       size_t workspace_bytes, void* hip_stream);
+
 /* Plugin-level point evaluation, the reference's MassProfile.deriv / LightProfile.light called on
  * arbitrary coordinates (tests/test_profiles.py calls exactly these):
  *   x, y [n_pts, B] when xy_batched, else [n_pts] shared by every sample (pixel-major, batch-minor

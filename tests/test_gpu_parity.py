@@ -220,6 +220,30 @@ def test_log_prob_layout_and_prior(gl):
     assert torch.allclose(fd, z.grad[:, k], rtol=5e-2, atol=5e-2 * float(z.grad[:, k].abs().max()))
 
 
+@pytest.mark.parametrize("name,kw", [("C2", dict(num_pix=40, batch=33)), ("C4", dict(num_pix=32, batch=5, n_halos=2, n_sources=3)),
+                                     ("C3", dict(num_pix=24, batch=6, interpolate=False, n_max=6))])
+def test_fused_log_prob_matches_unfused(gl, name, kw):
+    """gl_logprob_fwd_bwd (bijector + prior inside the native launch sequence) == torch bijector/prior around
+    gl_loglike_fwd_bwd, value and gradient w.r.t. z."""
+    wl = gl.workloads.make(name, **kw)
+    obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    pm = gl.ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time,
+                             error_map=None if err is None else err.cpu().numpy(), include_positions=False)
+    z0 = pm.bij.inverse(wl.prior.sample(wl.batch, seed=21)).to("cuda")
+    za, zb = z0.clone().requires_grad_(True), z0.clone().requires_grad_(True)
+    lpa, reda = pm.log_prob(sim, za)
+    lpb, redb = pm.log_prob_unfused(sim, zb)
+    lpa.sum().backward()
+    lpb.sum().backward()
+    assert torch.allclose(lpa, lpb, rtol=2e-6, atol=1e-3)
+    assert torch.allclose(reda, redb, rtol=2e-6)
+    scale = zb.grad.abs().max(dim=1, keepdim=True).values
+    assert ((za.grad - zb.grad).abs() <= 2e-4 * scale + 1e-4).all(), ((za.grad - zb.grad).abs() / scale).max()
+    lp_nograd, _ = pm.log_prob(sim, z0)  # forward-only entry
+    assert torch.allclose(lp_nograd, lpa.detach(), rtol=2e-6, atol=1e-3)
+
+
 def test_pix_region_and_constants(gl):
     """pix_region masks pixels out of the render and the likelihood (tf/simulator.py:34-44, tf/model.py:97-100);
     fixed parameters arrive through *_constants (model.py:29-44)."""

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Run only the native hot-path call (prep -> main -> finalize) for rocprofv3 counter collection.
+
+    rocprofv3 --kernel-trace --stats ... -- python3 tools/prof_kernel.py --workload C2 --iters 20
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU ... -- python3 tools/prof_kernel.py
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--num-pix", type=int, default=None)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--mode", default="grad", choices=["grad", "fwd", "img"])
+    ap.add_argument("--direct", action="store_true", help="C3: direct (non-table) shapelets")
+    args = ap.parse_args()
+    from gigalens_amd import workloads
+    from gigalens_amd.model import ForwardProbModel
+    from gigalens_amd.simulator import LensSimulator
+    kw = dict(num_pix=args.num_pix, batch=args.batch)
+    if args.workload.upper() == "C3":
+        kw["interpolate"] = not args.direct
+    wl = workloads.make(args.workload, **kw)
+    obs, err, _ = workloads.synthetic_observation(wl, LensSimulator)
+    sim = LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    packed = sim.pack(wl.prior.sample(wl.batch, seed=0)).contiguous()
+    m = sim._model
+    m.set_timing(True)
+    ts = []
+    for i in range(args.iters):
+        if args.mode == "img":
+            m.simulate_fwd(packed)
+        else:
+            m.loglike(packed, obs, err, None, wl.background_rms, wl.exp_time, args.mode == "grad")
+        ts.append(m.last_main_ms())
+    torch.cuda.synchronize()
+    ts = sorted(ts[2:]) if len(ts) > 4 else ts
+    print(f"{wl.name} B={wl.batch} N={m.N} P={m.P} mode={args.mode}: main kernel median {ts[len(ts)//2]:.4f} ms "
+          f"min {ts[0]:.4f} ms -> {wl.batch / (ts[len(ts)//2] * 1e-3):.0f} sims/s")
+
+
+if __name__ == "__main__":
+    main()
