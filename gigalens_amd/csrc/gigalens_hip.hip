@@ -15,6 +15,7 @@
 
 #include "gl_host_tables.h"
 #include "gl_kernels.hip.h"
+#include "gl_static.hip.h"
 
 using namespace glk;
 
@@ -48,7 +49,7 @@ int env_int(const char* name, int dflt) {
 struct gl_model {
   std::vector<CompDesc> comps;
   int n_lens = 0, n_ll = 0, n_src = 0;
-  int P = 0, D = 0, A = 0, Apad = 0;
+  int P = 0, D = 0, A = 0, Apad = 0, ncols = 64;
   bool has_shapelets = false, has_table = false;
   int height = 0, width = 0, supersample = 1, N = 0;
   float conversion_factor = 1.f;
@@ -66,11 +67,14 @@ struct gl_model {
   ZCol* d_zcols = nullptr;
   int* d_src = nullptr;
   float* d_const = nullptr;
+  int static_id = 0;   // 0 = generic interpreter kernel, >0 = compile-time-specialised composition
+  int static_variant = 0;
   bool has_epl = false;
   bool use_order = true;
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int tile = 4;          // pixels per thread per tile (template T)
+  int tile = 2;          // pixels per thread per tile (template T) for forward-only launches
+  int tile_grad = 2;     // ... and for launches that also produce gradients
   int target_wgs = 2048;  // work decomposition target (>= 8 workgroups per CU)
 };
 
@@ -79,7 +83,7 @@ namespace {
 // number of pixel chunks per sample: enough workgroups to fill 256 CUs several times over
 // (dynamic load balance: EPL trip counts differ per sample), but whole tiles per chunk.
 void chunking(const gl_model* m, int B, int* chunk, int* n_chunks) {
-  const long long tile_px = (long long)WG * m->tile;
+  const long long tile_px = (long long)WG * 4;  // whole tiles for every T in {1, 2, 4}
   long long want = std::max<long long>(1, (m->target_wgs + B - 1) / B);
   long long per = ((long long)m->N + want - 1) / want;
   per = std::max(tile_px, (per + tile_px - 1) / tile_px * tile_px);
@@ -123,16 +127,77 @@ Workspace carve(const gl_model* m, int B, void* base) {
   return w;
 }
 
+
+// ---- compile-time-specialised compositions (gl_static.hip.h) ------------------------------------------
+// SERSIC and SERSIC_ELLIPSE share one device code path (the spherical profile is the e = 0 member), so
+// signatures are matched after folding SERSIC_ELLIPSE -> SERSIC.
+using L_EplShear = KindList<K_EPL, K_SHEAR>;
+using L_Sie = KindList<K_SIE>;
+using L_SieShear = KindList<K_SIE, K_SHEAR>;
+using C_None = KindList<>;
+using C_Sersic = KindList<K_SERSIC>;
+using C_Shapelets = KindList<K_SHAPELETS>;
+
+enum StaticId { ST_NONE = 0, ST_EPLSHEAR_SERSIC, ST_EPLSHEAR_SERSIC_SERSIC, ST_SIE_SERSIC, ST_EPLSHEAR_SHAPELETS,
+                ST_SIESHEAR_SERSIC_SERSIC };
+
+int match_static(const gl_model* m) {
+  auto fold = [](int k) { return k == K_SERSIC_ELLIPSE ? (int)K_SERSIC : k; };
+  std::vector<int> L, C, S;
+  for (int i = 0; i < m->n_lens; ++i) L.push_back(m->comps[i].kind);
+  for (int i = 0; i < m->n_ll; ++i) C.push_back(fold(m->comps[m->n_lens + i].kind));
+  for (int i = 0; i < m->n_src; ++i) S.push_back(fold(m->comps[m->n_lens + m->n_ll + i].kind));
+  const std::vector<int> eplshear{K_EPL, K_SHEAR}, sie{K_SIE}, sieshear{K_SIE, K_SHEAR}, none{}, sersic{K_SERSIC},
+      shp{K_SHAPELETS};
+  if (L == eplshear && C == none && S == sersic) return ST_EPLSHEAR_SERSIC;
+  if (L == eplshear && C == sersic && S == sersic) return ST_EPLSHEAR_SERSIC_SERSIC;
+  if (L == sie && C == none && S == sersic) return ST_SIE_SERSIC;
+  if (L == eplshear && C == none && S == shp) return ST_EPLSHEAR_SHAPELETS;
+  if (L == sieshear && C == sersic && S == sersic) return ST_SIESHEAR_SERSIC_SERSIC;
+  return ST_NONE;
+}
+
+template <int MODE>
+bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
+  const int T = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
+#define GL_LAUNCH(TT, WW, LK, CK, SK) \
+  hipLaunchKernelGGL((gl_static_kernel<MODE, TT, WW, LK, CK, SK>), grid, block, shmem, stream, a)
+  switch (m->static_id) {
+    case ST_EPLSHEAR_SERSIC:
+      if (T == 4) { if (m->static_variant == 2) GL_LAUNCH(4, 2, L_EplShear, C_None, C_Sersic); else GL_LAUNCH(4, 3, L_EplShear, C_None, C_Sersic); }
+      else if (T == 1) GL_LAUNCH(1, 4, L_EplShear, C_None, C_Sersic);
+      else { if (m->static_variant == 3) GL_LAUNCH(2, 3, L_EplShear, C_None, C_Sersic); else GL_LAUNCH(2, 4, L_EplShear, C_None, C_Sersic); }
+      return true;
+    case ST_EPLSHEAR_SERSIC_SERSIC:
+      if (T == 4) GL_LAUNCH(4, 2, L_EplShear, C_Sersic, C_Sersic); else GL_LAUNCH(2, 4, L_EplShear, C_Sersic, C_Sersic);
+      return true;
+    case ST_SIE_SERSIC:
+      if (T == 4) GL_LAUNCH(4, 4, L_Sie, C_None, C_Sersic); else GL_LAUNCH(2, 4, L_Sie, C_None, C_Sersic);
+      return true;
+    case ST_SIESHEAR_SERSIC_SERSIC:
+      if (T == 4) GL_LAUNCH(4, 4, L_SieShear, C_Sersic, C_Sersic); else GL_LAUNCH(2, 4, L_SieShear, C_Sersic, C_Sersic);
+      return true;
+    case ST_EPLSHEAR_SHAPELETS:
+      if (T == 2) GL_LAUNCH(2, 2, L_EplShear, C_None, C_Shapelets); else if (T == 1) GL_LAUNCH(1, 2, L_EplShear, C_None, C_Shapelets);
+      else return false;
+      return true;
+  }
+#undef GL_LAUNCH
+  return false;
+}
+
 template <int MODE>
 int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream) {
   dim3 grid(n_chunks, B), block(WG);
-  size_t shmem = (size_t)(((m->D + 3) & ~3) + 4 * m->Apad) * sizeof(float);
+  size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
   if (m->timing) GL_HIP(hipEventRecord(m->ev0, stream));
-  if (m->has_shapelets) {
-    if (m->tile == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, true>), grid, block, shmem, stream, a);
+  if (m->static_id && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
+    // specialised kernel launched
+  } else if (const int Tg = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile; m->has_shapelets) {
+    if (Tg == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, true>), grid, block, shmem, stream, a);
     else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true>), grid, block, shmem, stream, a);
   } else {
-    if (m->tile == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, false>), grid, block, shmem, stream, a);
+    if (Tg == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, false>), grid, block, shmem, stream, a);
     else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, false>), grid, block, shmem, stream, a);
   }
   if (m->timing) GL_HIP(hipEventRecord(m->ev1, stream));
@@ -150,6 +215,7 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.D = m->D;
   a.A = m->A;
   a.Apad = m->Apad;
+  a.ncols = m->ncols;
   a.gx = m->d_gx;
   a.gy = m->d_gy;
   a.pix = m->d_pix;
@@ -285,16 +351,29 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   m->P = p_off;
   m->D = std::max(d_off, 4);
   m->A = a_off;
-  m->Apad = (a_off + 3) & ~3;
+  m->Apad = a_off | 1;  // odd: the 16 leader lanes of a wave land on 16 different LDS banks
+  m->ncols = ((size_t)(((m->D + 3) & ~3) + 64 * m->Apad) * sizeof(float) <= 60 * 1024) ? 64 : 16;
   m->height = grid->height;
   m->width = grid->width;
   m->supersample = grid->supersample;
   m->N = grid->n_region;
   m->conversion_factor = grid->conversion_factor;
-  m->tile = env_int("GIGALENS_HIP_TILE", 2) == 4 ? 4 : 2;
+  {
+    int t = env_int("GIGALENS_HIP_TILE", 0);
+    m->tile = (t == 4 || t == 1) ? t : 2;
+    int tg = env_int("GIGALENS_HIP_TILE_GRAD", t ? t : 0);
+    m->tile_grad = (tg == 4 || tg == 1 || tg == 2) ? tg : 0;
+  }
+  m->static_id = env_int("GIGALENS_HIP_STATIC", 1) ? match_static(m) : 0;
+  m->static_variant = env_int("GIGALENS_HIP_STATIC_VARIANT", 0);
+  if (!m->tile_grad) m->tile_grad = m->static_id ? 1 : 2;  // measured: T=1 wins once the VJP state lives in registers
+  if (!m->static_id) {  // the interpreter kernel is built for T = 2 and 4
+    if (m->tile == 1) m->tile = 2;
+    if (m->tile_grad == 1) m->tile_grad = 2;
+  }
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
-  size_t shmem = (size_t)(((m->D + 3) & ~3) + 4 * m->Apad) * sizeof(float);
+  size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
 
   auto up = [&](void** dst, const void* src, size_t bytes) -> bool {

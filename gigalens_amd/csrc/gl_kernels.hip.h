@@ -34,7 +34,7 @@ struct MainArgs {
   const CompDesc* comps;
   int n_lens, n_ll, n_src;
   const float* derived;  // [B][D]
-  int D, A, Apad;
+  int D, A, Apad, ncols;
   const float* gx;
   const float* gy;
   const int* pix;  // may be null
@@ -76,15 +76,55 @@ __device__ __forceinline__ float wave_sum63(float v) {
   v = dpp_add(v, 0x143, 0xC);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
   return v;
 }
-// n <= G live accumulators (n is wave-uniform): slots beyond n belong to other components / waves
-template <int G> __device__ __forceinline__ void wave_acc(float (&acc)[G], float* s_row, int lane, int n = G) {
-#pragma unroll
-  for (int k = 0; k < G; ++k)
-    if (k < n) acc[k] = wave_sum63(acc[k]);
-  if (lane == 63) {
+// ---- per-tile accumulation of parameter-gradient partials ------------------------------------------
+// A full wave64 reduction costs 12 VALU per value; doing it per (component, tile) dominated the
+// instruction count.  Instead each value is summed over a QUAD (2 DPP adds, or over a 16-lane row with
+// 4 when the model has too many accumulators for 64 LDS columns) and the quad/row leader adds it into
+// its own LDS column: s_acc[col][k].  Columns are private to one lane group of one wave, so the
+// read-modify-write needs no atomics and the result is order-deterministic.  The columns are summed
+// once per workgroup at the end.  Apad is odd, so the 16 leader lanes of a wave hit 16 different banks.
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm:[1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ float row_sum15(float v) {  // lane 15 of each 16-lane row holds the row sum
+  v = dpp_add(v, 0x111, 0xF);
+  v = dpp_add(v, 0x112, 0xF);
+  v = dpp_add(v, 0x114, 0xF);
+  v = dpp_add(v, 0x118, 0xF);
+  return v;
+}
+struct AccCol {
+  float* col;   // this lane group's LDS column
+  bool leader;  // lane that owns the column
+  bool quad;    // 64 columns (quad groups) or 16 columns (row groups)
+};
+__device__ __forceinline__ AccCol acc_col(float* s_acc, int Apad, int ncols, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  AccCol c;
+  c.quad = ncols == 64;
+  const int col = c.quad ? (wave * 16 + (lane >> 2)) : (wave * 4 + (lane >> 4));
+  c.leader = c.quad ? ((lane & 3) == 0) : ((lane & 15) == 15);
+  c.col = s_acc + col * Apad;
+  return c;
+}
+// n <= G live accumulators (n is wave-uniform)
+template <int G> __device__ __forceinline__ void wave_acc(float (&acc)[G], const AccCol& c, int off, int n = G) {
+  if (c.quad) {
 #pragma unroll
     for (int k = 0; k < G; ++k)
-      if (k < n) s_row[k] += acc[k];
+      if (k < n) acc[k] = quad_sum(acc[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+      if (k < n) acc[k] = row_sum15(acc[k]);
+  }
+  if (c.leader) {
+    float* dst = c.col + off;
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+      if (k < n) dst[k] += acc[k];
   }
 }
 
@@ -341,17 +381,17 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
   extern __shared__ float smem[];
   float* s_d = smem;
   float* s_acc = smem + ((a.D + 3) & ~3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
   const CompDesc* __restrict__ comps = a.comps;
   {
     const float* src = a.derived + (size_t)b * a.D;
     for (int i = tid; i < a.D; i += WG) s_d[i] = src[i];
     if (MODE != IMG_FWD)
-      for (int i = tid; i < 4 * a.Apad; i += WG) s_acc[i] = 0.f;
+      for (int i = tid; i < a.ncols * a.Apad; i += WG) s_acc[i] = 0.f;
   }
   __syncthreads();
-  float* s_row = s_acc + wave * a.Apad;
+  const AccCol ac = acc_col(s_acc, a.Apad, a.ncols, tid);
   const int n_lens = a.n_lens, n_light = a.n_ll + a.n_src, n_ll = a.n_ll;
   const int p0 = chunk * a.chunk;
   const int p1 = min(p0 + a.chunk, a.N);
@@ -466,7 +506,7 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
                                            src ? by[t] : y[t], gm[t], acc, dgx, dgy);
               if (src) { gbx[t] += dgx; gby[t] += dgy; }
             }
-            wave_acc<SHPA_AMP + SH_MAXL>(acc, s_row + cd.a_off, lane, cd.n_acc);
+            wave_acc<SHPA_AMP + SH_MAXL>(acc, ac, cd.a_off, cd.n_acc);
           }
         } else {
           float acc[SER_NACC];
@@ -478,7 +518,7 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
             sersic_vjp(d, src ? bx[t] : x[t], src ? by[t] : y[t], gm[t], acc, dgx, dgy);
             if (src) { gbx[t] += dgx; gby[t] += dgy; }
           }
-          wave_acc<SER_NACC>(acc, s_row + cd.a_off, lane);
+          wave_acc<SER_NACC>(acc, ac, cd.a_off);
         }
       }
       // ---- phase 4: lens VJPs with cotangent -g_beta (beta = x - sum alpha) ----
@@ -493,7 +533,7 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
 #pragma unroll
             for (int k = 0; k < EPL_NACC; ++k) acc[k] = 0.f;
             epl_vjp_T<T>(d, x, y, gbx, gby, acc);
-            wave_acc<EPL_NACC>(acc, s_row + cd.a_off, lane);
+            wave_acc<EPL_NACC>(acc, ac, cd.a_off);
           } break;
           case K_SIE: {
             float acc[SIE_NACC];
@@ -501,7 +541,7 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
             for (int k = 0; k < SIE_NACC; ++k) acc[k] = 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t) sie_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
-            wave_acc<SIE_NACC>(acc, s_row + cd.a_off, lane);
+            wave_acc<SIE_NACC>(acc, ac, cd.a_off);
           } break;
           case K_NFW: {
             float acc[NFW_NACC];
@@ -509,32 +549,35 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
             for (int k = 0; k < NFW_NACC; ++k) acc[k] = 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t) nfw_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
-            wave_acc<NFW_NACC>(acc, s_row + cd.a_off, lane);
+            wave_acc<NFW_NACC>(acc, ac, cd.a_off);
           } break;
           case K_SHEAR: {
             float acc[SHR_NACC];
             acc[0] = 0.f; acc[1] = 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t) shear_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
-            wave_acc<SHR_NACC>(acc, s_row + cd.a_off, lane);
+            wave_acc<SHR_NACC>(acc, ac, cd.a_off);
           } break;
           case K_SIS: {
             float acc[SIS_NACC];
             acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t) sis_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
-            wave_acc<SIS_NACC>(acc, s_row + cd.a_off, lane);
+            wave_acc<SIS_NACC>(acc, ac, cd.a_off);
           } break;
         }
       }
     }
   }
   if (MODE == IMG_FWD) return;
-  if (MODE == LL_FWD || MODE == LL_GRAD) wave_acc<2>(st, s_row, lane);
+  if (MODE == LL_FWD || MODE == LL_GRAD) wave_acc<2>(st, ac, 0);
   __syncthreads();
   float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
-  for (int k = tid; k < a.A; k += WG)
-    out[k] = (s_acc[k] + s_acc[a.Apad + k]) + (s_acc[2 * a.Apad + k] + s_acc[3 * a.Apad + k]);
+  for (int k = tid; k < a.A; k += WG) {
+    float v = 0.f;
+    for (int j = 0; j < a.ncols; ++j) v += s_acc[j * a.Apad + k];
+    out[k] = v;
+  }
 }
 
 // ---- finalize: sum chunk partials (fixed order), chain rule to raw parameters -------------------

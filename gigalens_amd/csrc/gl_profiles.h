@@ -72,7 +72,7 @@ GL_HD int kind_num_params(int kind, int iparam) {
 }
 GL_HD int kind_num_derived(int kind, int iparam) {
   switch (kind) {
-    case K_EPL: return EPL_TAB + 4 * (iparam + 1);
+    case K_EPL: return EPL_TAB + 4 * (iparam + 2);  // rows 0..cap plus one spare row for the loop's prefetch
     case K_SIE: return SIE_ND + 1;
     case K_NFW: return NFW_ND;
     case K_SHEAR: return SHR_ND + 2;
@@ -190,6 +190,7 @@ template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
     tab[4 * n + 3] = ct;
     K = n;
   }
+  for (int j = 0; j < 4; ++j) tab[4 * (K + 1) + j] = (R)0;  // the prefetched-but-unused row
   d[EPL_K] = (R)K;
 }
 
