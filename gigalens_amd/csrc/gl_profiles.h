@@ -34,7 +34,7 @@ constexpr int SH_NODES = 6000;                          // shapelets.py:39-40
 // layout of the derived-constant blocks and accumulator arrays
 // ---------------------------------------------------------------------------------------------
 // EPL
-enum { EPL_CX = 0, EPL_CY, EPL_C, EPL_S, EPL_Q, EPL_B, EPL_TM1, EPL_P0, EPL_K, EPL_INVB, EPL_TAB = 12 };
+enum { EPL_CX = 0, EPL_CY, EPL_C, EPL_S, EPL_Q, EPL_B, EPL_TM1, EPL_P0, EPL_K, EPL_INVB, EPL_KI /* K as int bits */, EPL_TAB = 12 };
 enum { EPLA_CX = 0, EPLA_CY, EPLA_PHI, EPLA_Q, EPLA_B, EPLA_T, EPLA_F, EPLA_P0, EPL_NACC };
 // SIE
 enum { SIE_CX = 0, SIE_CY, SIE_C, SIE_S, SIE_Q, SIE_SQ, SIE_A, SIE_ND };
@@ -192,6 +192,10 @@ template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
   }
   for (int j = 0; j < 4; ++j) tab[4 * (K + 1) + j] = (R)0;  // the prefetched-but-unused row
   d[EPL_K] = (R)K;
+  if (sizeof(R) == 4) {  // the same count as raw int bits, so a kernel can fetch it with a scalar load
+    int* ki = reinterpret_cast<int*>(&d[EPL_KI]);
+    *ki = K;
+  }
 }
 
 template <class R> GL_HD void epl_fwd(const R* d, R x, R y, R& ax, R& ay) {

@@ -42,10 +42,17 @@ template <int T> struct EplState {
 // `gtab` is the same coefficient table in GLOBAL memory (this sample's row of the derived buffer): its
 // address is wave-uniform, so the compiler reads it with scalar loads (s_load_dwordx4 -> SGPR operands) and
 // the series loop issues no LDS/vector-memory instruction at all.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int T, bool GRAD>
-__device__ __forceinline__ void epl_fwd_state(const float* d, const float4* __restrict__ gtab, const float (&x)[T],
+__device__ __forceinline__ void epl_fwd_state(const float* d, const float* __restrict__ gd, const float (&x)[T],
                                               const float (&y)[T], float (&bx)[T], float (&by)[T], EplState<T>& st) {
-  float E2x[T], E2y[T], Ex[T], Ey[T];
+  // Complex numbers are kept as (re, im) register pairs so that every instruction of the series loop is a
+  // packed fp32 op (v_pk_mul_f32 / v_pk_fma_f32: two lanes-worth of FMA per issue slot, which is what the
+  // 157 TFLOP/s vector peak of the chip assumes), with the coefficients as SGPR operands:
+  //   E <- E2 * E = E2x * (Ex, Ey) + (-E2y, E2y) * (Ey, Ex)          2 packed ops
+  //   O += c0 E ; S += c1 E ; F += c2 E ; Tt += c3 E                  4 packed ops (1 in forward-only mode)
+  v2f E[T], E2a[T], E2b[T], O[T], S[T], F[T], Tt[T];
   const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -60,35 +67,48 @@ __device__ __forceinline__ void epl_fwd_state(const float* d, const float4* __re
     st.Ss[t] = st.yr[t] * st.inv[t];
     st.inclamp[t] = (R0 >= 1e-10f) && (R0 <= 1e10f);
     st.iRc[t] = rcp(clamp_(R0, 1e-10f, 1e10f));
-    E2x[t] = st.Cs[t] * st.Cs[t] - st.Ss[t] * st.Ss[t];
-    E2y[t] = 2.f * st.Cs[t] * st.Ss[t];
-    Ex[t] = st.Cs[t]; Ey[t] = st.Ss[t];
-    st.Ox[t] = st.Cs[t]; st.Oy[t] = st.Ss[t];
-    if (GRAD) {
-      st.Sx[t] = st.Cs[t]; st.Sy[t] = st.Ss[t];
-      st.Fx[t] = 0.f; st.Fy[t] = 0.f; st.Tx[t] = 0.f; st.Ty[t] = 0.f;
-    }
+    float E2x = st.Cs[t] * st.Cs[t] - st.Ss[t] * st.Ss[t];
+    float E2y = 2.f * st.Cs[t] * st.Ss[t];
+    E2a[t] = v2f{E2x, E2x};
+    E2b[t] = v2f{-E2y, E2y};
+    E[t] = v2f{st.Cs[t], st.Ss[t]};
+    O[t] = E[t];
+    S[t] = E[t];
+    F[t] = v2f{0.f, 0.f};
+    Tt[t] = v2f{0.f, 0.f};
   }
-  const int K = (int)d[EPL_K];
-  float4 nxt = gtab[1];  // software pipeline: row n+1 is requested before row n is consumed
-  for (int n = 1; n <= K; ++n) {  // (the table is allocated with one spare row, so n+1 <= cap+1 is in bounds)
-    const float4 cc = nxt;
-    nxt = gtab[n + 1];
+  // trip count and coefficients come from GLOBAL memory at a wave-uniform address: scalar loads, scalar
+  // loop control, SGPR operands -- the loop issues no vector-memory or LDS instruction.
+  const int K = reinterpret_cast<const int*>(gd)[EPL_KI];
+  const float4* __restrict__ gtab = reinterpret_cast<const float4*>(gd + EPL_TAB);
+  auto step = [&](const float4 cc) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      float tx = E2x[t] * Ex[t] - E2y[t] * Ey[t];
-      Ey[t] = E2y[t] * Ex[t] + E2x[t] * Ey[t];
-      Ex[t] = tx;
-      st.Ox[t] += cc.x * Ex[t]; st.Oy[t] += cc.x * Ey[t];
+      v2f sw = __builtin_shufflevector(E[t], E[t], 1, 0);
+      E[t] = E2a[t] * E[t] + E2b[t] * sw;
+      O[t] += cc.x * E[t];
       if (GRAD) {
-        st.Sx[t] += cc.y * Ex[t]; st.Sy[t] += cc.y * Ey[t];
-        st.Fx[t] += cc.z * Ex[t]; st.Fy[t] += cc.z * Ey[t];
-        st.Tx[t] += cc.w * Ex[t]; st.Ty[t] += cc.w * Ey[t];
+        S[t] += cc.y * E[t];
+        F[t] += cc.z * E[t];
+        Tt[t] += cc.w * E[t];
       }
     }
+  };
+  int n = 1;
+  for (; n + 1 <= K; n += 2) {  // two terms per trip: one s_load_dwordx8, one wait
+    const float4 ca = gtab[n], cb = gtab[n + 1];
+    step(ca);
+    step(cb);
   }
+  if (n <= K) step(gtab[n]);
 #pragma unroll
   for (int t = 0; t < T; ++t) {
+    st.Ox[t] = O[t].x; st.Oy[t] = O[t].y;
+    if (GRAD) {
+      st.Sx[t] = S[t].x; st.Sy[t] = S[t].y;
+      st.Fx[t] = F[t].x; st.Fy[t] = F[t].y;
+      st.Tx[t] = Tt[t].x; st.Ty[t] = Tt[t].y;
+    }
     st.L2[t] = log2_(d[EPL_B] * st.iRc[t]);
     st.P[t] = d[EPL_P0] * exp2_(d[EPL_TM1] * st.L2[t]);
     float arx = st.P[t] * st.Ox[t], ary = st.P[t] * st.Oy[t];
@@ -240,7 +260,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_static_kernel(MainArgs a) {
       constexpr int kind = LK::kinds[i];
       const float* d = dL[i];
       if constexpr (kind == K_EPL) {
-        epl_fwd_state<T, GRAD>(d, reinterpret_cast<const float4*>(gder + comps[i].d_off + EPL_TAB), x, y, bx, by, est[i]);
+        epl_fwd_state<T, GRAD>(d, gder + comps[i].d_off, x, y, bx, by, est[i]);
       } else {
 #pragma unroll
         for (int t = 0; t < T; ++t) {

@@ -205,7 +205,7 @@ def test_log_prob_layout_and_prior(gl):
     lp, red = pm.log_prob(sim, z)
     ll = pm.log_like(sim, z.detach())
     lpr = pm.log_prior(z.detach())
-    assert torch.allclose(lp.detach(), ll + lpr, rtol=1e-6)
+    assert torch.allclose(lp.detach(), ll + lpr, rtol=LL_RTOL, atol=1e-3)
     ll_s, red_s = pm.stats_pixels(sim, x)
     # stats_pixels takes x itself, log_prob takes forward(inverse(x)): equal up to the fp32 bijector round trip
     assert torch.allclose(ll_s, ll, rtol=1e-4) and torch.allclose(red_s, red.detach(), rtol=1e-4)
