@@ -173,6 +173,13 @@ def main():
         bytes_b1 = 2 * 4 * N + 2 * 4 * P
         bytes_b2 = 4 * (2 * P + 2) + 4 * N * n_planes / B
         achieved = bytes_b1 * B / (main_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), profiles/<tag>_summary.json
+        try:
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
+            if prof and args.workload.upper() == "C2" and B == 1024:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1]))).get("traffic_bytes_per_launch")
+        except Exception:
+            traffic = None
         out = {
             "metric": "forward+grad lens sims/sec, 128x128 px batch 1024; achieved HBM GB/s vs peak",
             "value": round(sims, 1), "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,8 +192,8 @@ def main():
                                       if world > 1 else "single GPU",
                        "step": "ForwardProbModel.log_prob forward + gradient w.r.t. z"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "gl_main_kernel<LL_GRAD> (fused ray-shoot + render + chi2 + VJP)",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel": "gl_static_kernel<LL_GRAD> (fused ray-shoot + render + chi2 + VJP, EPL+Shear|Sersic specialisation)",
                          "kernel_ms": round(main_ms, 4), "native_call_ms": round(native_ms, 4),
                          "algorithmic_bytes_per_sim_B1": bytes_b1, "algorithmic_bytes_per_sim_B2": round(bytes_b2, 1),
                          "kernel_sims_per_s": round(B / (main_ms * 1e-3), 1),

@@ -1,0 +1,207 @@
+"""Callers of the hot path: the MAP -> SVI -> HMC modelling sequence (reference:
+src/gigalens/inference.py:10-139, src/gigalens/tf/inference.py:17-182, multi-device semantics from
+src/gigalens/jax/inference.py:32-208), as thin torch drivers around ``ForwardProbModel.log_prob``.
+
+These drivers are host orchestration, not kernels: each optimiser / leapfrog step costs one fused native
+forward+gradient call.  Data parallelism follows the JAX substrate: the sample batch is sharded over ranks
+(one process per GPU); MAP and HMC need no collective, SVI all-reduces ONE fused buffer
+``[ELBO, dELBO/dmu (d), dELBO/dL_packed (d(d+1)/2)]`` per step (``lax.pmean``, jax/inference.py:123-128).
+
+Differences from the TFP drivers, stated plainly: the HMC here is preconditioned HMC with dual-averaging
+step-size adaptation and a fixed number of leapfrog steps (TFP's gradient-based trajectory-length adaptation
+is not restated); SMC is not provided.
+"""
+import math
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from gigalens_amd import dist as gdist
+from gigalens_amd.simulator import LensSimulator
+
+
+class Adam:
+    """Plain Adam on one tensor (the reference passes a Keras / optax Adam; lr == 0 must be a no-op)."""
+
+    def __init__(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.m = self.v = None
+        self.t = 0
+
+    def step(self, x: torch.Tensor, grad: torch.Tensor):
+        if self.m is None:
+            self.m, self.v = torch.zeros_like(x), torch.zeros_like(x)
+        self.t += 1
+        lr = self.lr(self.t) if callable(self.lr) else self.lr
+        self.m.mul_(self.b1).add_(grad, alpha=1 - self.b1)
+        self.v.mul_(self.b2).addcmul_(grad, grad, value=1 - self.b2)
+        mhat = self.m / (1 - self.b1 ** self.t)
+        vhat = self.v / (1 - self.b2 ** self.t)
+        x.sub_(lr * mhat / (vhat.sqrt() + self.eps))
+        return x
+
+
+# ---- full-rank Gaussian surrogate ------------------------------------------------------------------
+def tril_unpack(packed: torch.Tensor, d: int, diag_shift: float = 1e-6) -> torch.Tensor:
+    """FillScaleTriL(diag_bijector=Exp, diag_shift=1e-6) (tf/inference.py:69-72).  Packing order here is
+    ``torch.tril_indices`` (row-major lower triangle); TFP's fill_triangular uses a different but equivalent
+    ordering -- only the coordinate labels of the variational parameters differ."""
+    idx = torch.tril_indices(d, d, device=packed.device)
+    L = torch.zeros((d, d), dtype=packed.dtype, device=packed.device)
+    L = L.index_put((idx[0], idx[1]), packed)
+    diag = torch.diagonal(L)
+    return L - torch.diag(diag) + torch.diag(torch.exp(diag) + diag_shift)
+
+
+def tril_pack(L: torch.Tensor, diag_shift: float = 1e-6) -> torch.Tensor:
+    d = L.shape[0]
+    idx = torch.tril_indices(d, d, device=L.device)
+    M = L.clone()
+    M[range(d), range(d)] = torch.log(torch.diagonal(L) - diag_shift)
+    return M[idx[0], idx[1]]
+
+
+def svi_step(mu: torch.Tensor, l_packed: torch.Tensor, log_prob_fn: Callable[[torch.Tensor], torch.Tensor],
+             n_local: int, generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """One ELBO evaluation on this rank's particle shard, all-reduced over ranks.
+
+    Returns ``(loss, grad_mu, grad_l_packed)`` identical on every rank: the mean over ranks of the per-rank
+    means (== the mean over all particles, shards being equal-sized)."""
+    d = mu.numel()
+    mu_ = mu.detach().clone().requires_grad_(True)
+    lp_ = l_packed.detach().clone().requires_grad_(True)
+    L = tril_unpack(lp_, d)
+    eps = torch.randn((n_local, d), generator=generator, dtype=mu.dtype,
+                      device=generator.device if generator is not None else mu.device).to(mu.device)
+    z = mu_ + eps @ L.T
+    # log q(z) of MultivariateNormalTriL: -1/2 |eps|^2 - sum log diag(L) - d/2 log 2pi
+    log_q = -0.5 * (eps * eps).sum(-1) - torch.log(torch.diagonal(L)).sum() - 0.5 * d * math.log(2 * math.pi)
+    elbo = (log_q - log_prob_fn(z)).mean()  # jax/inference.py:113-119
+    g_mu, g_lp = torch.autograd.grad(elbo, (mu_, lp_))
+    buf = torch.cat([elbo.detach().reshape(1), g_mu, g_lp])  # ONE fused buffer -> ONE collective
+    gdist.allreduce_mean_(buf)
+    return buf[0], buf[1:1 + d], buf[1 + d:]
+
+
+class ModellingSequence:
+    """Drop-in for ``gigalens.tf.inference.ModellingSequence`` (MAP / SVI / HMC)."""
+
+    def __init__(self, phys_model, prob_model, sim_config):
+        self.phys_model = phys_model
+        self.prob_model = prob_model
+        self.sim_config = sim_config
+
+    def _event_size(self, lens_sim):
+        return float(torch.count_nonzero(lens_sim.img_region))  # tf/inference.py:27-31 (pixel branch)
+
+    def MAP(self, optimizer: Adam, start=None, n_samples=500, num_steps=350, seed=0, progress=None):
+        """tf/inference.py:18-45.  ``n_samples`` is the GLOBAL count; each rank optimises its own shard and the
+        solutions are gathered at the end (jax/inference.py:62-68)."""
+        rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
+        lo, hi = gdist.shard_bounds(n_samples, rank, world)
+        n_local = hi - lo
+        pm = self.prob_model
+        if start is None:
+            start = pm.prior.sample(n_samples, seed=seed)
+        trial = pm.bij.inverse(start)[lo:hi].to(pm.device).contiguous().clone()
+        pm.init_centroids(bs=n_local)
+        lens_sim = LensSimulator(self.phys_model, self.sim_config, bs=n_local)
+        event_size = self._event_size(lens_sim)
+        red = None
+        for step in range(num_steps):
+            z = trial.detach().requires_grad_(True)
+            log_prob, red = pm.log_prob(lens_sim, z)
+            (g,) = torch.autograd.grad(log_prob.sum(), z)
+            # agg_loss = mean(-log_prob / event_size)  (tf/inference.py:36)
+            optimizer.step(trial, -g / (event_size * n_local))
+            if progress is not None:
+                progress(step, red)
+        self.last_red_chi2 = red
+        return gdist.gather_rows(trial)
+
+    def SVI(self, optimizer: Adam, start_mean, n_vi=250, init_scales=1e-3, num_steps=500, seed=2, progress=None):
+        """tf/inference.py:47-93 (full-rank), sharded like jax/inference.py:91-144."""
+        rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
+        n_local = max(1, n_vi // world)
+        pm = self.prob_model
+        lens_sim = LensSimulator(self.phys_model, self.sim_config, bs=n_local)
+        pm.init_centroids(bs=n_local)
+        mu = torch.as_tensor(start_mean, dtype=torch.float32, device=pm.device).reshape(-1).clone()
+        d = mu.numel()
+        scale = (torch.eye(d, device=pm.device) * float(init_scales) if not torch.is_tensor(init_scales)
+                 else init_scales.to(pm.device))
+        lp = tril_pack(scale)
+        gen = gdist.rank_generator(seed, rank, device="cpu")
+        params = torch.cat([mu, lp])
+        losses = []
+        for step in range(num_steps):
+            loss, g_mu, g_lp = svi_step(params[:d], params[d:], lambda z: pm.log_prob(lens_sim, z)[0], n_local, gen)
+            optimizer.step(params, torch.cat([g_mu, g_lp]))
+            losses.append(float(loss))
+            if progress is not None:
+                progress(step, loss)
+        self.q_mean, self.q_scale_tril = params[:d].clone(), tril_unpack(params[d:], d)
+        return (self.q_mean, self.q_scale_tril), losses
+
+    def HMC(self, q_z, init_eps=0.3, init_l=3, n_hmc=50, num_burnin_steps=250, num_results=750,
+            max_leapfrog_steps=30, adapt_rate=0.05, seed=3, target_accept=0.75):
+        """tf/inference.py:95-182: preconditioned HMC (momentum precision = SVI covariance) with dual-averaging
+        step-size adaptation during burn-in.  Chains are sharded over ranks with no collective
+        (jax/inference.py:157-208); samples are gathered along the chain axis at the end."""
+        rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
+        n_local = max(1, n_hmc // world)
+        pm = self.prob_model
+        lens_sim = LensSimulator(self.phys_model, self.sim_config, bs=n_local)
+        pm.init_centroids(bs=n_local)
+        mean, L = q_z
+        mean, L = mean.to(pm.device), L.to(pm.device)
+        d = mean.numel()
+        gen = gdist.rank_generator(seed, rank, device="cpu")
+        rnd = lambda *s: torch.randn(*s, generator=gen).to(pm.device)
+        z = mean + rnd(n_local, d) @ L.T
+        # momentum ~ N(0, Sigma^-1)  <=>  p = L^-T xi ; kinetic energy 1/2 p^T Sigma p = 1/2 |L^T p|^2
+        Linv_T = torch.linalg.inv(L).T
+
+        def value_and_grad(zz):
+            zz = zz.detach().requires_grad_(True)
+            lp, _ = pm.log_prob(lens_sim, zz)
+            (g,) = torch.autograd.grad(lp.sum(), zz)
+            return lp.detach(), g
+
+        lp, g = value_and_grad(z)
+        n_leap = int(min(max(init_l, 1), max_leapfrog_steps))
+        log_eps, log_eps_bar, h_bar, mu_da = math.log(init_eps), 0.0, 0.0, math.log(10 * init_eps)
+        samples, accept_hist = [], []
+        for it in range(num_burnin_steps + num_results):
+            eps = math.exp(log_eps)
+            p0 = rnd(n_local, d) @ Linv_T.T
+            zn, pn, gn, lpn = z, p0, g, lp
+            pn = pn + 0.5 * eps * gn
+            for i in range(n_leap):
+                zn = zn + eps * (pn @ (L @ L.T))
+                lpn, gn = value_and_grad(zn)
+                pn = pn + (eps if i < n_leap - 1 else 0.5 * eps) * gn
+            ke0 = 0.5 * ((p0 @ L) ** 2).sum(-1)
+            ke1 = 0.5 * ((pn @ L) ** 2).sum(-1)
+            log_acc = (lpn - ke1) - (lp - ke0)
+            log_acc = torch.where(torch.isfinite(log_acc), log_acc, torch.full_like(log_acc, -float("inf")))
+            acc = torch.log(torch.rand(n_local, generator=gen).to(pm.device)) < log_acc
+            z = torch.where(acc[:, None], zn, z)
+            g = torch.where(acc[:, None], gn, g)
+            lp = torch.where(acc, lpn, lp)
+            a = float(torch.exp(torch.clamp(log_acc, max=0.0)).mean())
+            accept_hist.append(a)
+            if it < num_burnin_steps:  # Nesterov dual averaging (Hoffman & Gelman 2014, alg. 5)
+                m = it + 1
+                h_bar = (1 - 1 / (m + 10)) * h_bar + (target_accept - a) / (m + 10)
+                log_eps = mu_da - math.sqrt(m) / adapt_rate * h_bar
+                eta = m ** -0.75
+                log_eps_bar = eta * log_eps + (1 - eta) * log_eps_bar
+                if it == num_burnin_steps - 1:
+                    log_eps = log_eps_bar
+            else:
+                samples.append(z.clone())
+        out = torch.stack(samples)  # (num_results, n_local, d)
+        if world > 1:
+            out = gdist.gather_rows(out.permute(1, 0, 2).contiguous()).permute(1, 0, 2)
+        return out, {"accept": accept_hist, "step_size": math.exp(log_eps), "num_leapfrog_steps": n_leap}

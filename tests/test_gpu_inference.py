@@ -1,0 +1,55 @@
+"""The reference's pipeline smoke tests (tests/tf/test_model.py:29-72: test_map, test_vi, test_hmc) against
+this repo's ModellingSequence, on the GPU: lr = 0 leaves parameters unchanged, lr > 0 moves them, HMC returns
+num_results samples; plus: MAP actually descends on a synthetic observation."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from gigalens_amd import workloads
+    from gigalens_amd.inference import ModellingSequence
+    from gigalens_amd.model import ForwardProbModel
+    from gigalens_amd.simulator import LensSimulator
+    wl = workloads.make("C2", num_pix=20, batch=2)
+    obs, _, truth = workloads.synthetic_observation(wl, LensSimulator)
+    pm = ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time, include_positions=False)
+    return wl, pm, ModellingSequence(wl.phys_model, pm, wl.sim_config)
+
+
+def test_map(setup):
+    from gigalens_amd.inference import Adam
+    from gigalens_amd.prior import nest_flatten
+    wl, pm, seq = setup
+    start = pm.prior.sample(2, seed=0)
+    ret = seq.MAP(Adam(0.0), start, n_samples=2, num_steps=5, seed=0)
+    end = pm.bij.forward(ret)
+    for a, b in zip(nest_flatten(start), nest_flatten(end)):
+        assert np.allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    ret = seq.MAP(Adam(1e-3), start, n_samples=2, num_steps=5, seed=0)
+    end = pm.bij.forward(ret)
+    assert not all(np.allclose(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(nest_flatten(start), nest_flatten(end)))
+
+
+def test_map_descends(setup):
+    from gigalens_amd.inference import Adam
+    wl, pm, seq = setup
+    hist = []
+    seq.MAP(Adam(5e-2), None, n_samples=64, num_steps=60, seed=1, progress=lambda s, red: hist.append(float(red.mean())))
+    assert hist[-1] < 0.5 * hist[0] and hist[-1] < 1.5  # mean reduced chi^2 falls to the noise floor (~1)
+
+
+def test_vi_and_hmc(setup):
+    from gigalens_amd.inference import Adam
+    wl, pm, seq = setup
+    start = pm.bij.inverse(pm.prior.sample(2, seed=0))[0]
+    (mean, L), losses = seq.SVI(Adam(0.0), start, n_vi=5, num_steps=5)
+    assert torch.allclose(mean.cpu(), start.cpu())
+    (mean, L), losses = seq.SVI(Adam(1e-3), start, n_vi=5, num_steps=5)
+    assert not torch.allclose(mean.cpu(), start.cpu()) and len(losses) == 5 and np.all(np.isfinite(losses))
+    samples, stats = seq.HMC((mean, L), n_hmc=3, init_eps=0.3, init_l=3, max_leapfrog_steps=5, num_burnin_steps=3,
+                             num_results=5)
+    assert len(samples) == 5 and samples.shape == (5, 3, 13) and torch.isfinite(samples).all()

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): collects the rocprofv3 evidence bench.py's numbers are checked against.
+#   bash tools/collect_profiles.sh r1
+# Counter passes are separate runs with --kernel-trace only (no sys/hip tracing), as the pool requires.
+set -u
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+for W in C2 C3 C4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_$W -- python3 $R/tools/prof_kernel.py --workload $W --iters 20 > $OUT/kernel_stats_$W.log 2>&1
+done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_mix -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_mix.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmc_clk -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_clk.log 2>&1
+python3 $R/bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
+tail -1 $OUT/bench.json

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/profiles_<tag>/ (rocprofv3 CSVs) into the tracked summaries under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"profiles_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name if len(name) < 110 else name[:107] + "..."
+
+
+def stats_table(d, out, top=12):
+    f = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv"))
+    if not f:
+        return None
+    rows = list(csv.DictReader(open(f[0])))
+    with open(os.path.join(dst, out), "w") as fh:
+        fh.write(f"# rocprofv3 --kernel-trace --stats ({d})\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
+        for r in rows[:top]:
+            fh.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | "
+                     f"{float(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |\n")
+    return rows
+
+
+def pmc(d, kernel_filter=("gl_static_kernel<3", "gl_main_kernel<3")):
+    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    if not f:
+        return {}
+    agg, dur = collections.defaultdict(list), []
+    for r in csv.DictReader(open(f[0])):
+        if any(k in r["Kernel_Name"] for k in kernel_filter):
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {k: sum(v[1:]) / max(len(v[1:]), 1) for k, v in agg.items()}
+    if dur:
+        out["_kernel_us"] = sum(dur[1:]) / max(len(dur[1:]), 1) / 1e3
+    return out
+
+
+summary = {}
+rows = stats_table("bench_stats", f"{tag}_bench_kernel_stats.md")
+for w in ("C2", "C3", "C4"):
+    stats_table(f"kernel_stats_{w}", f"{tag}_{w}_kernel_stats.md", top=6)
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mix", "pmc_clk"):
+    summary[d] = pmc(d)
+fetch_kb = summary.get("pmc_fetch", {}).get("FETCH_SIZE")
+write_kb = summary.get("pmc_write", {}).get("WRITE_SIZE")
+if fetch_kb is not None and write_kb is not None:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide
+    # coalesced reads -> double it; WRITE_SIZE is exact.
+    summary["traffic_bytes_per_launch"] = (2 * fetch_kb + write_kb) * 1024
+sq, clk = summary.get("pmc_sq", {}), summary.get("pmc_clk", {})
+if sq.get("SQ_INSTS_VALU") and clk.get("GRBM_GUI_ACTIVE"):
+    cycles = clk["GRBM_GUI_ACTIVE"] / 8.0                   # summed over the 8 XCDs
+    summary["kernel_cycles"] = cycles
+    summary["valu_busy_frac"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * cycles)   # quad-cycles -> cycles, 1024 SIMDs
+    summary["cycles_per_valu_inst"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / sq["SQ_INSTS_VALU"]
+    summary["eff_clock_ghz"] = cycles / (clk["_kernel_us"] * 1e3)
+bj = os.path.join(src, "bench.json")
+if os.path.exists(bj):
+    line = [l for l in open(bj) if l.startswith("{")]
+    if line:
+        summary["bench"] = json.loads(line[-1])
+json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k != "bench"}, indent=1))
