@@ -16,6 +16,7 @@
 #include "gl_host_tables.h"
 #include "gl_kernels.hip.h"
 #include "gl_static.hip.h"
+#include "gl_pair.hip.h"
 
 using namespace glk;
 
@@ -69,6 +70,7 @@ struct gl_model {
   float* d_const = nullptr;
   int static_id = 0;   // 0 = generic interpreter kernel, >0 = compile-time-specialised composition
   int static_variant = 0;
+  int pair = 1;        // pixel-pair (packed fp32) form of the specialised kernels
   bool has_epl = false;
   bool use_order = true;
   bool timing = false;
@@ -160,6 +162,24 @@ int match_static(const gl_model* m) {
 template <int MODE>
 bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
   const int T = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
+#define GL_PAIR(WW, LK, CK, SK) \
+  hipLaunchKernelGGL((gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>), grid, block, shmem, stream, a)
+  if (m->pair) {
+    // waves/SIMD the register budget is declared for: gradient modes keep the EPL / Sersic state of a pixel
+    // pair live between the forward and VJP halves (no spills at 3 resp. 2 waves per SIMD), forward modes fit 4+
+    constexpr bool G = (MODE == IMG_BWD || MODE == LL_GRAD);
+    constexpr int W1 = G ? 3 : 4, W2 = G ? 2 : 4;
+    switch (m->static_id) {
+      case ST_EPLSHEAR_SERSIC:
+        if (m->pair == 4) GL_PAIR(4, L_EplShear, C_None, C_Sersic); else GL_PAIR(W1, L_EplShear, C_None, C_Sersic);
+        return true;
+      case ST_EPLSHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_EplShear, C_Sersic, C_Sersic); return true;
+      case ST_SIE_SERSIC: GL_PAIR(4, L_Sie, C_None, C_Sersic); return true;
+      case ST_SIESHEAR_SERSIC_SERSIC: GL_PAIR(W1, L_SieShear, C_Sersic, C_Sersic); return true;
+      default: break;
+    }
+  }
+#undef GL_PAIR
 #define GL_LAUNCH(TT, WW, LK, CK, SK) \
   hipLaunchKernelGGL((gl_static_kernel<MODE, TT, WW, LK, CK, SK>), grid, block, shmem, stream, a)
   switch (m->static_id) {
@@ -366,6 +386,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   }
   m->static_id = env_int("GIGALENS_HIP_STATIC", 1) ? match_static(m) : 0;
   m->static_variant = env_int("GIGALENS_HIP_STATIC_VARIANT", 0);
+  m->pair = env_int("GIGALENS_HIP_PAIR", 1);
   if (!m->tile_grad) m->tile_grad = m->static_id ? 1 : 2;  // measured: T=1 wins once the VJP state lives in registers
   if (!m->static_id) {  // the interpreter kernel is built for T = 2 and 4
     if (m->tile == 1) m->tile = 2;

@@ -243,14 +243,15 @@ __global__ void __launch_bounds__(256) gl_order_kernel(const CompDesc* __restric
   auto cost = [&](int b) {
     int k = 0;
     for (int l = 0; l < n_lens; ++l)
-      if (comps[l].kind == K_EPL) k += (int)derived[(size_t)b * D + comps[l].d_off + EPL_K];
+      if (comps[l].kind == K_EPL) k += reinterpret_cast<const int*>(derived + (size_t)b * D + comps[l].d_off)[EPL_KI];
     return min(k, 255);
   };
   for (int b = threadIdx.x; b < B; b += 256) atomicAdd(&hist[cost(b)], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {
+  {  // exclusive prefix over DESCENDING cost: every thread sums the bins above its own (256 independent LDS reads)
     int run = 0;
-    for (int k = 255; k >= 0; --k) { offs[k] = run; run += hist[k]; }
+    for (int k = 255; k > (int)threadIdx.x; --k) run += hist[k];
+    offs[threadIdx.x] = run;
   }
   __syncthreads();
   for (int b = threadIdx.x; b < B; b += 256) order[atomicAdd(&offs[cost(b)], 1)] = b;

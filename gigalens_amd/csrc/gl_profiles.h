@@ -98,10 +98,19 @@ GL_HD int kind_num_acc(int kind, int iparam) {
 }
 
 // precise per-sample helpers (cost irrelevant: once per sample)
-template <class R> GL_HD R p_sqrt(R x) { return (R)::sqrt((double)x); }
-template <class R> GL_HD R p_atan2(R y, R x) { return (R)::atan2((double)y, (double)x); }
-template <class R> GL_HD R p_sin(R x) { return (R)::sin((double)x); }
-template <class R> GL_HD R p_cos(R x) { return (R)::cos((double)x); }
+GL_HD double p_sqrt(double x) { return ::sqrt(x); }
+GL_HD double p_atan2(double y, double x) { return ::atan2(y, x); }
+GL_HD double p_sin(double x) { return ::sin(x); }
+GL_HD double p_cos(double x) { return ::cos(x); }
+GL_HD double p_log(double x) { return ::log(x); }
+GL_HD double p_pow(double x, double y) { return ::pow(x, y); }
+// float: the precise (<= 1-2 ulp) single-precision library routines -- the reference is fp32 throughout
+GL_HD float p_sqrt(float x) { return ::sqrtf(x); }
+GL_HD float p_atan2(float y, float x) { return ::atan2f(y, x); }
+GL_HD float p_sin(float x) { return ::sinf(x); }
+GL_HD float p_cos(float x) { return ::cosf(x); }
+GL_HD float p_log(float x) { return ::logf(x); }
+GL_HD float p_pow(float x, float y) { return ::powf(x, y); }
 
 // (e1,e2) -> (phi, c, q) with c = min(|e|, cmax); EPL passes cmax = 1 (epl.py:22), every other
 // elliptical profile 0.9999 (sie.py:17, sersic.py:57).  Arithmetic in R like the reference's fp32.
@@ -170,7 +179,7 @@ template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
   d[EPL_INVB] = (R)1 / b;
   d[10] = (R)0;
   d[11] = (R)0;
-  R niter = (R)::log((double)(R)1e-12) / (R)::log((double)f) + (R)2;
+  R niter = p_log((R)1e-12) / p_log(f) + (R)2;
   int K = 0;
   R* tab = d + EPL_TAB;
   R c = (R)1, cf = (R)0, ct = (R)0;
@@ -324,7 +333,7 @@ template <class R> GL_HD void epl_point(const R* p, int cap, R x, R y, R& ax, R&
   R Rc = clamp_(R0, (R)1e-10, (R)1e10);
   R E2x = Cs * Cs - Ss * Ss, E2y = (R)2 * Cs * Ss;
   R lx = Cs, ly = Ss, Ox = Cs, Oy = Ss;
-  R niter = (R)::log((double)(R)1e-12) / (R)::log((double)f) + (R)2;
+  R niter = p_log((R)1e-12) / p_log(f) + (R)2;
   for (int n = 1; n <= cap; ++n) {
     if (!((R)n < niter)) break;
     R pn = -f * ((R)(2 * n) - ((R)2 - t)) / ((R)(2 * n) + ((R)2 - t));
@@ -334,7 +343,7 @@ template <class R> GL_HD void epl_point(const R* p, int cap, R x, R y, R& ax, R&
     Ox += lx;
     Oy += ly;
   }
-  R P = ((R)2 * b) / ((R)1 + q) * (R)::pow((double)(b / Rc), (double)(t - (R)1));
+  R P = ((R)2 * b) / ((R)1 + q) * p_pow(b / Rc, t - (R)1);
   R arx = P * Ox, ary = P * Oy;
   ax = arx * c - ary * s;
   ay = arx * s + ary * c;

@@ -247,7 +247,7 @@ def test_fused_log_prob_matches_unfused(gl, name, kw):
 @pytest.mark.parametrize("name,kw", [("C1", dict(num_pix=40, batch=9)), ("C2", dict(num_pix=50, batch=17)),
                                      ("C3", dict(num_pix=32, batch=5, interpolate=False)),
                                      ("C3", dict(num_pix=32, batch=5, interpolate=True, n_max=7)), ("DEMO", dict())])
-@pytest.mark.parametrize("tile", ["1", "2", "4"])
+@pytest.mark.parametrize("tile", ["1", "2", "4", "pair"])
 def test_specialised_kernels_match_interpreter(gl, name, kw, tile, monkeypatch):
     """The compile-time-specialised kernels (gl_static.hip.h) and the generic interpreter kernel evaluate the
     same maths: image, log-likelihood and gradient agree to rounding for every supported composition."""
@@ -266,7 +266,8 @@ def test_specialised_kernels_match_interpreter(gl, name, kw, tile, monkeypatch):
     res = {}
     for static in ("1", "0"):
         monkeypatch.setenv("GIGALENS_HIP_STATIC", static)
-        monkeypatch.setenv("GIGALENS_HIP_TILE", tile)
+        monkeypatch.setenv("GIGALENS_HIP_PAIR", "1" if tile == "pair" else "0")  # pixel-pair (packed fp32) kernels
+        monkeypatch.setenv("GIGALENS_HIP_TILE", "2" if tile == "pair" else tile)
         sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
         packed = H.sample_packed(wl, sim, seed=13)
         pm = gl.ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time,
