@@ -52,7 +52,7 @@ SYMBOLS = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gl_model_set_prior": (c_int, [c_void_p, POINTER(gl_zcolumn), c_int, POINTER(c_float)]),
     "gl_logprob_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     "gl_kind_num_params": (c_int, [POINTER(gl_component)]),
@@ -198,7 +198,7 @@ class Model:
             _check(lib().gl_model_set_prior(self._h, arr, len(columns), cr.ctypes.data_as(POINTER(c_float))))
         self.d_z = len(columns)
 
-    def logprob(self, z, obs, err, mask, bg_rms, exp_time, want_grad):
+    def logprob(self, z, obs, err, mask, bg_rms, exp_time, want_grad, chi2_divisor=1.0):
         _require_cuda(z, "z")
         if z.dtype != torch.float32 or z.dim() != 2 or z.shape[1] != self.d_z:
             raise NativeLibraryError(f"z must be float32 [B,{self.d_z}], got {z.dtype} {tuple(z.shape)}")
@@ -210,8 +210,8 @@ class Model:
         chi2 = torch.empty_like(lp)
         grad = torch.empty_like(z) if want_grad else None
         _check(lib().gl_logprob_fwd_bwd(self._h, _ptr(z), _ptr(obs), _ptr(err), _ptr(mask), float(bg_rms),
-                                        float(exp_time), B, _ptr(lp), _ptr(ll), _ptr(chi2), _ptr(grad), _ptr(ws),
-                                        ws.numel(), _stream()))
+                                        float(exp_time), B, _ptr(lp), _ptr(ll), _ptr(chi2), _ptr(grad),
+                                        float(chi2_divisor), _ptr(ws), ws.numel(), _stream()))
         return lp, ll, chi2, grad
 
     def set_timing(self, enabled=True):

@@ -270,11 +270,11 @@ int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, 
 
 int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, const Workspace& w, float* loglike,
                  float* chi2, float* grad, hipStream_t stream, const float* z = nullptr, float* logprob = nullptr,
-                 float* grad_z = nullptr) {
+                 float* grad_z = nullptr, float chi2_scale = 1.f) {
   size_t shmem = (size_t)(((m->A + 3) & ~3) + ((m->P + 3) & ~3) + ((m->d_z + 3) & ~3) + 4) * sizeof(float);
   hipLaunchKernelGGL(gl_finalize_kernel, dim3(B), dim3(128), shmem, stream, m->d_comps, (int)m->comps.size(), params,
                      m->P, w.partial, n_chunks, m->A, loglike, chi2, grad, z, m->d_z, z ? m->d_zcols : nullptr, logprob,
-                     grad_z);
+                     grad_z, chi2_scale);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -575,8 +575,10 @@ int gl_model_set_prior(gl_model* m, const gl_zcolumn* cols, int d, const float* 
 
 int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, const float* err_or_null,
                        const float* mask_or_null, float bg_rms, float exp_time, int B, float* logprob, float* loglike,
-                       float* chi2, float* grad_z_or_null, void* workspace, size_t workspace_bytes, void* hip_stream) {
+                       float* chi2, float* grad_z_or_null, float chi2_divisor, void* workspace, size_t workspace_bytes,
+                       void* hip_stream) {
   int rc = check_call(m, z, B, workspace, workspace_bytes);
+  if (!(chi2_divisor > 0.f)) return fail(GL_EINVAL, "chi2_divisor must be positive");
   if (rc) return rc;
   if (!m->d_zcols) return fail(GL_EINVAL, "gl_model_set_prior has not been called on this model");
   if (!obs || !logprob || !loglike || !chi2) return fail(GL_EINVAL, "obs / logprob / loglike / chi2 is null");
@@ -599,7 +601,8 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   if (grad_z_or_null) rc = launch_main<LL_GRAD>(m, a, B, n_chunks, stream);
   else rc = launch_main<LL_FWD>(m, a, B, n_chunks, stream);
   if (rc) return rc;
-  return run_finalize(m, w.params, B, n_chunks, w, loglike, chi2, nullptr, stream, z, logprob, grad_z_or_null);
+  return run_finalize(m, w.params, B, n_chunks, w, loglike, chi2, nullptr, stream, z, logprob, grad_z_or_null,
+                      1.0f / chi2_divisor);
 }
 
 int gl_profile_eval(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,

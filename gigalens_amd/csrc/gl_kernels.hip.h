@@ -590,7 +590,8 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
                                                           float* __restrict__ loglike, float* __restrict__ chi2,
                                                           float* __restrict__ grad, const float* __restrict__ z,
                                                           int d_z, const ZCol* __restrict__ zcols,
-                                                          float* __restrict__ logprob, float* __restrict__ grad_z) {
+                                                          float* __restrict__ logprob, float* __restrict__ grad_z,
+                                                          float chi2_scale) {
   extern __shared__ float s[];  // [A] accumulators, then [P] parameter gradients, then [d_z] prior terms
   float* s_g = s + ((A + 3) & ~3);
   float* s_t = s_g + ((P + 3) & ~3);
@@ -636,7 +637,7 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
   if (threadIdx.x == 0 && loglike) {
     float ll = -0.5f * (s[0] + s[1]);  // tf/model.py:99
     loglike[b] = ll;
-    chi2[b] = s[0];
+    chi2[b] = s[0] * chi2_scale;
     if (zcols && logprob) {
       float lp = 0.f;
       for (int k = 0; k < d_z; ++k) lp += s_t[k];

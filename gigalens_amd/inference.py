@@ -109,9 +109,7 @@ class ModellingSequence:
         event_size = self._event_size(lens_sim)
         red = None
         for step in range(num_steps):
-            z = trial.detach().requires_grad_(True)
-            log_prob, red = pm.log_prob(lens_sim, z)
-            (g,) = torch.autograd.grad(log_prob.sum(), z)
+            log_prob, red, g = pm.log_prob_and_grad(lens_sim, trial)
             # agg_loss = mean(-log_prob / event_size)  (tf/inference.py:36)
             optimizer.step(trial, -g / (event_size * n_local))
             if progress is not None:
@@ -163,10 +161,8 @@ class ModellingSequence:
         Linv_T = torch.linalg.inv(L).T
 
         def value_and_grad(zz):
-            zz = zz.detach().requires_grad_(True)
-            lp, _ = pm.log_prob(lens_sim, zz)
-            (g,) = torch.autograd.grad(lp.sum(), zz)
-            return lp.detach(), g
+            lp, _, g = pm.log_prob_and_grad(lens_sim, zz)
+            return lp, g
 
         lp, g = value_and_grad(z)
         n_leap = int(min(max(init_l, 1), max_leapfrog_steps))

@@ -119,9 +119,9 @@ class _LogProbFn(torch.autograd.Function):
     """autograd glue around gl_logprob_fwd_bwd (bijector + kernels + prior in one native launch sequence)."""
 
     @staticmethod
-    def forward(ctx, z, model, obs, err, mask, bg_rms, exp_time):
+    def forward(ctx, z, model, obs, err, mask, bg_rms, exp_time, n_eff):
         want = z.requires_grad
-        lp, ll, chi2, grad = model.logprob(z.detach(), obs, err, mask, bg_rms, exp_time, want)
+        lp, ll, chi2, grad = model.logprob(z.detach(), obs, err, mask, bg_rms, exp_time, want, n_eff)
         if want:
             ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(ll, chi2)
@@ -130,7 +130,7 @@ class _LogProbFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_lp, g_ll, g_chi2):
         (grad,) = ctx.saved_tensors
-        return g_lp[:, None] * grad, None, None, None, None, None, None
+        return g_lp[:, None] * grad, None, None, None, None, None, None, None
 
 
 class _PackBijector:
@@ -279,11 +279,28 @@ class ForwardProbModel(ProbabilisticModel):
         if self._fused_ok(simulator):
             # bijector -> prep -> fused render/chi2/VJP -> finalize + prior, all inside the native library
             model = self._bind_prior(simulator)
-            lp, _, chi2 = _LogProbFn.apply(z, model, self.observed_image, self.error_map,
-                                           simulator.img_region if simulator.sim_config.pix_region is not None else None,
-                                           self.background_rms or 0.0, self.exp_time or 1.0)
-            return lp, chi2 / self._n_eff(simulator)
+            lp, _, red_chi2 = _LogProbFn.apply(z, model, self.observed_image, self.error_map, self._mask(simulator),
+                                               self.background_rms or 0.0, self.exp_time or 1.0, self._n_eff(simulator))
+            return lp, red_chi2
         return self.log_prob_unfused(simulator, z)
+
+    def _mask(self, simulator):
+        return simulator.img_region if simulator.sim_config.pix_region is not None else None
+
+    def log_prob_and_grad(self, simulator, z):
+        """``(log_prob, red_chi2, d log_prob / d z)`` from ONE native launch sequence and no autograd graph --
+        what one MAP / HMC-leapfrog step of the reference computes with ``tf.GradientTape`` (tf/inference.py:33-39)."""
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        if self._fused_ok(simulator):
+            model = self._bind_prior(simulator)
+            lp, _, red, grad = model.logprob(z.detach(), self.observed_image, self.error_map, self._mask(simulator),
+                                             self.background_rms or 0.0, self.exp_time or 1.0, True,
+                                             self._n_eff(simulator))
+            return lp, red, grad
+        zz = z.detach().requires_grad_(True)
+        lp, red = self.log_prob_unfused(simulator, zz)
+        (g,) = torch.autograd.grad(lp.sum(), zz)
+        return lp.detach(), red.detach(), g
 
     def _n_eff(self, simulator):
         n = getattr(simulator, "_n_eff", None)

@@ -127,11 +127,12 @@ typedef struct gl_zcolumn {
 } gl_zcolumn;
 int gl_model_set_prior(gl_model* m, const gl_zcolumn* cols, int d, const float* const_row);
 
-/* z [B,d] -> logprob [B] = loglike + log prior(x) + log|dx/dz|, loglike [B], chi2 [B] and, when
- * grad_z_or_null != NULL, d logprob / d z [B,d] (what tf.GradientTape returns at tf/inference.py:33-39). */
+/* z [B,d] -> logprob [B] = loglike + log prior(x) + log|dx/dz|, loglike [B], red_chi2 [B] = chi^2 / chi2_divisor
+ * (the caller passes count_nonzero(img_region), tf/model.py:100) and, when grad_z_or_null != NULL,
+ * d logprob / d z [B,d] (what tf.GradientTape returns at tf/inference.py:33-39). */
 int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, const float* err_or_null,
                        const float* mask_or_null, float bg_rms, float exp_time, int B, float* logprob,
-                       float* loglike, float* chi2, float* grad_z_or_null, void* workspace,
+                       float* loglike, float* red_chi2, float* grad_z_or_null, float chi2_divisor, void* workspace,
                        size_t workspace_bytes, void* hip_stream);
 
 /* Plugin-level point evaluation, the reference's MassProfile.deriv / LightProfile.light called on

@@ -241,7 +241,9 @@ def test_fused_log_prob_matches_unfused(gl, name, kw):
     scale = zb.grad.abs().max(dim=1, keepdim=True).values
     assert ((za.grad - zb.grad).abs() <= 2e-4 * scale + 1e-4).all(), ((za.grad - zb.grad).abs() / scale).max()
     lp_nograd, _ = pm.log_prob(sim, z0)  # forward-only entry
-    assert torch.allclose(lp_nograd, lpa.detach(), rtol=2e-6, atol=1e-3)
+    assert torch.allclose(lp_nograd, lpa.detach(), rtol=LL_RTOL, atol=1e-3)
+    lp2, red2, g2 = pm.log_prob_and_grad(sim, z0)  # no autograd graph: bitwise the same numbers
+    assert torch.equal(lp2, lpa.detach()) and torch.equal(red2, reda.detach()) and torch.equal(g2, za.grad)
 
 
 @pytest.mark.parametrize("name,kw", [("C1", dict(num_pix=40, batch=9)), ("C2", dict(num_pix=50, batch=17)),
