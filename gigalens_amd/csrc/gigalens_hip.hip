@@ -17,6 +17,7 @@
 #include "gl_kernels.hip.h"
 #include "gl_static.hip.h"
 #include "gl_pair.hip.h"
+#include "gl_post.hip.h"
 
 using namespace glk;
 
@@ -61,8 +62,10 @@ struct gl_model {
   int* d_pix = nullptr;
   float* d_shp_tab = nullptr;
   int shp_stride = 0;
-  float* d_psf = nullptr;
+  float* d_psf = nullptr;  // effective kernel flip(psf) (*) box(ss)/ss^2, see gl_post.hip.h
   int psf_h = 0, psf_w = 0;
+  int KH = 1, KW = 1, pad_t = 0, pad_l = 0;
+  bool has_post = false;
   // unconstrained-space front end (gl_model_set_prior)
   int d_z = 0;
   ZCol* d_zcols = nullptr;
@@ -99,7 +102,8 @@ struct Workspace {
   float* params;  // [B,P] constrained rows produced from z (gl_logprob_fwd_bwd)
   int* order;     // [B] cost-ordered dispatch
   float* img_ss;   // supersampled / pre-PSF image or its cotangent (PSF path only)
-  float* img_tmp;  // second buffer for conv -> pool
+  float* img_tmp;  // final-resolution image / its cotangent (PSF path only)
+  float* stats;    // [B][2] chi2, normalisation of the materialised image (PSF path only)
   size_t bytes;
 };
 
@@ -117,13 +121,13 @@ Workspace carve(const gl_model* m, int B, void* base) {
   off += align_up((size_t)B * std::max(m->P, 1) * sizeof(float), 256);
   w.order = (int*)(p + off);
   off += align_up((size_t)B * sizeof(int), 256);
-  const bool post = m->d_psf || m->supersample != 1;
-  if (post) {
-    size_t img = align_up((size_t)B * m->height * m->width * sizeof(float), 256);
+  if (m->has_post) {
     w.img_ss = (float*)(p + off);
-    off += img;
-    w.img_tmp = (float*)(p + off);
-    off += img;
+    off += align_up((size_t)B * m->height * m->width * sizeof(float), 256);
+    w.img_tmp = (float*)(p + off);  // final-resolution image / its cotangent
+    off += align_up((size_t)B * (m->height / m->supersample) * (m->width / m->supersample) * sizeof(float), 256);
+    w.stats = (float*)(p + off);
+    off += align_up((size_t)B * 2 * sizeof(float), 256);
   }
   w.bytes = off;
   return w;
@@ -270,11 +274,12 @@ int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, 
 
 int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, const Workspace& w, float* loglike,
                  float* chi2, float* grad, hipStream_t stream, const float* z = nullptr, float* logprob = nullptr,
-                 float* grad_z = nullptr, float chi2_scale = 1.f) {
+                 float* grad_z = nullptr, float chi2_scale = 1.f, const float* extra_stats = nullptr,
+                 int use_partial = 1) {
   size_t shmem = (size_t)(((m->A + 3) & ~3) + ((m->P + 3) & ~3) + ((m->d_z + 3) & ~3) + 4) * sizeof(float);
   hipLaunchKernelGGL(gl_finalize_kernel, dim3(B), dim3(128), shmem, stream, m->d_comps, (int)m->comps.size(), params,
                      m->P, w.partial, n_chunks, m->A, loglike, chi2, grad, z, m->d_z, z ? m->d_zcols : nullptr, logprob,
-                     grad_z, chi2_scale);
+                     grad_z, chi2_scale, extra_stats, use_partial);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -288,6 +293,76 @@ int run_order(const gl_model* m, int B, const Workspace& w, MainArgs* a, hipStre
   GL_HIP(hipGetLastError());
   a->order = w.order;
   return GL_OK;
+}
+
+
+// ---- PSF / supersampling path (gl_post.hip.h) -------------------------------------------------------------
+PostArgs post_args(const gl_model* m, float scale) {
+  PostArgs p{};
+  p.keff = m->d_psf;
+  p.KH = m->KH; p.KW = m->KW; p.pt = m->pad_t; p.pl = m->pad_l;
+  p.Hs = m->height; p.Ws = m->width; p.ss = m->supersample;
+  p.H = m->height / m->supersample; p.W = m->width / m->supersample;
+  p.scale = scale;
+  return p;
+}
+// supersampled pre-PSF image S [B,Hs,Ws] -> final image [B,H,W] (x conversion factor)
+int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t stream) {
+  PostArgs p = post_args(m, m->conversion_factor);
+  const int TR = (PT - 1) * p.ss + p.KH, TC = ((PT - 1) * p.ss + p.KW) | 1;
+  size_t shmem = (size_t)TR * TC * sizeof(float);
+  if (shmem > 64 * 1024) return fail(GL_EUNSUPPORTED, "PSF too large for the LDS-tiled convolution (%zu B)", shmem);
+  dim3 grid((p.W + PT - 1) / PT, (p.H + PT - 1) / PT, B);
+  hipLaunchKernelGGL(gl_psf_pool_fwd_kernel, grid, dim3(256), shmem, stream, S, out, p);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+// cotangent of the final image [B,H,W] -> cotangent of S [B,Hs,Ws]
+int post_bwd(const gl_model* m, int B, const float* gP, float* gS, hipStream_t stream) {
+  PostArgs p = post_args(m, m->conversion_factor);
+  const int TR = (PT - 1 + p.KH) / p.ss + 3, TC = ((PT - 1 + p.KW) / p.ss + 3) | 1;
+  size_t shmem = (size_t)TR * TC * sizeof(float);
+  dim3 grid((p.Ws + PT - 1) / PT, (p.Hs + PT - 1) / PT, B);
+  hipLaunchKernelGGL(gl_psf_pool_bwd_kernel, grid, dim3(256), shmem, stream, gP, gS, p);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+int render_ss(const gl_model* m, MainArgs a, int B, int n_chunks, const Workspace& w, hipStream_t stream) {
+  if (m->d_pix) GL_HIP(hipMemsetAsync(w.img_ss, 0, sizeof(float) * (size_t)B * m->height * m->width, stream));
+  a.img = w.img_ss;
+  a.out_scale = 1.f;  // NaN -> 0 happens in the kernel; the det(T) scale is applied after pooling (tf/simulator.py:156)
+  return launch_main<IMG_FWD>(m, a, B, n_chunks, stream);
+}
+
+// likelihood after prep: fused kernel when the image never has to exist, else render -> PSF/pool -> pixel
+// statistics (-> transposes -> VJP).  Tells finalize where chi2 / normalisation come from.
+int run_likelihood(const gl_model* m, int B, const Workspace& w, int chunk, int n_chunks, const float* obs,
+                   const float* err, const float* mask, float bg_rms, float exp_time, bool want_grad,
+                   hipStream_t stream, const float** extra_stats, int* use_partial) {
+  int rc;
+  MainArgs a = base_args(m, w, chunk);
+  a.obs = obs;
+  a.err = err;
+  a.mask = mask;
+  a.bg2 = bg_rms * bg_rms;
+  a.inv_t = 1.0f / exp_time;
+  if ((rc = run_order(m, B, w, &a, stream))) return rc;
+  *extra_stats = nullptr;
+  *use_partial = 1;
+  if (!m->has_post) return want_grad ? launch_main<LL_GRAD>(m, a, B, n_chunks, stream) : launch_main<LL_FWD>(m, a, B, n_chunks, stream);
+  if ((rc = render_ss(m, a, B, n_chunks, w, stream))) return rc;
+  if ((rc = post_fwd(m, B, w.img_ss, w.img_tmp, stream))) return rc;
+  const int HW = (m->height / m->supersample) * (m->width / m->supersample);
+  hipLaunchKernelGGL(gl_imgstats_kernel, dim3(B), dim3(256), 0, stream, w.img_tmp, obs, err, mask, a.bg2, a.inv_t, HW,
+                     w.stats, want_grad ? w.img_tmp : nullptr);
+  GL_HIP(hipGetLastError());
+  *extra_stats = w.stats;
+  *use_partial = want_grad ? 1 : 0;
+  if (!want_grad) return GL_OK;
+  if ((rc = post_bwd(m, B, w.img_tmp, w.img_ss, stream))) return rc;
+  a.gimg = w.img_ss;
+  a.out_scale = 1.f;
+  return launch_main<IMG_BWD>(m, a, B, n_chunks, stream);
 }
 
 }  // namespace
@@ -419,10 +494,25 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     glh::build_shapelet_table(sh_nmax, tab, &m->shp_stride);
     ok = ok && up((void**)&m->d_shp_tab, tab.data(), tab.size() * sizeof(float));
   }
-  if (grid->psf) {
-    m->psf_h = grid->psf_h;
-    m->psf_w = grid->psf_w;
-    ok = ok && up((void**)&m->d_psf, grid->psf, sizeof(float) * grid->psf_h * grid->psf_w);
+  m->has_post = grid->psf != nullptr || grid->supersample != 1;
+  if (m->has_post) {
+    // flat = flip(psf) cross-correlated with SAME padding (tf/simulator.py:62-70,145-147), then box(ss)/ss^2 pooling
+    const int kh = grid->psf ? grid->psf_h : 1, kw = grid->psf ? grid->psf_w : 1, ss = grid->supersample;
+    m->psf_h = kh;
+    m->psf_w = kw;
+    m->KH = kh + ss - 1;
+    m->KW = kw + ss - 1;
+    m->pad_t = (kh - 1) / 2;
+    m->pad_l = (kw - 1) / 2;
+    std::vector<double> keff((size_t)m->KH * m->KW, 0.0);
+    for (int u = 0; u < kh; ++u)
+      for (int v = 0; v < kw; ++v) {
+        double f = grid->psf ? (double)grid->psf[(size_t)(kh - 1 - u) * kw + (kw - 1 - v)] : 1.0;
+        for (int a2 = 0; a2 < ss; ++a2)
+          for (int c2 = 0; c2 < ss; ++c2) keff[(size_t)(u + a2) * m->KW + (v + c2)] += f / (double)(ss * ss);
+      }
+    std::vector<float> kf(keff.begin(), keff.end());
+    ok = ok && up((void**)&m->d_psf, kf.data(), sizeof(float) * kf.size());
   }
   if (!ok) {
     gl_model_destroy(m);
@@ -484,16 +574,19 @@ int gl_simulate_fwd(const gl_model* m, const float* params, int B, float* img, v
   int rc = check_call(m, params, B, workspace, workspace_bytes);
   if (rc) return rc;
   if (!img) return fail(GL_EINVAL, "img is null");
-  if (m->d_psf || m->supersample != 1) return fail(GL_EUNSUPPORTED, "PSF / supersampling path not built yet");
   hipStream_t stream = (hipStream_t)hip_stream;
   Workspace w = carve(m, B, workspace);
   int chunk, n_chunks;
   chunking(m, B, &chunk, &n_chunks);
   if ((rc = run_prep(m, params, B, w, stream))) return rc;
-  if (m->d_pix) GL_HIP(hipMemsetAsync(img, 0, sizeof(float) * (size_t)B * m->height * m->width, stream));
   MainArgs a = base_args(m, w, chunk);
-  a.img = img;
   if ((rc = run_order(m, B, w, &a, stream))) return rc;
+  if (m->has_post) {
+    if ((rc = render_ss(m, a, B, n_chunks, w, stream))) return rc;
+    return post_fwd(m, B, w.img_ss, img, stream);
+  }
+  if (m->d_pix) GL_HIP(hipMemsetAsync(img, 0, sizeof(float) * (size_t)B * m->height * m->width, stream));
+  a.img = img;
   return launch_main<IMG_FWD>(m, a, B, n_chunks, stream);
 }
 
@@ -502,7 +595,6 @@ int gl_simulate_bwd(const gl_model* m, const float* params, const float* grad_im
   int rc = check_call(m, params, B, workspace, workspace_bytes);
   if (rc) return rc;
   if (!grad_img || !grad_params) return fail(GL_EINVAL, "grad_img / grad_params is null");
-  if (m->d_psf || m->supersample != 1) return fail(GL_EUNSUPPORTED, "PSF / supersampling path not built yet");
   hipStream_t stream = (hipStream_t)hip_stream;
   Workspace w = carve(m, B, workspace);
   int chunk, n_chunks;
@@ -510,6 +602,11 @@ int gl_simulate_bwd(const gl_model* m, const float* params, const float* grad_im
   if ((rc = run_prep(m, params, B, w, stream))) return rc;
   MainArgs a = base_args(m, w, chunk);
   a.gimg = grad_img;
+  if (m->has_post) {
+    if ((rc = post_bwd(m, B, grad_img, w.img_ss, stream))) return rc;
+    a.gimg = w.img_ss;
+    a.out_scale = 1.f;
+  }
   if ((rc = run_order(m, B, w, &a, stream))) return rc;
   if ((rc = launch_main<IMG_BWD>(m, a, B, n_chunks, stream))) return rc;
   return run_finalize(m, params, B, n_chunks, w, nullptr, nullptr, grad_params, stream);
@@ -521,23 +618,18 @@ int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs,
   int rc = check_call(m, params, B, workspace, workspace_bytes);
   if (rc) return rc;
   if (!obs || !loglike || !chi2) return fail(GL_EINVAL, "obs / loglike / chi2 is null");
-  if (m->d_psf || m->supersample != 1) return fail(GL_EUNSUPPORTED, "PSF / supersampling path not built yet");
   hipStream_t stream = (hipStream_t)hip_stream;
   Workspace w = carve(m, B, workspace);
   int chunk, n_chunks;
   chunking(m, B, &chunk, &n_chunks);
   if ((rc = run_prep(m, params, B, w, stream))) return rc;
-  MainArgs a = base_args(m, w, chunk);
-  a.obs = obs;
-  a.err = err_or_null;
-  a.mask = mask_or_null;
-  a.bg2 = bg_rms * bg_rms;
-  a.inv_t = 1.0f / exp_time;
-  if ((rc = run_order(m, B, w, &a, stream))) return rc;
-  if (grad_params_or_null) rc = launch_main<LL_GRAD>(m, a, B, n_chunks, stream);
-  else rc = launch_main<LL_FWD>(m, a, B, n_chunks, stream);
-  if (rc) return rc;
-  return run_finalize(m, params, B, n_chunks, w, loglike, chi2, grad_params_or_null, stream);
+  const float* extra = nullptr;
+  int use_partial = 1;
+  if ((rc = run_likelihood(m, B, w, chunk, n_chunks, obs, err_or_null, mask_or_null, bg_rms, exp_time,
+                           grad_params_or_null != nullptr, stream, &extra, &use_partial)))
+    return rc;
+  return run_finalize(m, params, B, n_chunks, w, loglike, chi2, grad_params_or_null, stream, nullptr, nullptr, nullptr,
+                      1.f, extra, use_partial);
 }
 
 int gl_model_set_prior(gl_model* m, const gl_zcolumn* cols, int d, const float* const_row) {
@@ -582,7 +674,6 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   if (rc) return rc;
   if (!m->d_zcols) return fail(GL_EINVAL, "gl_model_set_prior has not been called on this model");
   if (!obs || !logprob || !loglike || !chi2) return fail(GL_EINVAL, "obs / logprob / loglike / chi2 is null");
-  if (m->d_psf || m->supersample != 1) return fail(GL_EUNSUPPORTED, "PSF / supersampling path not built yet");
   hipStream_t stream = (hipStream_t)hip_stream;
   Workspace w = carve(m, B, workspace);
   int chunk, n_chunks;
@@ -591,18 +682,13 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   hipLaunchKernelGGL(gl_zprep_kernel, dim3((B * n_comp + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, z,
                      m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D);
   GL_HIP(hipGetLastError());
-  MainArgs a = base_args(m, w, chunk);
-  a.obs = obs;
-  a.err = err_or_null;
-  a.mask = mask_or_null;
-  a.bg2 = bg_rms * bg_rms;
-  a.inv_t = 1.0f / exp_time;
-  if ((rc = run_order(m, B, w, &a, stream))) return rc;
-  if (grad_z_or_null) rc = launch_main<LL_GRAD>(m, a, B, n_chunks, stream);
-  else rc = launch_main<LL_FWD>(m, a, B, n_chunks, stream);
-  if (rc) return rc;
+  const float* extra = nullptr;
+  int use_partial = 1;
+  if ((rc = run_likelihood(m, B, w, chunk, n_chunks, obs, err_or_null, mask_or_null, bg_rms, exp_time,
+                           grad_z_or_null != nullptr, stream, &extra, &use_partial)))
+    return rc;
   return run_finalize(m, w.params, B, n_chunks, w, loglike, chi2, nullptr, stream, z, logprob, grad_z_or_null,
-                      1.0f / chi2_divisor);
+                      1.0f / chi2_divisor, extra, use_partial);
 }
 
 int gl_profile_eval(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,

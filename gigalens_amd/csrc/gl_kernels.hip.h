@@ -591,7 +591,8 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
                                                           float* __restrict__ grad, const float* __restrict__ z,
                                                           int d_z, const ZCol* __restrict__ zcols,
                                                           float* __restrict__ logprob, float* __restrict__ grad_z,
-                                                          float chi2_scale) {
+                                                          float chi2_scale, const float* __restrict__ extra_stats,
+                                                          int use_partial) {
   extern __shared__ float s[];  // [A] accumulators, then [P] parameter gradients, then [d_z] prior terms
   float* s_g = s + ((A + 3) & ~3);
   float* s_t = s_g + ((P + 3) & ~3);
@@ -599,7 +600,9 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
   const float* src = partial + (size_t)b * n_chunks * A;
   for (int k = threadIdx.x; k < A; k += 128) {
     float v = 0.f;
-    for (int ch = 0; ch < n_chunks; ++ch) v += src[(size_t)ch * A + k];
+    if (use_partial)
+      for (int ch = 0; ch < n_chunks; ++ch) v += src[(size_t)ch * A + k];
+    if (extra_stats && k < 2) v += extra_stats[2 * b + k];  // chi2 / normalisation of a materialised image (PSF path)
     s[k] = v;
   }
   __syncthreads();

@@ -252,8 +252,7 @@ class ForwardProbModel(ProbabilisticModel):
         return model
 
     def _fused_ok(self, simulator):
-        return (self.include_pixels and not self.include_positions and simulator.supersample == 1
-                and simulator.kernel is None)
+        return self.include_pixels and not self.include_positions
 
     def _packed_from_x(self, simulator, x):
         cols, consts = self._perm(simulator)
@@ -262,8 +261,6 @@ class ForwardProbModel(ProbabilisticModel):
         return x.index_select(1, cols)
 
     def _pixel_stats_packed(self, simulator, packed):
-        if simulator.supersample != 1 or simulator.kernel is not None:
-            raise NotImplementedError("pixel likelihood with PSF / supersampling is not built yet")
         ll, chi2 = _LogLikeFn.apply(packed, simulator._model, self.observed_image, self.error_map,
                                     simulator.img_region if simulator.sim_config.pix_region is not None else None,
                                     self.background_rms or 0.0, self.exp_time or 1.0)

@@ -98,7 +98,10 @@ class LensSimulator(LensSimulatorInterface):
     ``region``, ``bs``, ``wcs``, ``supersample``, ``conversion_factor``.
     """
 
-    def __init__(self, phys_model, sim_config: SimulatorConfig, bs: int):
+    def __init__(self, phys_model, sim_config: SimulatorConfig, bs: int, supersampled_kernel=None):
+        """``supersampled_kernel``: PSF already sampled on the supersampled grid.  The reference derives it from
+        ``sim_config.kernel`` with lenstronomy's ``subgrid_kernel`` (tf/simulator.py:62-65), a third-party routine
+        that is not restated here: with ``supersample > 1`` pass the supersampled PSF explicitly."""
         super().__init__(phys_model, sim_config, bs)
         self.device = _native.device()
         self.supersample = int(sim_config.supersample)
@@ -125,12 +128,14 @@ class LensSimulator(LensSimulatorInterface):
         self.numPix = sim_config.num_pix
         self.depth = len(phys_model.lens_light) + len(phys_model.source_light)
         psf = None
-        if sim_config.kernel is not None:
-            psf = np.asarray(sim_config.kernel, dtype=np.float32)
+        if supersampled_kernel is not None:
+            psf = np.asarray(supersampled_kernel, dtype=np.float32)
+        elif sim_config.kernel is not None:
             if ss != 1:
                 raise NotImplementedError(
                     "supersample > 1 with a PSF needs lenstronomy's subgrid_kernel (third party, not restated); "
-                    "pass a kernel already sampled on the supersampled grid via LensSimulator.from_supersampled_kernel")
+                    "pass LensSimulator(..., supersampled_kernel=<PSF sampled on the supersampled grid>)")
+            psf = np.asarray(sim_config.kernel, dtype=np.float32)
         self.kernel = psf
         comps = ([_native.component_of(p) for p in phys_model.lenses]
                  + [_native.component_of(p) for p in phys_model.lens_light]

@@ -404,3 +404,67 @@ def test_full_size_properties(gl, name, kw):
         delta2 = (sim.simulate(other) - sim.simulate(packed))
         assert torch.allclose(2 * delta, delta2, rtol=1e-4, atol=1e-5 * float(delta2.abs().max()))
     assert torch.isfinite(p.grad).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# PSF convolution + supersampling (tf/simulator.py:60-70,142-156) -- the image-materialising path
+# ---------------------------------------------------------------------------------------------------
+def _gauss_psf(n, sigma, seed=0):
+    r = np.random.default_rng(seed)
+    ax = np.arange(n) - (n - 1) / 2
+    k = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / (2 * sigma ** 2)) * (1 + 0.1 * r.uniform(size=(n, n)))  # asymmetric
+    return (k / k.sum()).astype(np.float32)
+
+
+@pytest.mark.parametrize("ss,ksize", [(1, 7), (2, 0), (2, 9), (3, 5), (2, 8)])
+def test_psf_supersample_vs_oracle(gl, ss, ksize):
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import SersicEllipse
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.simulator import SimulatorConfig
+    from oracle import ref_torch as ref
+    from tests.test_prior_host import default_prior
+    n, B = 22, 3
+    phys = PhysicalModel([EPL(), Shear()], [SersicEllipse()], [SersicEllipse()])
+    prior = default_prior()
+    psf = _gauss_psf(ksize, 1.2 * ss) if ksize else None
+    cfg = SimulatorConfig(delta_pix=0.08, num_pix=n, supersample=ss)
+    sim = gl.LensSimulator(phys, cfg, bs=B, supersampled_kernel=psf)
+    wl = gl.workloads.Workload("PSF", phys, prior, cfg, B)
+    packed = H.sample_packed(wl, sim, seed=4)
+    rs = ref.RefSimulator(phys, cfg, B, dtype=torch.float64, supersampled_kernel=psf)
+    p64 = packed.cpu().double().requires_grad_(True)
+    img_o = rs.simulate(H.struct_from_packed(phys, p64))
+    r = np.random.default_rng(1)
+    obs = (img_o[0].detach().numpy() + 0.3 * r.normal(size=(n, n))).astype(np.float32)
+    ll_o, red_o = ref.stats_pixels(rs, H.struct_from_packed(phys, p64), obs, 0.2, 100.0)
+    (g_o,) = torch.autograd.grad(ll_o.sum(), p64)
+    img = sim.simulate(packed)
+    assert img.shape == (B, n, n)
+    assert np.abs(img.cpu().numpy() - img_o.detach().numpy()).max() <= IMG_RTOL * float(img_o.abs().max())
+    pm = gl.ForwardProbModel(prior, obs, 0.2, 100.0, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, red = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    assert np.allclose(ll.detach().cpu().numpy(), ll_o.detach().numpy(), rtol=LL_RTOL)
+    assert np.allclose(red.detach().cpu().numpy(), red_o.detach().numpy(), rtol=LL_RTOL)
+    g, go = p.grad.cpu().numpy(), g_o.numpy()
+    scale = np.abs(go).max(axis=1, keepdims=True)
+    assert np.all(np.abs(g - go) <= GRAD_RTOL * scale + 1e-6), (np.abs(g - go) / scale).max()
+    # image-boundary pair through autograd (gl_simulate_bwd with the transposed PSF / pooling)
+    p2 = packed.clone().requires_grad_(True)
+    w = torch.as_tensor(r.normal(size=(B, n, n)).astype(np.float32), device=p2.device)
+    (sim.simulate(p2) * w).sum().backward()
+    (g2_o,) = torch.autograd.grad((rs.simulate(H.struct_from_packed(phys, p64)) * w.cpu().double()).sum(), p64)
+    sc2 = np.abs(g2_o.numpy()).max(axis=1, keepdims=True)
+    assert np.all(np.abs(p2.grad.cpu().numpy() - g2_o.numpy()) <= GRAD_RTOL * sc2 + 1e-6)
+    # the z-space entry uses the same path
+    z = pm.bij.inverse(prior.sample(B, seed=9)).to("cuda")
+    lp, red2, gz = pm.log_prob_and_grad(sim, z)
+    zz = z.clone().requires_grad_(True)
+    lpu, _ = pm.log_prob_unfused(sim, zz)
+    lpu.sum().backward()
+    assert torch.allclose(lp, lpu.detach(), rtol=LL_RTOL, atol=1e-3)
+    sc = zz.grad.abs().max(dim=1, keepdim=True).values
+    assert ((gz - zz.grad).abs() <= 5e-4 * sc + 1e-4).all()
