@@ -13,7 +13,10 @@ follows the reference's TF substrate line by line (file:line cited on every
 function) and is pinned by (i) the reference's one executable known-answer test
 (``tests/test_profiles.py:17-26``), (ii) the reference's own test recipes
 re-targeted at independently restated published formulas (``published.py``),
-(iii) closed-form identities between independent code paths.  Third-party
+(iii) closed-form identities between independent code paths, (iv) the one piece of
+reference-GENERATED data available -- the tf-demo image ``src/gigalens/assets/demo.npy``,
+which the restatement explains at reduced chi^2 = 0.9989 from the notebook's truth
+parameters (tests/test_reference_demo.py).  Third-party
 pieces that could not be pinned (TFP bijector layout, lenstronomy
 ``subgrid_kernel`` for supersample>1) are marked "parity unpinned" where used.
 """

@@ -1,0 +1,68 @@
+"""End-to-end pin against data the REFERENCE ITSELF generated (tests/golden/reference_assets): the demo image
+of tf-demo.ipynb.  Simulating the notebook's truth parameters (EPL+Shear, SersicEllipse lens light and source,
+13x13 PSF) must explain that image statistically: reduced chi^2 = 1 up to the unknown noise realisation.
+Any error in the grid convention, a deflection, a light profile, the PSF handling or the det(T) scale moves
+chi^2 far from 1 (dropping the PSF alone gives 1.59)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.join(os.path.dirname(__file__), "golden", "reference_assets")
+TRUTH = {  # tf-demo.ipynb cell 5
+    "lens_mass": [{"theta_E": 1.1, "gamma": 2.0, "e1": 0.1, "e2": 0.1, "center_x": 0.1, "center_y": 0.0},
+                  {"gamma1": -0.01, "gamma2": 0.03}],
+    "lens_light": [{"R_sersic": 0.8, "n_sersic": 2.5, "e1": 0.09534746574143645, "e2": 0.14849487967198177,
+                    "center_x": 0.1, "center_y": 0.0, "Ie": 499.3695906504067}],
+    "source_light": [{"R_sersic": 0.25, "n_sersic": 1.5, "e1": 0.0, "e2": 0.0, "center_x": 0.09566681002252231,
+                      "center_y": -0.0639623054267272, "Ie": 149.58828877085668}],
+}
+
+
+def _setup():
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import SersicEllipse
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.simulator import SimulatorConfig
+    obs = np.load(os.path.join(HERE, "demo.npy"))
+    psf = np.load(os.path.join(HERE, "psf.npy")).astype(np.float32)
+    phys = PhysicalModel([EPL(50), Shear()], [SersicEllipse()], [SersicEllipse()])
+    cfg = SimulatorConfig(delta_pix=0.065, num_pix=60, supersample=1, kernel=psf)
+    return obs, psf, phys, cfg
+
+
+def test_oracle_explains_reference_demo_image():
+    from oracle import ref_torch as ref
+    obs, psf, phys, cfg = _setup()
+    rs = ref.RefSimulator(phys, cfg, 1, dtype=torch.float64)
+    tt = {k: [{n: torch.tensor([v], dtype=torch.float64) for n, v in d.items()} for d in lst] for k, lst in TRUTH.items()}
+    ll, red = ref.stats_pixels(rs, tt, obs, 0.2, 100.0)
+    assert 0.95 < float(red) < 1.05, float(red)          # measured: 0.9989
+    assert abs(float(rs.simulate(tt).sum()) / obs.sum() - 1) < 2e-3
+    # sensitivity: without the PSF the same parameters do NOT explain the image
+    cfg.kernel = None
+    rs0 = ref.RefSimulator(phys, cfg, 1, dtype=torch.float64)
+    assert float(ref.stats_pixels(rs0, tt, obs, 0.2, 100.0)[1]) > 1.4
+
+
+@pytest.mark.gpu
+def test_hip_explains_reference_demo_image():
+    from gigalens_amd import prior as tfd
+    from gigalens_amd.model import ForwardProbModel
+    from gigalens_amd.simulator import LensSimulator
+    from oracle import ref_torch as ref
+    obs, psf, phys, cfg = _setup()
+    sim = LensSimulator(phys, cfg, bs=1)
+    prior = tfd.JointDistributionNamed(dict(lens_mass=tfd.JointDistributionSequential(
+        [tfd.JointDistributionNamed(dict(theta_E=tfd.Normal(0, 1)))])))
+    pm = ForwardProbModel(prior, obs, 0.2, 100.0, include_positions=False)
+    ll, red = pm.stats_pixels(sim, TRUTH)
+    assert 0.95 < float(red) < 1.05, float(red)
+    rs = ref.RefSimulator(phys, cfg, 1, dtype=torch.float64)
+    tt = {k: [{n: torch.tensor([np.float32(v)], dtype=torch.float64) for n, v in d.items()} for d in lst] for k, lst in TRUTH.items()}
+    ll_o, red_o = ref.stats_pixels(rs, tt, obs, 0.2, 100.0)
+    assert np.isclose(float(ll), float(ll_o), rtol=1e-5) and np.isclose(float(red), float(red_o), rtol=1e-5)
+    img = sim.simulate(TRUTH)
+    assert img.shape == (60, 60)  # bs == 1 squeezes like tf.squeeze (tf/simulator.py:156)
