@@ -98,8 +98,9 @@ def main():
     rank, local_rank, world = gdist.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import __graft_entry__ as ge
     from gigalens_amd import _native, workloads
@@ -199,7 +200,7 @@ def main():
                          "note": "path is VALU/transcendental-bound (SURVEY 8d): HBM fraction is reported as the "
                                  "metric asks, the binding bound is fp32 VALU issue"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(wl, obs, seconds=args.cpu_seconds)
         print(json.dumps(out), flush=True)
     gdist.barrier()

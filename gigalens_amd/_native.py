@@ -11,7 +11,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 import numpy as np
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgigalens_hip.so")
+_LIB_PATH = os.environ.get("GIGALENS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                           "libgigalens_hip.so")
 _lib = None
 
 GL_FLAG_SHAPELETS_INTERPOLATE = 1

@@ -25,6 +25,8 @@ using glm::atanh_;
 // ---- per-lane transcendentals on pairs -----------------------------------------------------------
 __device__ __forceinline__ v2f rcp(v2f a) { return v2f{glm::rcp(a.x), glm::rcp(a.y)}; }
 __device__ __forceinline__ v2f sqrt_(v2f a) { return v2f{glm::sqrt_(a.x), glm::sqrt_(a.y)}; }
+__device__ __forceinline__ float rsq_(float a) { return __builtin_amdgcn_rsqf(a); }
+__device__ __forceinline__ v2f rsq_(v2f a) { return v2f{__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)}; }
 __device__ __forceinline__ v2f exp2_(v2f a) { return v2f{glm::exp2_(a.x), glm::exp2_(a.y)}; }
 __device__ __forceinline__ v2f log2_(v2f a) { return v2f{glm::log2_(a.x), glm::log2_(a.y)}; }
 __device__ __forceinline__ v2f atan_(v2f a) { return v2f{glm::atan_(a.x), glm::atan_(a.y)}; }
@@ -57,14 +59,16 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   st.xr = dx * c + dy * s;
   st.yr = dy * c - dx * s;
   V X = st.xr * q;
-  V R0 = sqrt_(X * X + st.yr * st.yr);
-  auto pos = R0 > V(0.f);
-  st.inv = pos ? rcp(R0) : V(0.f);
-  V Cs = pos ? X * st.inv : V(1.f);
+  V r2 = X * X + st.yr * st.yr;
+  // one transcendental instead of sqrt + 2 rcp: r = 1/R0 (inf at R0 = 0), and 1/clip(R0, 1e-10, 1e10) is the
+  // clip of 1/R0 to [1e-10, 1e10] (epl.py:31); R0 itself is only needed through 1/R0
+  V r = rsq_(r2);
+  auto pos = r2 > V(0.f);
+  st.inv = pos ? r : V(0.f);
+  V Cs = pos ? X * r : V(1.f);
   V Ss = st.yr * st.inv;
-  auto inclamp = (R0 >= V(1e-10f)) & (R0 <= V(1e10f));
-  V iRc = rcp(vmin(vmax(R0, V(1e-10f)), V(1e10f)));  // epl.py:31
-  st.invc = inclamp ? iRc : V(0.f);                   // clip_by_value passes gradient only inside the clamp
+  V iRc = vmin(vmax(r, V(1e-10f)), V(1e10f));
+  st.invc = (iRc == r) ? r : V(0.f);  // clip_by_value passes gradient only inside the clamp
   V E2x = Cs * Cs - Ss * Ss, E2y = (Cs + Cs) * Ss;
   V Ex = Cs, Ey = Ss;
   st.Ox = Cs; st.Oy = Ss;
@@ -87,12 +91,18 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
     }
   };
   int n = 1;
+#if defined(GL_EXP_NOTABLE)  // timing experiment only: coefficients hoisted out of the loop (wrong numbers)
+  const float4 c1 = gtab[1], c2 = gtab[2];
+  for (; n + 1 <= K; n += 2) { step(c1); step(c2); }
+  if (n <= K) step(c1);
+#else
   for (; n + 1 <= K; n += 2) {
     const float4 ca = gtab[n], cb = gtab[n + 1];
     step(ca);
     step(cb);
   }
   if (n <= K) step(gtab[n]);
+#endif
   st.L2 = log2_(iRc * d[EPL_B]);
   st.P = exp2_(st.L2 * d[EPL_TM1]) * d[EPL_P0];  // 2b/(1+q) (b/R)^(t-1), epl.py:55
   V arx = st.P * st.Ox, ary = st.P * st.Oy;
@@ -204,7 +214,7 @@ template <class V> __device__ __forceinline__ V sersic_fwd_v(const float* d, V x
   st.a2 = dy * c - dx * s;
   V xt1 = st.a1 * d[SER_SQ], xt2 = st.a2 * d[SER_ISQ];
   st.r2 = xt1 * xt1 + xt2 * xt2;
-  st.L2 = log2_(sqrt_(st.r2) * d[SER_INVRS]);
+  st.L2 = log2_(st.r2) * 0.5f + d[SER_L2IRS];  // log2(R / R_sersic) without the square root
   st.u = exp2_(st.L2 * d[SER_INVN]);
   st.E = vexp<V>((st.u - 1.f) * -d[SER_BN]);
   return st.E * d[SER_IE];
@@ -249,8 +259,6 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   const float* __restrict__ gder = a.derived + (size_t)b * a.D;
   {
     for (int i = tid; i < a.D; i += WG) s_d[i] = gder[i];
-    if (MODE != IMG_FWD)
-      for (int i = tid; i < a.ncols * a.Apad; i += WG) s_acc[i] = 0.f;
   }
   __syncthreads();
   constexpr int NACC_L = [] { int n = 0; for (int i = 0; i < NL; ++i) n += static_nacc(LK::kinds[i]); return n; }();
@@ -277,25 +285,28 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
 
   const int p0 = chunk * a.chunk;
   const int p1 = min(p0 + a.chunk, a.N);
-  for (int base = p0; base < p1; base += WG * W) {
-    int jj[W], pidx[W];
+  // One tile = W*256 pixels.  CHECK=false is the steady state (whole tile inside the chunk, no pixel mask):
+  // no validity selects, no weights.  CHECK=true handles the ragged last tile and img_region weights.
+  auto tile = [&](int base, auto check_tag) {
+    constexpr bool CHECK = decltype(check_tag)::value;
+    unsigned jj[W], pidx[W];
     bool valid[W];
-    V x, y, vmask;
+    V x, y, vmask = V(1.f);
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       int j = base + w * WG + tid;
-      valid[w] = j < p1;
-      jj[w] = valid[w] ? j : p1 - 1;
-      pidx[w] = has_pix ? a.pix[jj[w]] : jj[w];
+      valid[w] = CHECK ? (j < p1) : true;
+      jj[w] = (unsigned)(valid[w] ? j : p1 - 1);
+      pidx[w] = has_pix ? (unsigned)a.pix[jj[w]] : jj[w];
     }
     if constexpr (W == 2) {
       x = V{a.gx[jj[0]], a.gx[jj[1]]};
       y = V{a.gy[jj[0]], a.gy[jj[1]]};
-      vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
+      if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
     } else {
       x = a.gx[jj[0]];
       y = a.gy[jj[0]];
-      vmask = valid[0] ? 1.f : 0.f;
+      if (CHECK) vmask = valid[0] ? 1.f : 0.f;
     }
     V bx = x, by = y, m = V(0.f);
     EplStateV<V> est[NL > 0 ? NL : 1];
@@ -323,42 +334,42 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
       } else {
         if (valid[0]) row[pidx[0]] = m;
       }
-      continue;
+      return;
     }
     V gm;
     if (MODE == IMG_BWD) {
       const float* row = a.gimg + (size_t)b * a.img_stride;
       V g;
       if constexpr (W == 2) g = V{row[pidx[0]], row[pidx[1]]}; else g = row[pidx[0]];
-      gm = nanp ? V(0.f) : g * vmask * a.out_scale;
+      gm = nanp ? V(0.f) : (CHECK ? g * vmask : g) * a.out_scale;
     } else {
       V o, w = vmask, e = V(1.f);
       if constexpr (W == 2) {
         o = V{a.obs[pidx[0]], a.obs[pidx[1]]};
-        if (has_mask) w = w * V{a.mask[pidx[0]], a.mask[pidx[1]]};
+        if (CHECK && has_mask) w = w * V{a.mask[pidx[0]], a.mask[pidx[1]]};
         if (has_err) e = V{a.err[pidx[0]], a.err[pidx[1]]};
       } else {
         o = a.obs[pidx[0]];
-        if (has_mask) w = w * a.mask[pidx[0]];
+        if (CHECK && has_mask) w = w * a.mask[pidx[0]];
         if (has_err) e = a.err[pidx[0]];
       }
       // tf/model.py:92-99; sigma^2 = bg^2 + m/t (no clip: negative -> NaN like sqrt of a negative)
       V dmo = m - o;
       V s2 = has_err ? e * e : m * a.inv_t + a.bg2;
-      auto neg = s2 < V(0.f);
       V is2 = rcp(s2);
-      V c2 = dmo * dmo * is2;
-      V nm = vlog<V>(s2 * (float)(2 * kPi));
-      const V qnan = V(__builtin_nanf(""));
-      c2 = neg ? qnan : c2;
-      nm = neg ? qnan : nm;
-      // invalid lanes carry weight 0; "x * 0" would keep a NaN, so select instead
-      auto use = w != V(0.f);
-      st0 += use ? c2 * w : V(0.f);
-      st1 += use ? nm * w : V(0.f);
+      V nm = vlog<V>(s2 * (float)(2 * kPi));  // NaN for sigma^2 < 0, like log(2 pi sqrt(.)^2) in the reference
+      V c2 = __builtin_elementwise_fma(nm, V(0.f), dmo * dmo * is2);  // + 0 * nm: carries that NaN into chi^2
+      if (CHECK) {  // invalid lanes carry weight 0; "x * 0" would keep a NaN, so select instead
+        auto use = w != V(0.f);
+        st0 += use ? c2 * w : V(0.f);
+        st1 += use ? nm * w : V(0.f);
+      } else {
+        st0 += c2;
+        st1 += nm;
+      }
       if (MODE == LL_GRAD) {
         V g = has_err ? -(dmo * is2) : (dmo * dmo * is2 - 1.f) * (is2 * (0.5f * a.inv_t)) - dmo * is2;
-        gm = nanp ? V(0.f) : g * w * a.out_scale;
+        gm = nanp ? V(0.f) : (CHECK ? g * w : g) * a.out_scale;
       }
     }
     if constexpr (GRAD) {
@@ -385,14 +396,31 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
         else sis_vjp_v<V>(dL[i], x, y, gbx, gby, accL + off);
       }, std::make_integer_sequence<int, NL>{});
     }
+  };
+  {
+    const bool plain = !has_mask;
+    int base = p0;
+    if (plain)
+      for (; base + WG * W <= p1; base += WG * W) tile(base, std::false_type{});
+    for (; base < p1; base += WG * W) tile(base, std::true_type{});
   }
   if (MODE == IMG_FWD) return;
   // ---- epilogue: per-sample scale factors deferred out of the pixel loop, lane sum, one reduction ----
-  const AccCol ac = acc_col(s_acc, a.Apad, a.ncols, tid);
-  if (MODE == LL_FWD || MODE == LL_GRAD) {
-    float st[2] = {hsum(st0), hsum(st1)};
-    wave_acc<2>(st, ac, 0);
+  // accumulators live in registers for the whole chunk, so ONE full wave64 reduction per value per workgroup
+  // is cheap: lane 63 of each wave stores its sums into the wave's own LDS row (no zero-fill, no read-modify-write)
+  if (!GRAD) {  // forward-only: the gradient slots of the partial row are defined (zero), never garbage
+    for (int i = tid; i < 4 * a.Apad; i += WG) s_acc[i] = 0.f;
+    __syncthreads();
   }
+  float* s_row = s_acc + (tid >> 6) * a.Apad;
+  const bool last_lane = (tid & 63) == 63;
+  auto put = [&](float v, int idx) {
+    v = wave_sum63(v);
+    if (last_lane) s_row[idx] = v;
+  };
+  put((MODE == LL_FWD || MODE == LL_GRAD) ? hsum(st0) : 0.f, 0);
+  put((MODE == LL_FWD || MODE == LL_GRAD) ? hsum(st1) : 0.f, 1);
+  if (last_lane) { s_row[2] = 0.f; s_row[3] = 0.f; }
   if constexpr (GRAD) {
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
@@ -406,7 +434,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
         tmp[EPLA_B] *= dL[i][EPL_INVB];
         tmp[EPLA_P0] *= rcp(dL[i][EPL_P0]);
       }
-      wave_acc<G>(tmp, ac, comps[i].a_off, comps[i].n_acc);
+#pragma unroll
+      for (int k = 0; k < G; ++k) put(tmp[k], comps[i].a_off + k);
     }, std::make_integer_sequence<int, NL>{});
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
@@ -420,15 +449,14 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
 #pragma unroll
       for (int k = 0; k < G; ++k) tmp[k] = hsum(accC[off + k]);
       tmp[SERA_INVN] *= (float)kLn2;
-      wave_acc<G>(tmp, ac, comps[NL + i].a_off, comps[NL + i].n_acc);
+#pragma unroll
+      for (int k = 0; k < G; ++k) put(tmp[k], comps[NL + i].a_off + k);
     }, std::make_integer_sequence<int, NLIGHT>{});
   }
   __syncthreads();
   float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
   for (int k = tid; k < a.A; k += WG) {
-    float v = 0.f;
-    for (int j = 0; j < a.ncols; ++j) v += s_acc[j * a.Apad + k];
-    out[k] = v;
+    out[k] = (s_acc[k] + s_acc[a.Apad + k]) + (s_acc[2 * a.Apad + k] + s_acc[3 * a.Apad + k]);
   }
 }
 

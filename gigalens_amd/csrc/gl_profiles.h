@@ -49,7 +49,7 @@ enum { SHR_NACC = 2 };
 enum { SIS_CX = 0, SIS_CY, SIS_TE, SIS_ND };
 enum { SIS_NACC = 3 };
 // SERSIC / SERSIC_ELLIPSE (one code path; the spherical profile is the e=0 member, sersic.py:52-55)
-enum { SER_CX = 0, SER_CY, SER_C, SER_S, SER_SQ, SER_ISQ, SER_INVRS, SER_INVN, SER_BN, SER_IE, SER_ND };
+enum { SER_CX = 0, SER_CY, SER_C, SER_S, SER_SQ, SER_ISQ, SER_INVRS, SER_INVN, SER_BN, SER_IE, SER_ND, SER_L2IRS = SER_ND /* log2(1/R_sersic) */ };
 enum { SERA_CX = 0, SERA_CY, SERA_PHI, SERA_SQ, SERA_L, SERA_INVN, SERA_BN, SERA_IE, SER_NACC };
 // SHAPELETS
 enum { SHP_CX = 0, SHP_CY, SHP_IB, SHP_NMAX, SHP_AMP = 4 };
@@ -585,7 +585,7 @@ template <class R> GL_HD void sersic_prep(const R* p, bool ellipse, R* d) {
   d[SER_INVN] = (R)1 / p[1];
   d[SER_BN] = (R)1.9992 * p[1] - (R)0.3271;  // sersic.py:33
   d[SER_IE] = rest[2];
-  d[SER_ND] = (R)0;
+  d[SER_L2IRS] = -p_log(p[0]) * (R)kLog2e;
   d[SER_ND + 1] = (R)0;
 }
 template <class R> GL_HD R sersic_fwd(const R* d, R x, R y) {
