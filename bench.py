@@ -122,9 +122,9 @@ def main():
 
     def step():
         lp, red, g = pm.log_prob_and_grad(sim, z)
-        if world > 1:
-            coll[0] = lp.mean()
-            coll[1:1 + d] = g.mean(0)
+        if world > 1:  # the path's one collective: fused [ELBO, grad] buffer, mean over ranks
+            torch.mean(lp, 0, keepdim=True, out=coll[0:1])
+            torch.mean(g, 0, out=coll[1:1 + d])
             gdist.allreduce_mean_(coll)
         return lp, g
 

@@ -468,3 +468,100 @@ def test_psf_supersample_vs_oracle(gl, ss, ksize):
     assert torch.allclose(lp, lpu.detach(), rtol=LL_RTOL, atol=1e-3)
     sc = zz.grad.abs().max(dim=1, keepdim=True).values
     assert ((gz - zz.grad).abs() <= 5e-4 * sc + 1e-4).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# edge cases: degenerate compositions, truncated series, exact-zero ellipticity, large / tiny batches
+# ---------------------------------------------------------------------------------------------------
+def _edge_case(gl, phys, prior, n, B, seed=3):
+    from gigalens_amd.simulator import SimulatorConfig
+    wl = gl.workloads.Workload("EDGE", phys, prior, SimulatorConfig(delta_pix=0.07, num_pix=n), B)
+    obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(phys, wl.sim_config, bs=B)
+    packed = H.sample_packed(wl, sim, seed=seed)
+    ll_o, red_o, g_o, img_o = H.oracle_loglike_and_grad(wl, packed.cpu().double(), obs.cpu().numpy(), None, B)
+    img = sim.simulate(packed).cpu().numpy().reshape(img_o.shape)
+    assert np.abs(img - img_o).max() <= IMG_RTOL * np.abs(img_o).max() + 1e-7
+    pm = gl.ForwardProbModel(prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, red = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    assert np.allclose(ll.detach().cpu().numpy().reshape(-1), ll_o.reshape(-1), rtol=LL_RTOL)
+    g = p.grad.cpu().numpy()
+    scale = np.maximum(np.abs(g_o).max(axis=1, keepdims=True), 1e-3 * np.abs(g_o).max())
+    bad = np.abs(g - g_o) > GRAD_RTOL * scale + 1e-6
+    assert not bad.any(), (np.argwhere(bad)[:5], g[bad][:5], g_o[bad][:5])
+
+
+def test_edge_compositions(gl):
+    import math
+    from gigalens_amd import prior as tfd
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import Sersic, SersicEllipse
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.sis import SIS
+    J, S = tfd.JointDistributionNamed, tfd.JointDistributionSequential
+    ser = lambda: J(dict(R_sersic=tfd.LogNormal(math.log(0.3), 0.1), n_sersic=tfd.Uniform(1, 3), center_x=tfd.Normal(0, 0.1),
+                         center_y=tfd.Normal(0, 0.1), Ie=tfd.LogNormal(math.log(50.0), 0.3)))
+    # lens light only -- no lens, no source (no deflection at all)
+    _edge_case(gl, PhysicalModel([], [Sersic()], []), J(dict(lens_light=S([ser()]))), 18, 3)
+    # source only, seen without a lens
+    _edge_case(gl, PhysicalModel([], [], [Sersic()]), J(dict(source_light=S([ser()]))), 18, 2)
+    # SIS lens (interpreter kernel), one-sample batch: bs == 1 squeezes the outputs like tf.squeeze
+    sis = J(dict(theta_E=tfd.LogNormal(math.log(0.5), 0.1), center_x=tfd.Normal(0, 0.02), center_y=tfd.Normal(0, 0.02)))
+    _edge_case(gl, PhysicalModel([SIS()], [], [Sersic()]), J(dict(lens_mass=S([sis]), source_light=S([ser()]))), 21, 1)
+    # EPL whose series is cut by a small `niter` cap (epl.py:15,51): truncation must match the reference's
+    epl = J(dict(theta_E=tfd.LogNormal(math.log(0.5), 0.1), gamma=tfd.TruncatedNormal(2, 0.25, 1, 3), e1=tfd.Normal(0.3, 0.05),
+                 e2=tfd.Normal(-0.2, 0.05), center_x=tfd.Normal(0, 0.02), center_y=tfd.Normal(0, 0.02)))
+    _edge_case(gl, PhysicalModel([EPL(niter=6)], [SersicEllipse()], [Sersic()]),
+               J(dict(lens_mass=S([epl]), lens_light=S([J(dict(R_sersic=tfd.LogNormal(0, 0.1), n_sersic=tfd.Uniform(2, 4),
+                 e1=tfd.Normal(0, 0.1), e2=tfd.Normal(0, 0.1), center_x=tfd.Normal(0, 0.02), center_y=tfd.Normal(0, 0.02),
+                 Ie=tfd.LogNormal(math.log(20.0), 0.2)))]), source_light=S([ser()]))), 20, 4)
+
+
+def test_epl_circular_and_large_batch(gl):
+    """e1 = e2 = 0 exactly: f = 0, the series has a single term (epl.py:37: log(1e-12)/log(0) + 2 = 2); and a batch
+    larger than one grid row of workgroups, with fewer pixels than one tile."""
+    wl = gl.workloads.make("C2", num_pix=12, batch=2500)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    packed = H.sample_packed(wl, sim, seed=2)
+    packed[:7, 2] = 0.0
+    packed[:7, 3] = 0.0
+    sub = torch.cat([packed[:12], packed[-5:]])
+    ll_o, red_o, g_o, img_o = H.oracle_loglike_and_grad(gl.workloads.make("C2", num_pix=12, batch=17), sub.cpu().double(),
+                                                        np.ones((12, 12), np.float32), None, 17)
+    pm = gl.ForwardProbModel(wl.prior, np.ones((12, 12), np.float32), wl.background_rms, wl.exp_time, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, _ = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    got = torch.cat([ll.detach()[:12], ll.detach()[-5:]]).cpu().numpy()
+    assert np.allclose(got, ll_o, rtol=LL_RTOL)
+    g = torch.cat([p.grad[:12], p.grad[-5:]]).cpu().numpy()
+    # d/de at e == 0 is undefined in the reference (sqrt'(0) * 0 = NaN in TF / torch); here it is defined as 0
+    assert np.all(np.isnan(g_o[:7, 2:4])) and np.all(g[:7, 2:4] == 0)
+    keep = np.ones_like(g, dtype=bool)
+    keep[:7, 2:4] = False
+    scale = np.nanmax(np.abs(np.where(keep, g_o, np.nan)), axis=1, keepdims=True)
+    assert np.all(np.abs(g - g_o)[keep] <= (GRAD_RTOL * scale + 1e-6).repeat(g.shape[1], 1)[keep])
+    with pytest.raises(__import__("gigalens_amd._native", fromlist=["x"]).NativeLibraryError):
+        sim._model.simulate_fwd(torch.zeros((70000, sim._model.P), device="cuda"))  # B > 65535: refused, not truncated
+
+
+def test_hip_graph_capture(gl):
+    """No per-call allocation / synchronisation inside the library: a whole forward+gradient call sequence can be
+    captured into a HIP graph and replayed (tf.function-style reuse for the HMC leapfrog loop)."""
+    wl = gl.workloads.make("C2", num_pix=32, batch=16)
+    obs, _, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    pm = gl.ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time, include_positions=False)
+    z = pm.bij.inverse(wl.prior.sample(wl.batch, seed=4)).to("cuda").contiguous()
+    lp0, red0, g0 = pm.log_prob_and_grad(sim, z)  # warm-up: binds the prior, sizes the workspace
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        lp, red, g = pm.log_prob_and_grad(sim, z)
+    z.add_(0.01)
+    graph.replay()
+    torch.cuda.synchronize()
+    lp1, red1, g1 = pm.log_prob_and_grad(sim, z)
+    assert torch.equal(lp, lp1) and torch.equal(g, g1) and not torch.equal(lp, lp0)
