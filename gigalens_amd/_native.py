@@ -48,6 +48,7 @@ SYMBOLS = {
     "gl_model_num_pixels": (c_int64, [c_void_p]),
     "gl_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "gl_simulate_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gl_simulate_parts_fwd": (c_int, [c_void_p, c_void_p, c_int, c_uint32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gl_simulate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gl_loglike_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -243,6 +244,15 @@ class Model:
         ws = self._workspace(B)
         img = torch.empty((B, self.out_h, self.out_w), dtype=torch.float32, device=params.device)
         _check(lib().gl_simulate_fwd(self._h, _ptr(params), B, _ptr(img), _ptr(ws), ws.numel(), _stream()))
+        return img
+
+    def simulate_parts(self, params, parts):
+        params = self._params(params)
+        B = params.shape[0]
+        ws = self._workspace(B)
+        img = torch.empty((B, self.out_h, self.out_w), dtype=torch.float32, device=params.device)
+        _check(lib().gl_simulate_parts_fwd(self._h, _ptr(params), B, int(parts), _ptr(img), _ptr(ws), ws.numel(),
+                                           _stream()))
         return img
 
     def simulate_bwd(self, params, grad_img):

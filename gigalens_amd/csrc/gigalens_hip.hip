@@ -215,7 +215,7 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
   dim3 grid(n_chunks, B), block(WG);
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
   if (m->timing) GL_HIP(hipEventRecord(m->ev0, stream));
-  if (m->static_id && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
+  if (m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
     // specialised kernel launched
   } else if (const int Tg = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile; m->has_shapelets) {
     if (Tg == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, true>), grid, block, shmem, stream, a);
@@ -250,6 +250,7 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.partial = w.partial;
   a.shp_tab = m->d_shp_tab;
   a.shp_stride = m->shp_stride;
+  a.parts = 7u;
   return a;
 }
 
@@ -580,6 +581,29 @@ int gl_simulate_fwd(const gl_model* m, const float* params, int B, float* img, v
   chunking(m, B, &chunk, &n_chunks);
   if ((rc = run_prep(m, params, B, w, stream))) return rc;
   MainArgs a = base_args(m, w, chunk);
+  if ((rc = run_order(m, B, w, &a, stream))) return rc;
+  if (m->has_post) {
+    if ((rc = render_ss(m, a, B, n_chunks, w, stream))) return rc;
+    return post_fwd(m, B, w.img_ss, img, stream);
+  }
+  if (m->d_pix) GL_HIP(hipMemsetAsync(img, 0, sizeof(float) * (size_t)B * m->height * m->width, stream));
+  a.img = img;
+  return launch_main<IMG_FWD>(m, a, B, n_chunks, stream);
+}
+
+int gl_simulate_parts_fwd(const gl_model* m, const float* params, int B, unsigned parts, float* img, void* workspace,
+                          size_t workspace_bytes, void* hip_stream) {
+  int rc = check_call(m, params, B, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!img) return fail(GL_EINVAL, "img is null");
+  if (parts == 0 || parts > 7u) return fail(GL_EINVAL, "parts must be a non-empty subset of {1,2,4}");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  Workspace w = carve(m, B, workspace);
+  int chunk, n_chunks;
+  chunking(m, B, &chunk, &n_chunks);
+  if ((rc = run_prep(m, params, B, w, stream))) return rc;
+  MainArgs a = base_args(m, w, chunk);
+  a.parts = parts;
   if ((rc = run_order(m, B, w, &a, stream))) return rc;
   if (m->has_post) {
     if ((rc = render_ss(m, a, B, n_chunks, w, stream))) return rc;

@@ -51,6 +51,7 @@ struct MainArgs {
   const float* shp_tab;
   int shp_stride;
   const int* order;  // cost-ordered dispatch: blockIdx.y -> sample index (heaviest first), or null
+  unsigned parts;    // forward-only partial renders (tf/simulator.py:242-328): bit0 deflect, bit1 lens light, bit2 sources
 };
 
 // ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
       bx[t] = x[t]; by[t] = y[t]; m[t] = 0.f;
     }
     // ---- phase 1: ray-shoot  beta = (x,y) - sum_i alpha_i(x,y)   (tf/simulator.py:72-78) ----
-    for (int l = 0; l < n_lens; ++l) {
+    for (int l = 0; l < ((a.parts & 1u) ? n_lens : 0); ++l) {
       const int kind = comps[l].kind;
       const float* d = s_d + comps[l].d_off;
       switch (kind) {
@@ -441,6 +442,7 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
       const CompDesc& cd = comps[n_lens + ci];
       const float* d = s_d + cd.d_off;
       const bool src = ci >= n_ll;
+      if (!(a.parts & (src ? 4u : 2u))) continue;
       if (cd.kind == K_SHAPELETS) {
         if (SHP) {
           const bool interp = cd.flags & 1u;

@@ -160,11 +160,41 @@ class LensSimulator(LensSimulatorInterface):
 
     def simulate(self, params, no_deflection=False):
         """tf/simulator.py:109-156.  Returns ``(bs, H, W)`` squeezed like ``tf.squeeze``."""
-        if no_deflection:
-            raise NotImplementedError("no_deflection=True is not built yet")
         packed = params if torch.is_tensor(params) else self.pack(params)
+        if no_deflection:  # tf/simulator.py:125-126: sources are rendered on the un-deflected grid
+            return self._parts(packed, 2 | 4)
         img = _SimulateFn.apply(packed, self._model)
         return torch.squeeze(img)
+
+    def _parts(self, packed, parts):
+        if packed.requires_grad:
+            raise NotImplementedError("partial renders are forward-only helpers (no gradient)")
+        return torch.squeeze(self._model.simulate_parts(packed, parts))
+
+    def _pack_partial(self, params):
+        """Partial renders only receive the groups they use; the unused columns are filled with a valid dummy (1)."""
+        if torch.is_tensor(params):
+            return params
+        cols = []
+        for g, i, name, const in self._layout.slots:
+            grp = params.get(g)
+            v = grp[i].get(name) if grp is not None and i < len(grp) else None
+            v = const if v is None else v
+            v = torch.as_tensor(1.0 if v is None else v, dtype=torch.float32, device=self.device)
+            cols.append(v.reshape(-1).expand(self.bs) if v.numel() != self.bs else v.reshape(self.bs))
+        return torch.stack(cols, dim=1)
+
+    def simulate_source(self, params):
+        """tf/simulator.py:242-269: the sources on the image grid, without lensing."""
+        return self._parts(self._pack_partial(params), 4)
+
+    def simulate_lens_light(self, params):
+        """tf/simulator.py:271-297."""
+        return self._parts(self._pack_partial(params), 2)
+
+    def simulate_images(self, params):
+        """tf/simulator.py:299-328: the lensed sources only."""
+        return self._parts(self._pack_partial(params), 1 | 4)
 
     def lstsq_simulate(self, params, observed_image, err_map, **kw):
         raise NotImplementedError("lstsq_simulate (linear amplitude solve) is a later row (SURVEY 8f-4)")

@@ -98,6 +98,16 @@ size_t gl_workspace_bytes(const gl_model* m, int B);
 int gl_simulate_fwd(const gl_model* m, const float* params, int B, float* img,
                     void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* Partial renders (forward only): LensSimulator.simulate(no_deflection=True) (tf/simulator.py:125-126),
+ * simulate_source (:242-269), simulate_lens_light (:271-297), simulate_images (:299-328).
+ * parts is a bit set: 1 = apply the deflection, 2 = lens light, 4 = source light
+ * (simulate == 7, no_deflection == 6, simulate_source == 4, simulate_lens_light == 2, simulate_images == 5). */
+#define GL_PART_DEFLECT 1u
+#define GL_PART_LENS_LIGHT 2u
+#define GL_PART_SOURCE_LIGHT 4u
+int gl_simulate_parts_fwd(const gl_model* m, const float* params, int B, unsigned parts, float* img,
+                          void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Vector-Jacobian product of the above (what tf.GradientTape supplies, tf/inference.py:33-39):
  * grad_img [B,H,W] -> grad_params [B,P]. */
 int gl_simulate_bwd(const gl_model* m, const float* params, const float* grad_img, int B,

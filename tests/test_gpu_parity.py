@@ -565,3 +565,31 @@ def test_hip_graph_capture(gl):
     torch.cuda.synchronize()
     lp1, red1, g1 = pm.log_prob_and_grad(sim, z)
     assert torch.equal(lp, lp1) and torch.equal(g, g1) and not torch.equal(lp, lp0)
+
+
+def test_partial_renders(gl):
+    """simulate(no_deflection=True), simulate_source, simulate_lens_light, simulate_images (tf/simulator.py:125-126,242-328)."""
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import SersicEllipse
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.simulator import SimulatorConfig
+    from oracle import ref_torch as ref
+    from tests.test_prior_host import default_prior
+    phys = PhysicalModel([EPL(), Shear()], [SersicEllipse()], [SersicEllipse()])
+    cfg = SimulatorConfig(delta_pix=0.07, num_pix=26)
+    B = 3
+    sim = gl.LensSimulator(phys, cfg, bs=B)
+    x = default_prior().sample(B, seed=8)
+    full, nodefl = sim.simulate(x), sim.simulate(x, no_deflection=True)
+    src, ll, arcs = sim.simulate_source(x), sim.simulate_lens_light(x), sim.simulate_images(x)
+    tol = dict(rtol=1e-5, atol=1e-5 * float(full.abs().max()))
+    assert torch.allclose(full, ll + arcs, **tol) and torch.allclose(nodefl, ll + src, **tol)
+    assert not torch.allclose(arcs, src, **tol)
+    rs = ref.RefSimulator(phys, cfg, B, dtype=torch.float64)
+    x64 = {k: [{n: v.double().cpu() for n, v in d.items()} for d in lst] for k, lst in x.items()}
+    o = rs.simulate(x64, no_deflection=True).numpy()
+    assert np.abs(nodefl.cpu().numpy() - o).max() <= IMG_RTOL * np.abs(o).max()
+    # the helpers accept only the group they need, like the reference's
+    only_src = sim.simulate_source({"source_light": x["source_light"]})
+    assert torch.equal(only_src, src)
