@@ -54,7 +54,12 @@ SYMBOLS = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gl_model_set_prior": (c_int, [c_void_p, POINTER(gl_zcolumn), c_int, POINTER(c_float)]),
     "gl_logprob_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint32, c_void_p, c_size_t,
+                                   c_void_p]),
+    "gl_model_set_positions": (c_int, [c_void_p, c_int, POINTER(c_int32), POINTER(c_float), POINTER(c_float),
+                                       POINTER(c_float), POINTER(c_float)]),
+    "gl_positions_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
     "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     "gl_kind_num_params": (c_int, [POINTER(gl_component)]),
@@ -200,7 +205,32 @@ class Model:
             _check(lib().gl_model_set_prior(self._h, arr, len(columns), cr.ctypes.data_as(POINTER(c_float))))
         self.d_z = len(columns)
 
-    def logprob(self, z, obs, err, mask, bg_rms, exp_time, want_grad, chi2_divisor=1.0):
+    def set_positions(self, xs, ys, exs, eys):
+        """xs, ys, exs, eys: lists (one entry per image family) of 1-D arrays of equal length."""
+        sizes = np.asarray([len(np.atleast_1d(x)) for x in xs], dtype=np.int32)
+        cat = lambda L: np.ascontiguousarray(np.concatenate([np.atleast_1d(np.asarray(v, dtype=np.float32)) for v in L]))
+        x, y, ex, ey = cat(xs), cat(ys), cat(exs), cat(eys)
+        if not (x.size == y.size == ex.size == ey.size == int(sizes.sum())):
+            raise NativeLibraryError("centroids / errors of a family must have the same length")
+        fp = lambda a: a.ctypes.data_as(POINTER(c_float))
+        with torch.cuda.device(self.device):
+            _check(lib().gl_model_set_positions(self._h, len(sizes), sizes.ctypes.data_as(POINTER(c_int32)), fp(x), fp(y),
+                                                fp(ex), fp(ey)))
+        self.n_images = int(sizes.sum())
+        self._ws = {}  # workspace layout changed
+
+    def positions(self, params, want_grad):
+        params = self._params(params)
+        B = params.shape[0]
+        ws = self._workspace(B)
+        ll = torch.empty(B, dtype=torch.float32, device=params.device)
+        chi2 = torch.empty_like(ll)
+        grad = torch.empty_like(params) if want_grad else None
+        _check(lib().gl_positions_fwd_bwd(self._h, _ptr(params), B, _ptr(ll), _ptr(chi2), _ptr(grad), _ptr(ws),
+                                          ws.numel(), _stream()))
+        return ll, chi2, grad
+
+    def logprob(self, z, obs, err, mask, bg_rms, exp_time, want_grad, chi2_divisor=1.0, terms=1):
         _require_cuda(z, "z")
         if z.dtype != torch.float32 or z.dim() != 2 or z.shape[1] != self.d_z:
             raise NativeLibraryError(f"z must be float32 [B,{self.d_z}], got {z.dtype} {tuple(z.shape)}")
@@ -213,7 +243,7 @@ class Model:
         grad = torch.empty_like(z) if want_grad else None
         _check(lib().gl_logprob_fwd_bwd(self._h, _ptr(z), _ptr(obs), _ptr(err), _ptr(mask), float(bg_rms),
                                         float(exp_time), B, _ptr(lp), _ptr(ll), _ptr(chi2), _ptr(grad),
-                                        float(chi2_divisor), _ptr(ws), ws.numel(), _stream()))
+                                        float(chi2_divisor), int(terms), _ptr(ws), ws.numel(), _stream()))
         return lp, ll, chi2, grad
 
     def set_timing(self, enabled=True):

@@ -18,6 +18,7 @@
 #include "gl_static.hip.h"
 #include "gl_pair.hip.h"
 #include "gl_post.hip.h"
+#include "gl_positions.hip.h"
 
 using namespace glk;
 
@@ -74,6 +75,10 @@ struct gl_model {
   int static_id = 0;   // 0 = generic interpreter kernel, >0 = compile-time-specialised composition
   int static_variant = 0;
   int pair = 1;        // pixel-pair (packed fp32) form of the specialised kernels
+  // image-position likelihood (gl_model_set_positions)
+  int pos_J = 0, pos_F = 0, lens_params = 0;
+  float* d_pos = nullptr;  // [4][J]: x, y, err_x, err_y
+  int* d_fam = nullptr;    // [F+1]
   bool has_epl = false;
   bool use_order = true;
   bool timing = false;
@@ -101,6 +106,7 @@ struct Workspace {
   float* partial;
   float* params;  // [B,P] constrained rows produced from z (gl_logprob_fwd_bwd)
   int* order;     // [B] cost-ordered dispatch
+  float *pos_w, *pos_adj, *pos_g, *pos_fam, *pos_ll, *pos_chi2, *pos_grad;  // image-position likelihood
   float* img_ss;   // supersampled / pre-PSF image or its cotangent (PSF path only)
   float* img_tmp;  // final-resolution image / its cotangent (PSF path only)
   float* stats;    // [B][2] chi2, normalisation of the materialised image (PSF path only)
@@ -121,6 +127,16 @@ Workspace carve(const gl_model* m, int B, void* base) {
   off += align_up((size_t)B * std::max(m->P, 1) * sizeof(float), 256);
   w.order = (int*)(p + off);
   off += align_up((size_t)B * sizeof(int), 256);
+  if (m->pos_J) {
+    auto take = [&](size_t n) { float* q = (float*)(p + off); off += align_up(n * sizeof(float), 256); return q; };
+    w.pos_w = take((size_t)B * m->pos_J * 6);
+    w.pos_adj = take((size_t)B * m->pos_J * 3);
+    w.pos_g = take((size_t)B * m->pos_J * std::max(m->P, 1));
+    w.pos_fam = take((size_t)B * m->pos_F * 2);
+    w.pos_ll = take(B);
+    w.pos_chi2 = take(B);
+    w.pos_grad = take((size_t)B * std::max(m->P, 1));
+  }
   if (m->has_post) {
     w.img_ss = (float*)(p + off);
     off += align_up((size_t)B * m->height * m->width * sizeof(float), 256);
@@ -276,11 +292,13 @@ int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, 
 int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, const Workspace& w, float* loglike,
                  float* chi2, float* grad, hipStream_t stream, const float* z = nullptr, float* logprob = nullptr,
                  float* grad_z = nullptr, float chi2_scale = 1.f, const float* extra_stats = nullptr,
-                 int use_partial = 1) {
+                 int use_partial = 1, bool with_positions = false, float pos_chi2_scale = 0.f) {
   size_t shmem = (size_t)(((m->A + 3) & ~3) + ((m->P + 3) & ~3) + ((m->d_z + 3) & ~3) + 4) * sizeof(float);
   hipLaunchKernelGGL(gl_finalize_kernel, dim3(B), dim3(128), shmem, stream, m->d_comps, (int)m->comps.size(), params,
                      m->P, w.partial, n_chunks, m->A, loglike, chi2, grad, z, m->d_z, z ? m->d_zcols : nullptr, logprob,
-                     grad_z, chi2_scale, extra_stats, use_partial);
+                     grad_z, chi2_scale, extra_stats, use_partial, with_positions ? w.pos_ll : nullptr,
+                     with_positions ? w.pos_chi2 : nullptr,
+                     with_positions && (grad || grad_z) ? w.pos_grad : nullptr, pos_chi2_scale);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -296,6 +314,38 @@ int run_order(const gl_model* m, int B, const Workspace& w, MainArgs* a, hipStre
   return GL_OK;
 }
 
+
+// image-position likelihood on the packed parameter rows `params` [B,P] (already on the device)
+int run_positions(const gl_model* m, const float* params, int B, const Workspace& w, bool want_grad, hipStream_t stream) {
+  PosArgs a{};
+  a.comps = m->d_comps;
+  a.n_lens = m->n_lens;
+  a.P = m->P;
+  a.B = B;
+  a.J = m->pos_J;
+  a.F = m->pos_F;
+  a.params = params;
+  a.px = m->d_pos;
+  a.py = m->d_pos + m->pos_J;
+  a.ex = m->d_pos + 2 * m->pos_J;
+  a.ey = m->d_pos + 3 * m->pos_J;
+  a.fam_off = m->d_fam;
+  a.w_pos = w.pos_w;
+  a.w_adj = w.pos_adj;
+  a.w_g = w.pos_g;
+  a.w_fam = w.pos_fam;
+  a.ll = w.pos_ll;
+  a.chi2 = w.pos_chi2;
+  a.grad = want_grad ? w.pos_grad : nullptr;
+  auto blocks = [](long long n) { return dim3((unsigned)((n + 63) / 64)); };
+  hipLaunchKernelGGL(gl_pos_p1_kernel, blocks((long long)B * a.J), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(gl_pos_p2_kernel, blocks((long long)B * a.F), dim3(64), 0, stream, a);
+  if (want_grad && m->n_lens)
+    hipLaunchKernelGGL(gl_pos_p3_kernel, blocks((long long)B * a.J * a.n_lens), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(gl_pos_p4_kernel, blocks((long long)B * (a.P + 1)), dim3(64), 0, stream, a, m->lens_params);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
 
 // ---- PSF / supersampling path (gl_post.hip.h) -------------------------------------------------------------
 PostArgs post_args(const gl_model* m, float scale) {
@@ -445,6 +495,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     m->comps.push_back(cd);
   }
   m->P = p_off;
+  for (int i = 0; i < n_lens; ++i) m->lens_params += m->comps[i].n_par;
   m->D = std::max(d_off, 4);
   m->A = a_off;
   m->Apad = a_off | 1;  // odd: the 16 leader lanes of a wave land on 16 different LDS banks
@@ -551,6 +602,8 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_pix) (void)hipFree(m->d_pix);
   if (m->d_shp_tab) (void)hipFree(m->d_shp_tab);
   if (m->d_psf) (void)hipFree(m->d_psf);
+  if (m->d_pos) (void)hipFree(m->d_pos);
+  if (m->d_fam) (void)hipFree(m->d_fam);
   if (m->d_zcols) (void)hipFree(m->d_zcols);
   if (m->d_src) (void)hipFree(m->d_src);
   if (m->d_const) (void)hipFree(m->d_const);
@@ -656,6 +709,45 @@ int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs,
                       1.f, extra, use_partial);
 }
 
+int gl_model_set_positions(gl_model* m, int n_families, const int* family_sizes, const float* x, const float* y,
+                           const float* err_x, const float* err_y) {
+  if (!m) return fail(GL_EINVAL, "model is null");
+  if (n_families <= 0 || !family_sizes || !x || !y || !err_x || !err_y) return fail(GL_EINVAL, "bad position tables");
+  std::vector<int> off(n_families + 1, 0);
+  for (int f = 0; f < n_families; ++f) {
+    if (family_sizes[f] <= 0) return fail(GL_EINVAL, "image family %d is empty", f);
+    off[f + 1] = off[f] + family_sizes[f];
+  }
+  const int J = off[n_families];
+  std::vector<float> tab((size_t)4 * J);
+  for (int j = 0; j < J; ++j) { tab[j] = x[j]; tab[J + j] = y[j]; tab[2 * J + j] = err_x[j]; tab[3 * J + j] = err_y[j]; }
+  if (m->d_pos) { (void)hipFree(m->d_pos); m->d_pos = nullptr; }
+  if (m->d_fam) { (void)hipFree(m->d_fam); m->d_fam = nullptr; }
+  GL_HIP(hipMalloc((void**)&m->d_pos, tab.size() * sizeof(float)));
+  GL_HIP(hipMalloc((void**)&m->d_fam, off.size() * sizeof(int)));
+  GL_HIP(hipMemcpy(m->d_pos, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  GL_HIP(hipMemcpy(m->d_fam, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+  m->pos_J = J;
+  m->pos_F = n_families;
+  return GL_OK;
+}
+
+int gl_positions_fwd_bwd(const gl_model* m, const float* params, int B, float* loglike, float* chi2,
+                         float* grad_params_or_null, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = check_call(m, params, B, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!m->pos_J) return fail(GL_EINVAL, "gl_model_set_positions has not been called on this model");
+  if (!loglike || !chi2) return fail(GL_EINVAL, "loglike / chi2 is null");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  Workspace w = carve(m, B, workspace);
+  if ((rc = run_positions(m, params, B, w, grad_params_or_null != nullptr, stream))) return rc;
+  GL_HIP(hipMemcpyAsync(loglike, w.pos_ll, sizeof(float) * B, hipMemcpyDeviceToDevice, stream));
+  GL_HIP(hipMemcpyAsync(chi2, w.pos_chi2, sizeof(float) * B, hipMemcpyDeviceToDevice, stream));
+  if (grad_params_or_null)
+    GL_HIP(hipMemcpyAsync(grad_params_or_null, w.pos_grad, sizeof(float) * (size_t)B * m->P, hipMemcpyDeviceToDevice, stream));
+  return GL_OK;
+}
+
 int gl_model_set_prior(gl_model* m, const gl_zcolumn* cols, int d, const float* const_row) {
   if (!m) return fail(GL_EINVAL, "model is null");
   if (d < 0 || (d > 0 && !cols)) return fail(GL_EINVAL, "bad prior column table");
@@ -691,13 +783,16 @@ int gl_model_set_prior(gl_model* m, const gl_zcolumn* cols, int d, const float* 
 
 int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, const float* err_or_null,
                        const float* mask_or_null, float bg_rms, float exp_time, int B, float* logprob, float* loglike,
-                       float* chi2, float* grad_z_or_null, float chi2_divisor, void* workspace, size_t workspace_bytes,
-                       void* hip_stream) {
+                       float* chi2, float* grad_z_or_null, float chi2_divisor, unsigned terms, void* workspace,
+                       size_t workspace_bytes, void* hip_stream) {
   int rc = check_call(m, z, B, workspace, workspace_bytes);
-  if (!(chi2_divisor > 0.f)) return fail(GL_EINVAL, "chi2_divisor must be positive");
   if (rc) return rc;
+  const bool pix = terms & GL_TERM_PIXELS, pos = terms & GL_TERM_POSITIONS;
+  if (!pix && !pos) return fail(GL_EINVAL, "terms selects no likelihood term");
+  if (pix && !(chi2_divisor > 0.f)) return fail(GL_EINVAL, "chi2_divisor must be positive");
   if (!m->d_zcols) return fail(GL_EINVAL, "gl_model_set_prior has not been called on this model");
-  if (!obs || !logprob || !loglike || !chi2) return fail(GL_EINVAL, "obs / logprob / loglike / chi2 is null");
+  if (pos && !m->pos_J) return fail(GL_EINVAL, "gl_model_set_positions has not been called on this model");
+  if ((pix && !obs) || !logprob || !loglike || !chi2) return fail(GL_EINVAL, "obs / logprob / loglike / chi2 is null");
   hipStream_t stream = (hipStream_t)hip_stream;
   Workspace w = carve(m, B, workspace);
   int chunk, n_chunks;
@@ -707,12 +802,16 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
                      m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D);
   GL_HIP(hipGetLastError());
   const float* extra = nullptr;
-  int use_partial = 1;
-  if ((rc = run_likelihood(m, B, w, chunk, n_chunks, obs, err_or_null, mask_or_null, bg_rms, exp_time,
-                           grad_z_or_null != nullptr, stream, &extra, &use_partial)))
+  int use_partial = 0;
+  if (pix && (rc = run_likelihood(m, B, w, chunk, n_chunks, obs, err_or_null, mask_or_null, bg_rms, exp_time,
+                                  grad_z_or_null != nullptr, stream, &extra, &use_partial)))
     return rc;
+  if (pos && (rc = run_positions(m, w.params, B, w, grad_z_or_null != nullptr, stream))) return rc;
+  // red_chi2 = (red_pix + red_pos) / n_chi  (tf/model.py:150-162)
+  const float n_chi = (pix ? 1.f : 0.f) + (pos ? 1.f : 0.f);
   return run_finalize(m, w.params, B, n_chunks, w, loglike, chi2, nullptr, stream, z, logprob, grad_z_or_null,
-                      1.0f / chi2_divisor, extra, use_partial);
+                      pix ? 1.0f / (chi2_divisor * n_chi) : 0.f, extra, use_partial, pos,
+                      pos ? 1.0f / (2.0f * (float)m->pos_J * n_chi) : 0.f);
 }
 
 int gl_profile_eval(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,

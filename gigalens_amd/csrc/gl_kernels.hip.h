@@ -594,7 +594,9 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
                                                           int d_z, const ZCol* __restrict__ zcols,
                                                           float* __restrict__ logprob, float* __restrict__ grad_z,
                                                           float chi2_scale, const float* __restrict__ extra_stats,
-                                                          int use_partial) {
+                                                          int use_partial, const float* __restrict__ pos_ll,
+                                                          const float* __restrict__ pos_chi2,
+                                                          const float* __restrict__ pos_grad, float pos_chi2_scale) {
   extern __shared__ float s[];  // [A] accumulators, then [P] parameter gradients, then [d_z] prior terms
   float* s_g = s + ((A + 3) & ~3);
   float* s_t = s_g + ((P + 3) & ~3);
@@ -627,6 +629,10 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
       }
     }
     __syncthreads();
+    if (pos_grad) {  // image-position likelihood: its parameter gradient joins before the chain to z
+      for (int k = threadIdx.x; k < P; k += 128) s_g[k] += pos_grad[(size_t)b * P + k];
+      __syncthreads();
+    }
     if (grad)
       for (int k = threadIdx.x; k < P; k += 128) grad[(size_t)b * P + k] = s_g[k];
   }
@@ -641,8 +647,13 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
   }
   if (threadIdx.x == 0 && loglike) {
     float ll = -0.5f * (s[0] + s[1]);  // tf/model.py:99
+    float c2 = s[0] * chi2_scale;
+    if (pos_ll) {  // tf/model.py:157-162
+      ll += pos_ll[b];
+      c2 += pos_chi2[b] * pos_chi2_scale;
+    }
     loglike[b] = ll;
-    chi2[b] = s[0] * chi2_scale;
+    chi2[b] = c2;
     if (zcols && logprob) {
       float lp = 0.f;
       for (int k = 0; k < d_z; ++k) lp += s_t[k];

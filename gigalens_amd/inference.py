@@ -92,7 +92,12 @@ class ModellingSequence:
         self.sim_config = sim_config
 
     def _event_size(self, lens_sim):
-        return float(torch.count_nonzero(lens_sim.img_region))  # tf/inference.py:27-31 (pixel branch)
+        pm, n = self.prob_model, 0.0  # tf/inference.py:27-31
+        if pm.include_pixels:
+            n += float(torch.count_nonzero(lens_sim.img_region))
+        if pm.include_positions:
+            n += pm.n_position
+        return n
 
     def MAP(self, optimizer: Adam, start=None, n_samples=500, num_steps=350, seed=0, progress=None):
         """tf/inference.py:18-45.  ``n_samples`` is the GLOBAL count; each rank optimises its own shard and the

@@ -119,9 +119,9 @@ class _LogProbFn(torch.autograd.Function):
     """autograd glue around gl_logprob_fwd_bwd (bijector + kernels + prior in one native launch sequence)."""
 
     @staticmethod
-    def forward(ctx, z, model, obs, err, mask, bg_rms, exp_time, n_eff):
+    def forward(ctx, z, model, obs, err, mask, bg_rms, exp_time, n_eff, terms):
         want = z.requires_grad
-        lp, ll, chi2, grad = model.logprob(z.detach(), obs, err, mask, bg_rms, exp_time, want, n_eff)
+        lp, ll, chi2, grad = model.logprob(z.detach(), obs, err, mask, bg_rms, exp_time, want, n_eff, terms)
         if want:
             ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(ll, chi2)
@@ -130,7 +130,25 @@ class _LogProbFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_lp, g_ll, g_chi2):
         (grad,) = ctx.saved_tensors
-        return g_lp[:, None] * grad, None, None, None, None, None, None, None
+        return g_lp[:, None] * grad, None, None, None, None, None, None, None, None
+
+
+class _PositionsFn(torch.autograd.Function):
+    """autograd glue around gl_positions_fwd_bwd (image-position likelihood)."""
+
+    @staticmethod
+    def forward(ctx, packed, model):
+        want = packed.requires_grad
+        ll, chi2, grad = model.positions(packed.detach(), want)
+        if want:
+            ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(chi2)
+        return ll, chi2
+
+    @staticmethod
+    def backward(ctx, g_ll, g_chi2):
+        (grad,) = ctx.saved_tensors
+        return g_ll[:, None] * grad, None
 
 
 class _PackBijector:
@@ -163,13 +181,9 @@ class _ChainBijector:
 
 
 class ForwardProbModel(ProbabilisticModel):
-    """Drop-in for ``gigalens.tf.model.ForwardProbModel`` (tf/model.py:12-194), pixel branch.
-
-    The image-position branch (``stats_positions``) is a later row: constructing with
-    ``include_positions=True`` *and* centroids raises ``NotImplementedError``; with the reference's
-    default ``include_positions=True`` and no centroids the reference itself fails (it iterates ``None``,
-    tf/model.py:69-70), so that combination raises ``TypeError`` here too.
-    """
+    """Drop-in for ``gigalens.tf.model.ForwardProbModel`` (tf/model.py:12-194): pixel likelihood and
+    image-position likelihood.  With the reference's default ``include_positions=True`` and no centroids the
+    reference itself fails (it iterates ``None``, tf/model.py:69-70), so that combination raises ``TypeError``."""
 
     def __init__(self, prior, observed_image=None, background_rms=None, exp_time=None, error_map=None,
                  centroids_x=None, centroids_y=None, centroids_errors_x=None, centroids_errors_y=None,
@@ -190,11 +204,17 @@ class ForwardProbModel(ProbabilisticModel):
             else:
                 self.background_rms = float(np.float32(background_rms))
                 self.exp_time = float(np.float32(exp_time))
+        self.centroids_x = self.centroids_y = self.centroids_errors_x = self.centroids_errors_y = None
+        self.n_position = 0.0
         if self.include_positions:
             if centroids_x is None:
                 raise TypeError("include_positions=True needs centroids_x/centroids_y (the reference iterates them, "
                                 "tf/model.py:69-70); pass include_positions=False for a pixel-only model")
-            raise NotImplementedError("image-position likelihood (stats_positions) is not built yet (SURVEY 8f-2)")
+            f32 = lambda L: [np.atleast_1d(np.asarray(v, dtype=np.float32)) for v in L]
+            self.centroids_x, self.centroids_y = f32(centroids_x), f32(centroids_y)
+            self.centroids_errors_x = [np.broadcast_to(e, x.shape).copy() for e, x in zip(f32(centroids_errors_x), self.centroids_x)]
+            self.centroids_errors_y = [np.broadcast_to(e, x.shape).copy() for e, x in zip(f32(centroids_errors_y), self.centroids_y)]
+            self.n_position = 2.0 * float(sum(x.size for x in self.centroids_x))  # tf/model.py:74
         self._flat = prior.flat(self.device)
         example = prior.sample(seed=0)
         self.pack_bij = _PackBijector(example)
@@ -252,7 +272,23 @@ class ForwardProbModel(ProbabilisticModel):
         return model
 
     def _fused_ok(self, simulator):
-        return self.include_pixels and not self.include_positions
+        return self.include_pixels or self.include_positions
+
+    def _bind_positions(self, simulator):
+        model = simulator._model
+        if getattr(model, "_positions_owner", None) is not self:
+            model.set_positions(self.centroids_x, self.centroids_y, self.centroids_errors_x, self.centroids_errors_y)
+            model._positions_owner = self
+        return model
+
+    def _terms(self):
+        return (1 if self.include_pixels else 0) | (2 if self.include_positions else 0)
+
+    def stats_positions(self, simulator, params):
+        """tf/model.py:103-124: ``(log_like, red_chi2)`` of the image-position term."""
+        packed = params if torch.is_tensor(params) else simulator.pack(params)
+        ll, chi2 = _PositionsFn.apply(packed, self._bind_positions(simulator))
+        return ll, chi2 / self.n_position
 
     def _packed_from_x(self, simulator, x):
         cols, consts = self._perm(simulator)
@@ -276,8 +312,11 @@ class ForwardProbModel(ProbabilisticModel):
         if self._fused_ok(simulator):
             # bijector -> prep -> fused render/chi2/VJP -> finalize + prior, all inside the native library
             model = self._bind_prior(simulator)
+            if self.include_positions:
+                self._bind_positions(simulator)
             lp, _, red_chi2 = _LogProbFn.apply(z, model, self.observed_image, self.error_map, self._mask(simulator),
-                                               self.background_rms or 0.0, self.exp_time or 1.0, self._n_eff(simulator))
+                                               self.background_rms or 0.0, self.exp_time or 1.0, self._n_eff(simulator),
+                                               self._terms())
             return lp, red_chi2
         return self.log_prob_unfused(simulator, z)
 
@@ -290,9 +329,11 @@ class ForwardProbModel(ProbabilisticModel):
         z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
         if self._fused_ok(simulator):
             model = self._bind_prior(simulator)
+            if self.include_positions:
+                self._bind_positions(simulator)
             lp, _, red, grad = model.logprob(z.detach(), self.observed_image, self.error_map, self._mask(simulator),
                                              self.background_rms or 0.0, self.exp_time or 1.0, True,
-                                             self._n_eff(simulator))
+                                             self._n_eff(simulator), self._terms())
             return lp, red, grad
         zz = z.detach().requires_grad_(True)
         lp, red = self.log_prob_unfused(simulator, zz)
@@ -313,8 +354,14 @@ class ForwardProbModel(ProbabilisticModel):
         log_like = torch.zeros(z.shape[0], dtype=torch.float32, device=self.device)
         red_chi2 = torch.zeros_like(log_like)
         n_chi = 0
+        packed = self._packed_from_x(simulator, x)
         if self.include_pixels:
-            ll, rc = self._pixel_stats_packed(simulator, self._packed_from_x(simulator, x))
+            ll, rc = self._pixel_stats_packed(simulator, packed)
+            log_like = log_like + ll
+            red_chi2 = red_chi2 + rc
+            n_chi += 1
+        if self.include_positions:
+            ll, rc = self.stats_positions(simulator, packed)
             log_like = log_like + ll
             red_chi2 = red_chi2 + rc
             n_chi += 1
@@ -327,8 +374,11 @@ class ForwardProbModel(ProbabilisticModel):
         z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
         x = self._flat.forward(z)
         ll = torch.zeros(z.shape[0], dtype=torch.float32, device=self.device)
+        packed = self._packed_from_x(simulator, x)
         if self.include_pixels:
-            ll = ll + self._pixel_stats_packed(simulator, self._packed_from_x(simulator, x))[0]
+            ll = ll + self._pixel_stats_packed(simulator, packed)[0]
+        if self.include_positions:
+            ll = ll + self.stats_positions(simulator, packed)[0]
         return ll
 
     def log_prior(self, z):

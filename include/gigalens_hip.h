@@ -140,10 +140,22 @@ int gl_model_set_prior(gl_model* m, const gl_zcolumn* cols, int d, const float* 
 /* z [B,d] -> logprob [B] = loglike + log prior(x) + log|dx/dz|, loglike [B], red_chi2 [B] = chi^2 / chi2_divisor
  * (the caller passes count_nonzero(img_region), tf/model.py:100) and, when grad_z_or_null != NULL,
  * d logprob / d z [B,d] (what tf.GradientTape returns at tf/inference.py:33-39). */
+#define GL_TERM_PIXELS 1u    /* include_pixels    (tf/model.py:152-156) */
+#define GL_TERM_POSITIONS 2u /* include_positions (tf/model.py:157-161), needs gl_model_set_positions */
 int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, const float* err_or_null,
                        const float* mask_or_null, float bg_rms, float exp_time, int B, float* logprob,
-                       float* loglike, float* red_chi2, float* grad_z_or_null, float chi2_divisor, void* workspace,
-                       size_t workspace_bytes, void* hip_stream);
+                       float* loglike, float* red_chi2, float* grad_z_or_null, float chi2_divisor, unsigned terms,
+                       void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Image-position likelihood, ForwardProbModel.stats_positions (tf/model.py:103-124) with LensSimulator.beta and
+ * .magnification (tf/simulator.py:72-91): observed positions of multiply-imaged sources, grouped in families.
+ * x, y, err_x, err_y: concatenation over families (HOST pointers, copied).  loglike [B], chi2 [B] (sum over
+ * families, not reduced: the caller divides by n_position = 2 * total images, tf/model.py:74,123) and the
+ * gradient w.r.t. the packed parameters [B,P] (zero outside the lens columns). */
+int gl_model_set_positions(gl_model* m, int n_families, const int* family_sizes, const float* x, const float* y,
+                           const float* err_x, const float* err_y);
+int gl_positions_fwd_bwd(const gl_model* m, const float* params, int B, float* loglike, float* chi2,
+                         float* grad_params_or_null, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Plugin-level point evaluation, the reference's MassProfile.deriv / LightProfile.light called on
  * arbitrary coordinates (tests/test_profiles.py calls exactly these):

@@ -450,3 +450,48 @@ def stats_pixels(simulator: RefSimulator, params, observed_image, background_rms
     log_like = -1 / 2 * (chi2 + normalization)
     red_chi2 = chi2 / torch.count_nonzero(reg).to(dt)
     return log_like, red_chi2
+
+
+# --------------------------------------------------------------------------
+# image-position likelihood (tf/model.py:103-124, tf/simulator.py:72-91, tf/profile.py:9-43)
+# --------------------------------------------------------------------------
+def lens_hessian_autodiff(simulator: RefSimulator, x, y, lens_params):
+    """Sum over lenses of the autodiff Hessian of ``deriv`` (tf/profile.py:9-27, tf/simulator.py:80-88).
+    The reference overrides it analytically for NFW / Shear / SIS; those closed forms equal the derivative of
+    the deflection away from the clamps, so one autodiff path serves as the oracle for every profile."""
+    x = x.clone().requires_grad_(True)
+    y = y.clone().requires_grad_(True)
+    fxx = fxy = fyx = fyy = 0
+    consts = simulator._consts("lenses_constants", len(simulator.phys_model.lenses))
+    for lens, p, c in zip(simulator.phys_model.lenses, lens_params, consts):
+        fx, fy = mass_deriv(lens, x, y, **p, **c)
+        a, b = torch.autograd.grad(fx.sum(), [x, y], create_graph=True)
+        cc, d = torch.autograd.grad(fy.sum(), [x, y], create_graph=True)
+        fxx, fxy, fyx, fyy = fxx + a, fxy + b, fyx + cc, fyy + d
+    return fxx, fxy, fyx, fyy
+
+
+def stats_positions(simulator: RefSimulator, params, centroids_x, centroids_y, errors_x, errors_y):
+    """tf/model.py:103-124 with centroids batched as (n_img, bs) (init_centroids, :187-194)."""
+    dt = simulator.dtype
+    bs = simulator.bs
+    chi2 = 0.0
+    log_like = 0.0
+    n_position = 0.0
+    for cx, cy, cex, cey in zip(centroids_x, centroids_y, errors_x, errors_y):
+        cx = torch.as_tensor(np.asarray(cx, dtype=np.float32)).to(dt)[:, None].repeat(1, bs)
+        cy = torch.as_tensor(np.asarray(cy, dtype=np.float32)).to(dt)[:, None].repeat(1, bs)
+        cex = torch.as_tensor(np.asarray(cex, dtype=np.float32)).to(dt)
+        cey = torch.as_tensor(np.asarray(cey, dtype=np.float32)).to(dt)
+        n_position += 2.0 * cx.shape[0]
+        bx, by = simulator.beta(cx, cy, params['lens_mass'])
+        beta = torch.stack([bx, by], dim=0).permute(2, 0, 1)  # batch, xy, images
+        bary = beta.mean(dim=2, keepdim=True)
+        fxx, fxy, fyx, fyy = lens_hessian_autodiff(simulator, cx, cy, params['lens_mass'])
+        mag = (1.0 / ((1 - fxx) * (1 - fyy) - fxy * fyx)).permute(1, 0)  # batch, images
+        err = torch.stack([cex / mag, cey / mag], dim=1)  # batch, xy, images
+        chi2_i = (((beta - bary) / err) ** 2).sum(dim=(-2, -1))
+        norm_i = torch.log(2 * np.pi * err ** 2).sum(dim=(-2, -1))
+        log_like = log_like + (-0.5) * (chi2_i + norm_i)
+        chi2 = chi2 + chi2_i
+    return log_like, chi2 / n_position

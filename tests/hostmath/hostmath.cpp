@@ -9,6 +9,7 @@
 
 #include "../../gigalens_amd/csrc/gl_host_tables.h"
 #include "../../gigalens_amd/csrc/gl_profiles.h"
+#include "../../gigalens_amd/csrc/gl_dual.h"
 
 using namespace glp;
 
@@ -83,6 +84,31 @@ void run_light(int kind, int iparam, unsigned flags, const R* p, int n, const R*
 
 }  // namespace
 
+// Nested-dual evaluation used by the image-position kernels (gl_positions.hip.h), on the host in float64:
+// out = [ax, ay, fxx, fxy, fyx, fyy] followed by d(those 6)/d(param k) for k < P  ->  6 * (1 + P) doubles.
+template <int PL> static void lens_jet(int kind, int iparam, const double* p0, double x0, double y0, double* out) {
+  using R1 = gld::Dual<double, PL>;
+  using R = gld::Dual<R1, 2>;
+  R x{R1(x0)}, y{R1(y0)};
+  x.d[0] = R1(1.0);
+  y.d[1] = R1(1.0);
+  R p[PL];
+  for (int k = 0; k < PL; ++k) { R1 v(p0[k]); v.d[k] = 1.0; p[k] = R(v); }
+  R ax, ay;
+  switch (kind) {
+    case K_EPL: epl_point<R>(p, iparam, x, y, ax, ay); break;
+    case K_SIE: { R d[SIE_ND + 1]; sie_prep<R>(p, d); sie_fwd<R>(d, x, y, ax, ay); } break;
+    case K_NFW: { R d[NFW_ND]; nfw_prep<R>(p, d); nfw_fwd<R>(d, x, y, ax, ay); } break;
+    case K_SHEAR: { R d[4]; shear_prep<R>(p, d); shear_fwd<R>(d, x, y, ax, ay); } break;
+    default: { R d[4]; sis_prep<R>(p, d); sis_fwd<R>(d, x, y, ax, ay); } break;
+  }
+  const R1 q[6] = {ax.v, ay.v, ax.d[0], ax.d[1], ay.d[0], ay.d[1]};
+  for (int i = 0; i < 6; ++i) {
+    out[i] = q[i].v;
+    for (int k = 0; k < PL; ++k) out[6 * (1 + k) + i] = q[i].d[k];
+  }
+}
+
 extern "C" {
 void hm_mass_f64(int kind, int iparam, const double* p, int n, const double* x, const double* y, const double* gx,
                  const double* gy, double* ax, double* ay, double* grad) {
@@ -114,4 +140,14 @@ void hm_chi2_f64(int n, const double* m, const double* o, const double* w, int h
   *norm = nm;
 }
 int hm_num_params(int kind, int iparam) { return kind_num_params(kind, iparam); }
+
+void hm_lens_jet_f64(int kind, int iparam, const double* p, double x, double y, double* out) {
+  switch (kind) {
+    case K_EPL: lens_jet<6>(kind, iparam, p, x, y, out); break;
+    case K_SIE: lens_jet<5>(kind, iparam, p, x, y, out); break;
+    case K_NFW: lens_jet<4>(kind, iparam, p, x, y, out); break;
+    case K_SHEAR: lens_jet<2>(kind, iparam, p, x, y, out); break;
+    default: lens_jet<3>(kind, iparam, p, x, y, out); break;
+  }
+}
 }

@@ -191,3 +191,32 @@ def test_mass_f32_host_close_to_f64(hostmath, name, p):
     # (b/sqrt(1-q^2) * atan(sqrt(1-q^2) ...)): the e1/e2 gradients cancel to ~3 digits in ANY fp32 evaluation.
     loose = name == "SIE" and abs(p[1]) < 0.01
     assert np.allclose(grad, ograd, rtol=1e-2 if loose else 2e-4, atol=(1e-3 if loose else 2e-5) * np.abs(ograd).max())
+
+
+@pytest.mark.parametrize("name,p", [("EPL", [1.2, 2.2, -0.1, 0.1, 0.03, -0.02]), ("EPL", [0.9, 1.7, 0.25, 0.3, -0.1, 0.05]),
+                                    ("SIE", [1.2, 0.1, -0.1, 0.02, 0.01]), ("NFW", [1.7, 0.9, 0.1, -0.2]),
+                                    ("NFW", [0.6, 1.4, -0.3, 0.25]), ("SHEAR", [0.05, -0.03]), ("SIS", [1.1, 0.04, -0.06])])
+def test_nested_dual_hessian_and_parameter_jet(hostmath, name, p):
+    """gl_dual.h instantiated on the profile templates (what the image-position kernels run) == torch autograd of the
+    oracle: deflection, Hessian d alpha/d(x,y) (tf/profile.py:9-27) and the parameter derivatives of both."""
+    r = np.random.default_rng(len(p))
+    for _ in range(6):
+        x0, y0 = r.normal(size=2) * 1.2
+        out = np.zeros(6 * (1 + len(p)))
+        hostmath.hm_lens_jet_f64(c_int(K[name]), c_int(60), _dp(np.asarray(p, dtype=np.float64)), c_double(x0), c_double(y0),
+                                 _dp(out))
+        pt = [torch.tensor([v], dtype=torch.float64, requires_grad=True) for v in p]
+        X = torch.tensor([[x0]], dtype=torch.float64, requires_grad=True)
+        Y = torch.tensor([[y0]], dtype=torch.float64, requires_grad=True)
+        fn = dict(EPL=lambda: ref.epl_deriv(X, Y, *pt, niter_cap=60), SIE=lambda: ref.sie_deriv(X, Y, *pt),
+                  NFW=lambda: ref.nfw_deriv(X, Y, *pt), SHEAR=lambda: ref.shear_deriv(X, Y, *pt), SIS=lambda: ref.sis_deriv(X, Y, *pt))[name]
+        fx, fy = fn()
+        fxx, fxy = torch.autograd.grad(fx.sum(), [X, Y], create_graph=True)
+        fyx, fyy = torch.autograd.grad(fy.sum(), [X, Y], create_graph=True)
+        q = [fx.sum(), fy.sum(), fxx.sum(), fxy.sum(), fyx.sum(), fyy.sum()]
+        assert np.allclose(out[:6], [float(v) for v in q], rtol=1e-9, atol=1e-11)
+        for i, v in enumerate(q):
+            g = torch.autograd.grad(v, pt, retain_graph=True, allow_unused=True)
+            want = np.array([0.0 if gi is None else float(gi) for gi in g])
+            got = out[6 + i::6][: len(p)]
+            assert np.allclose(got, want, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(want).max())), (name, i, got, want)
