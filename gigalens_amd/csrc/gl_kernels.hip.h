@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gl_profiles.h"
+#include "gl_vec.hip.h"
 
 namespace glk {
 using namespace glp;
@@ -424,8 +425,17 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
           for (int t = 0; t < T; ++t) { float ax, ay; sie_fwd(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
           break;
         case K_NFW:
+          if constexpr (T % 2 == 0) {  // pixel pairs -> packed fp32
 #pragma unroll
-          for (int t = 0; t < T; ++t) { float ax, ay; nfw_fwd(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+            for (int t = 0; t < T; t += 2) {
+              v2f vbx{bx[t], bx[t + 1]}, vby{by[t], by[t + 1]};
+              nfw_fwd_v<v2f>(d, v2f{x[t], x[t + 1]}, v2f{y[t], y[t + 1]}, vbx, vby);
+              bx[t] = vbx.x; bx[t + 1] = vbx.y; by[t] = vby.x; by[t + 1] = vby.y;
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) { float ax, ay; nfw_fwd(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          }
           break;
         case K_SHEAR:
 #pragma unroll
@@ -449,6 +459,15 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
 #pragma unroll 1
           for (int t = 0; t < T; ++t)
             m[t] += shapelets_fwd<float, SH_CAP>(d, a.shp_tab, a.shp_stride, interp, src ? bx[t] : x[t], src ? by[t] : y[t]);
+        }
+      } else if constexpr (T % 2 == 0) {
+#pragma unroll
+        for (int t = 0; t < T; t += 2) {
+          SerStateV<v2f> stv;
+          v2f I = sersic_fwd_v<v2f>(d, src ? v2f{bx[t], bx[t + 1]} : v2f{x[t], x[t + 1]},
+                                    src ? v2f{by[t], by[t + 1]} : v2f{y[t], y[t + 1]}, stv);
+          m[t] += I.x;
+          m[t + 1] += I.y;
         }
       } else {
 #pragma unroll
@@ -513,13 +532,31 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
           }
         } else {
           float acc[SER_NACC];
+          if constexpr (T % 2 == 0) {
+            v2f va[SER_NACC];
 #pragma unroll
-          for (int k = 0; k < SER_NACC; ++k) acc[k] = 0.f;
+            for (int k = 0; k < SER_NACC; ++k) va[k] = v2f(0.f);
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            float dgx = 0.f, dgy = 0.f;
-            sersic_vjp(d, src ? bx[t] : x[t], src ? by[t] : y[t], gm[t], acc, dgx, dgy);
-            if (src) { gbx[t] += dgx; gby[t] += dgy; }
+            for (int t = 0; t < T; t += 2) {
+              SerStateV<v2f> stv;
+              (void)sersic_fwd_v<v2f>(d, src ? v2f{bx[t], bx[t + 1]} : v2f{x[t], x[t + 1]},
+                                      src ? v2f{by[t], by[t + 1]} : v2f{y[t], y[t + 1]}, stv);
+              v2f dgx(0.f), dgy(0.f);
+              sersic_vjp_v<v2f, true>(d, stv, v2f{gm[t], gm[t + 1]}, va, dgx, dgy);
+              if (src) { gbx[t] += dgx.x; gbx[t + 1] += dgx.y; gby[t] += dgy.x; gby[t + 1] += dgy.y; }
+            }
+#pragma unroll
+            for (int k = 0; k < SER_NACC; ++k) acc[k] = va[k].x + va[k].y;
+            acc[SERA_INVN] *= (float)kLn2;  // sersic_vjp_v defers this factor
+          } else {
+#pragma unroll
+            for (int k = 0; k < SER_NACC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              float dgx = 0.f, dgy = 0.f;
+              sersic_vjp(d, src ? bx[t] : x[t], src ? by[t] : y[t], gm[t], acc, dgx, dgy);
+              if (src) { gbx[t] += dgx; gby[t] += dgy; }
+            }
           }
           wave_acc<SER_NACC>(acc, ac, cd.a_off);
         }
@@ -548,10 +585,21 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
           } break;
           case K_NFW: {
             float acc[NFW_NACC];
+            if constexpr (T % 2 == 0) {
+              v2f va[NFW_NACC];
 #pragma unroll
-            for (int k = 0; k < NFW_NACC; ++k) acc[k] = 0.f;
+              for (int k = 0; k < NFW_NACC; ++k) va[k] = v2f(0.f);
 #pragma unroll
-            for (int t = 0; t < T; ++t) nfw_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
+              for (int t = 0; t < T; t += 2)
+                nfw_vjp_v<v2f>(d, v2f{x[t], x[t + 1]}, v2f{y[t], y[t + 1]}, v2f{gbx[t], gbx[t + 1]}, v2f{gby[t], gby[t + 1]}, va);
+#pragma unroll
+              for (int k = 0; k < NFW_NACC; ++k) acc[k] = va[k].x + va[k].y;
+            } else {
+#pragma unroll
+              for (int k = 0; k < NFW_NACC; ++k) acc[k] = 0.f;
+#pragma unroll
+              for (int t = 0; t < T; ++t) nfw_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
+            }
             wave_acc<NFW_NACC>(acc, ac, cd.a_off);
           } break;
           case K_SHEAR: {

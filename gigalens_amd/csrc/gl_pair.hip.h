@@ -11,237 +11,9 @@
 // per lane.  Supported components: EPL, SIE, SHEAR, SIS lenses; SERSIC / SERSIC_ELLIPSE lights.
 #pragma once
 #include "gl_static.hip.h"
+#include "gl_vec.hip.h"
 
 namespace glk {
-
-// bring the scalar wrappers into this scope so that they overload with the pair versions below
-using glm::rcp;
-using glm::sqrt_;
-using glm::exp2_;
-using glm::log2_;
-using glm::atan_;
-using glm::atanh_;
-
-// ---- per-lane transcendentals on pairs -----------------------------------------------------------
-__device__ __forceinline__ v2f rcp(v2f a) { return v2f{glm::rcp(a.x), glm::rcp(a.y)}; }
-__device__ __forceinline__ v2f sqrt_(v2f a) { return v2f{glm::sqrt_(a.x), glm::sqrt_(a.y)}; }
-__device__ __forceinline__ float rsq_(float a) { return __builtin_amdgcn_rsqf(a); }
-__device__ __forceinline__ v2f rsq_(v2f a) { return v2f{__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)}; }
-__device__ __forceinline__ v2f exp2_(v2f a) { return v2f{glm::exp2_(a.x), glm::exp2_(a.y)}; }
-__device__ __forceinline__ v2f log2_(v2f a) { return v2f{glm::log2_(a.x), glm::log2_(a.y)}; }
-__device__ __forceinline__ v2f atan_(v2f a) { return v2f{glm::atan_(a.x), glm::atan_(a.y)}; }
-__device__ __forceinline__ v2f atanh_(v2f a) { return v2f{glm::atanh_(a.x), glm::atanh_(a.y)}; }
-template <class V> __device__ __forceinline__ V vexp(V x) {  // exp with the product rounding folded back in
-  const float hi = (float)kLog2e;
-  const float lo = (float)(kLog2e - (double)(float)kLog2e);
-  V t = x * hi;
-  V e = __builtin_elementwise_fma(x, V(hi), -t) + x * lo;
-  V p = exp2_(t);
-  return __builtin_elementwise_fma(p, e * (float)kLn2, p);
-}
-template <> __device__ __forceinline__ float vexp<float>(float x) { return glm::exp_(x); }
-template <class V> __device__ __forceinline__ V vlog(V x) { return log2_(x) * (float)kLn2; }
-template <class V> __device__ __forceinline__ V vmin(V a, V b) { return a < b ? a : b; }
-template <class V> __device__ __forceinline__ V vmax(V a, V b) { return a > b ? a : b; }
-__device__ __forceinline__ float hsum(float a) { return a; }
-__device__ __forceinline__ float hsum(v2f a) { return a.x + a.y; }
-
-// ---- EPL ------------------------------------------------------------------------------------------------
-template <class V> struct EplStateV {
-  V xr, yr, inv, invc, L2, P, Ox, Oy, Sx, Sy, Fx, Fy, Tx, Ty;
-};
-
-template <class V, bool GRAD>
-__device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restrict__ gd, V x, V y, V& bx, V& by,
-                                          EplStateV<V>& st) {
-  const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
-  V dx = x - d[EPL_CX], dy = y - d[EPL_CY];
-  st.xr = dx * c + dy * s;
-  st.yr = dy * c - dx * s;
-  V X = st.xr * q;
-  V r2 = X * X + st.yr * st.yr;
-  // one transcendental instead of sqrt + 2 rcp: r = 1/R0 (inf at R0 = 0), and 1/clip(R0, 1e-10, 1e10) is the
-  // clip of 1/R0 to [1e-10, 1e10] (epl.py:31); R0 itself is only needed through 1/R0
-  V r = rsq_(r2);
-  auto pos = r2 > V(0.f);
-  st.inv = pos ? r : V(0.f);
-  V Cs = pos ? X * r : V(1.f);
-  V Ss = st.yr * st.inv;
-  V iRc = vmin(vmax(r, V(1e-10f)), V(1e10f));
-  st.invc = (iRc == r) ? r : V(0.f);  // clip_by_value passes gradient only inside the clamp
-  V E2x = Cs * Cs - Ss * Ss, E2y = (Cs + Cs) * Ss;
-  V Ex = Cs, Ey = Ss;
-  st.Ox = Cs; st.Oy = Ss;
-  if (GRAD) {
-    st.Sx = Cs; st.Sy = Ss;
-    st.Fx = V(0.f); st.Fy = V(0.f); st.Tx = V(0.f); st.Ty = V(0.f);
-  }
-  // scalar-loaded trip count and coefficients (wave-uniform address): SGPR operands, scalar loop control
-  const int K = reinterpret_cast<const int*>(gd)[EPL_KI];
-  const float4* __restrict__ gtab = reinterpret_cast<const float4*>(gd + EPL_TAB);
-  auto step = [&](const float4 cc) {
-    V tx = E2x * Ex - E2y * Ey;
-    Ey = E2y * Ex + E2x * Ey;
-    Ex = tx;
-    st.Ox += cc.x * Ex; st.Oy += cc.x * Ey;
-    if (GRAD) {
-      st.Sx += cc.y * Ex; st.Sy += cc.y * Ey;
-      st.Fx += cc.z * Ex; st.Fy += cc.z * Ey;
-      st.Tx += cc.w * Ex; st.Ty += cc.w * Ey;
-    }
-  };
-  int n = 1;
-#if defined(GL_EXP_NOTABLE)  // timing experiment only: coefficients hoisted out of the loop (wrong numbers)
-  const float4 c1 = gtab[1], c2 = gtab[2];
-  for (; n + 1 <= K; n += 2) { step(c1); step(c2); }
-  if (n <= K) step(c1);
-#else
-  for (; n + 1 <= K; n += 2) {
-    const float4 ca = gtab[n], cb = gtab[n + 1];
-    step(ca);
-    step(cb);
-  }
-  if (n <= K) step(gtab[n]);
-#endif
-  st.L2 = log2_(iRc * d[EPL_B]);
-  st.P = exp2_(st.L2 * d[EPL_TM1]) * d[EPL_P0];  // 2b/(1+q) (b/R)^(t-1), epl.py:55
-  V arx = st.P * st.Ox, ary = st.P * st.Oy;
-  bx -= arx * c - ary * s;
-  by -= arx * s + ary * c;
-}
-
-template <class V>
-__device__ __forceinline__ void epl_vjp_v(const float* d, V gx, V gy, const EplStateV<V>& st, V* acc) {
-  const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q], tm1 = d[EPL_TM1];
-  V P = st.P;
-  V arx = P * st.Ox, ary = P * st.Oy;
-  V ax = arx * c - ary * s, ay = arx * s + ary * c;
-  V grx = gx * c + gy * s, gry = gy * c - gx * s;
-  V g_phi = gy * ax - gx * ay;
-  V gP = grx * st.Ox + gry * st.Oy;
-  V gOx = P * grx, gOy = P * gry;
-  V g_ang = gOy * st.Sx - gOx * st.Sy;
-  V g_t = gOx * st.Tx + gOy * st.Ty;
-  V g_f = gOx * st.Fx + gOy * st.Fy;
-  V gW_W = gP * P;
-  g_t += gW_W * (st.L2 * (float)kLn2);
-  V gWt = gW_W * tm1;
-  V gR0 = -(gWt * st.invc);
-  V Cs = st.xr * q * st.inv, Ss = st.yr * st.inv;  // (R0 == 0: inv = 0, and g_ang * inv = 0 as in the scalar code)
-  V gai = g_ang * st.inv;
-  V gX = gR0 * Cs - gai * Ss;
-  V gyr = gR0 * Ss + gai * Cs;
-  V gxr = gX * q;
-  g_phi += gxr * st.yr - gyr * st.xr;
-  acc[EPLA_CX] -= gxr * c - gyr * s;
-  acc[EPLA_CY] -= gxr * s + gyr * c;
-  acc[EPLA_PHI] += g_phi;
-  acc[EPLA_Q] += gX * st.xr;
-  acc[EPLA_B] += gWt;     // x 1/b in the epilogue
-  acc[EPLA_T] += g_t;
-  acc[EPLA_F] += g_f;
-  acc[EPLA_P0] += gW_W;   // x 1/P0 in the epilogue (gP * W = gP * P / P0)
-}
-
-// ---- SIE / SHEAR / SIS (stateless: cheap to re-evaluate) ----------------------------------------------
-template <class V> __device__ __forceinline__ void sie_fwd_v(const float* d, V x, V y, V& bx, V& by) {
-  const float c = d[SIE_C], s = d[SIE_S], q = d[SIE_Q], sq = d[SIE_SQ], A = d[SIE_A];
-  V dx = x - d[SIE_CX], dy = y - d[SIE_CY];
-  V xr = dx * c + dy * s, yr = dy * c - dx * s;
-  V ipsi = rcp(sqrt_(xr * xr * (q * q) + yr * yr));
-  V arx = atan_(xr * ipsi * sq) * A, ary = atanh_(yr * ipsi * sq) * A;
-  bx -= arx * c - ary * s;
-  by -= arx * s + ary * c;
-}
-template <class V> __device__ __forceinline__ void sie_vjp_v(const float* d, V x, V y, V gx, V gy, V* acc) {
-  const float c = d[SIE_C], s = d[SIE_S], q = d[SIE_Q], sq = d[SIE_SQ], A = d[SIE_A];
-  V dx = x - d[SIE_CX], dy = y - d[SIE_CY];
-  V xr = dx * c + dy * s, yr = dy * c - dx * s;
-  V ipsi = rcp(sqrt_(xr * xr * (q * q) + yr * yr));
-  V u = xr * ipsi * sq, v = yr * ipsi * sq;
-  V fu = atan_(u), fv = atanh_(v);
-  V arx = fu * A, ary = fv * A;
-  V ax = arx * c - ary * s, ay = arx * s + ary * c;
-  V grx = gx * c + gy * s, gry = gy * c - gx * s;
-  V g_phi = gy * ax - gx * ay;
-  V gu = grx * A * rcp(V(1.f) + u * u);
-  V gv = gry * A * rcp(V(1.f) - v * v);
-  V gpsi = -(gu * u + gv * v) * ipsi;
-  V gxr = gu * ipsi * sq + gpsi * xr * ipsi * (q * q);
-  V gyr = gv * ipsi * sq + gpsi * yr * ipsi;
-  g_phi += gxr * yr - gyr * xr;
-  acc[SIEA_CX] -= gxr * c - gyr * s;
-  acc[SIEA_CY] -= gxr * s + gyr * c;
-  acc[SIEA_PHI] += g_phi;
-  acc[SIEA_Q] += gpsi * xr * xr * ipsi * q;
-  acc[SIEA_SQ] += (gu * xr + gv * yr) * ipsi;
-  acc[SIEA_A] += grx * fu + gry * fv;
-}
-template <class V> __device__ __forceinline__ void shear_fwd_v(const float* d, V x, V y, V& bx, V& by) {
-  bx -= x * d[SHR_G1] + y * d[SHR_G2];
-  by -= x * d[SHR_G2] - y * d[SHR_G1];
-}
-template <class V> __device__ __forceinline__ void shear_vjp_v(V x, V y, V gx, V gy, V* acc) {
-  acc[0] += gx * x - gy * y;
-  acc[1] += gx * y + gy * x;
-}
-template <class V> __device__ __forceinline__ void sis_fwd_v(const float* d, V x, V y, V& bx, V& by) {
-  V dx = x - d[SIS_CX], dy = y - d[SIS_CY];
-  V R0 = sqrt_(dx * dx + dy * dy);
-  V a = (R0 == V(0.f)) ? V(0.f) : rcp(R0) * d[SIS_TE];
-  bx -= a * dx;
-  by -= a * dy;
-}
-template <class V> __device__ __forceinline__ void sis_vjp_v(const float* d, V x, V y, V gx, V gy, V* acc) {
-  V dx = x - d[SIS_CX], dy = y - d[SIS_CY];
-  V R0 = sqrt_(dx * dx + dy * dy);
-  V iR = (R0 == V(0.f)) ? V(0.f) : rcp(R0);
-  V a = iR * d[SIS_TE];
-  V ga = gx * dx + gy * dy;
-  V gR0 = -(ga * a * iR);
-  acc[0] -= gx * a + gR0 * dx * iR;
-  acc[1] -= gy * a + gR0 * dy * iR;
-  acc[2] += ga * iR;
-}
-
-// ---- SERSIC ---------------------------------------------------------------------------------------------
-template <class V> struct SerStateV { V a1, a2, r2, L2, u, E; };
-
-template <class V> __device__ __forceinline__ V sersic_fwd_v(const float* d, V x, V y, SerStateV<V>& st) {
-  const float c = d[SER_C], s = d[SER_S];
-  V dx = x - d[SER_CX], dy = y - d[SER_CY];
-  st.a1 = dx * c + dy * s;
-  st.a2 = dy * c - dx * s;
-  V xt1 = st.a1 * d[SER_SQ], xt2 = st.a2 * d[SER_ISQ];
-  st.r2 = xt1 * xt1 + xt2 * xt2;
-  st.L2 = log2_(st.r2) * 0.5f + d[SER_L2IRS];  // log2(R / R_sersic) without the square root
-  st.u = exp2_(st.L2 * d[SER_INVN]);
-  st.E = vexp<V>((st.u - 1.f) * -d[SER_BN]);
-  return st.E * d[SER_IE];
-}
-template <class V, bool SRC>
-__device__ __forceinline__ void sersic_vjp_v(const float* d, const SerStateV<V>& st, V gI, V* acc, V& gpx, V& gpy) {
-  const float c = d[SER_C], s = d[SER_S], sq = d[SER_SQ], isq = d[SER_ISQ];
-  V xt1 = st.a1 * sq, xt2 = st.a2 * isq;
-  auto pos = st.r2 > V(0.f);
-  V gE = gI * st.E;
-  V tI = gE * d[SER_IE];
-  V guu = -(tI * st.u) * d[SER_BN];
-  V gL = guu * d[SER_INVN];
-  V k = pos ? gL * rcp(st.r2) : V(0.f);
-  V gxt1 = k * xt1, gxt2 = k * xt2;
-  V ga1 = gxt1 * sq, ga2 = gxt2 * isq;
-  V gdx = ga1 * c - ga2 * s, gdy = ga1 * s + ga2 * c;
-  acc[SERA_CX] -= gdx;
-  acc[SERA_CY] -= gdy;
-  acc[SERA_PHI] += ga1 * st.a2 - ga2 * st.a1;
-  acc[SERA_SQ] += gxt1 * st.a1 - gxt2 * st.a2 * (isq * isq);
-  acc[SERA_L] += gL;
-  acc[SERA_INVN] += pos ? guu * st.L2 : V(0.f);  // x ln2 in the epilogue
-  acc[SERA_BN] -= tI * (st.u - 1.f);
-  acc[SERA_IE] += gE;
-  if (SRC) { gpx += gdx; gpy += gdy; }
-}
 
 // ---- the pair kernel ----------------------------------------------------------------------------------------
 // V = v2f: each thread owns pixels (j, j + 256) of every 512-pixel tile; V = float: one pixel per thread.

@@ -13,7 +13,7 @@
 #pragma once
 #include <utility>
 
-#include "gl_kernels.hip.h"
+#include "gl_kernels.hip.h"  // (brings gl_vec.hip.h: v2f and the V-generic profile maths)
 
 namespace glk {
 
@@ -42,8 +42,6 @@ template <int T> struct EplState {
 // `gtab` is the same coefficient table in GLOBAL memory (this sample's row of the derived buffer): its
 // address is wave-uniform, so the compiler reads it with scalar loads (s_load_dwordx4 -> SGPR operands) and
 // the series loop issues no LDS/vector-memory instruction at all.
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 template <int T, bool GRAD>
 __device__ __forceinline__ void epl_fwd_state(const float* d, const float* __restrict__ gd, const float (&x)[T],
                                               const float (&y)[T], float (&bx)[T], float (&by)[T], EplState<T>& st) {
