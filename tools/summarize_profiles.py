@@ -32,7 +32,7 @@ def stats_table(d, out, top=12):
     return rows
 
 
-def pmc(d, kernel_filter=("gl_static_kernel<3", "gl_main_kernel<3")):
+def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_kernel<3")):
     f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
     if not f:
         return {}
@@ -71,5 +71,8 @@ if os.path.exists(bj):
     line = [l for l in open(bj) if l.startswith("{")]
     if line:
         summary["bench"] = json.loads(line[-1])
+cfg = os.path.join(src, "bench_configs.jsonl")
+if os.path.exists(cfg):
+    summary["configs"] = [json.loads(l) for l in open(cfg) if l.startswith("{")]
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in summary.items() if k != "bench"}, indent=1))
+print(json.dumps({k: v for k, v in summary.items() if k not in ("bench", "configs")}, indent=1))
