@@ -23,6 +23,8 @@ using namespace glm;
 
 enum Kind : int {
   K_EPL = 1, K_SIE = 2, K_NFW = 3, K_SHEAR = 4, K_SIS = 5,
+  K_DPIS = 6, K_DPIE = 7, K_DPIEP = 8,  // gl_dpie.h
+  K_SCALED = 9,                         // ScalingRelation over a galaxy catalogue (gl_dpie.h); iparam = catalogue slot
   K_SERSIC = 16, K_SERSIC_ELLIPSE = 17, K_SHAPELETS = 18
 };
 
@@ -64,6 +66,9 @@ GL_HD int kind_num_params(int kind, int iparam) {
     case K_NFW: return 4;
     case K_SHEAR: return 2;
     case K_SIS: return 3;
+    case K_DPIS: return 5;
+    case K_DPIE:
+    case K_DPIEP: return 7;
     case K_SERSIC: return 5;
     case K_SERSIC_ELLIPSE: return 7;
     case K_SHAPELETS: return 3 + sh_layers(iparam);
@@ -77,6 +82,10 @@ GL_HD int kind_num_derived(int kind, int iparam) {
     case K_NFW: return NFW_ND;
     case K_SHEAR: return SHR_ND + 2;
     case K_SIS: return SIS_ND + 1;
+    case K_DPIS:
+    case K_DPIE:
+    case K_DPIEP: return 32;  // DPX_ND
+    case K_SCALED: return 4;  // the member blocks live in the catalogue workspace, not in the sample's LDS block
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_ND + 2;
     case K_SHAPELETS: return SHP_AMP + ((sh_layers(iparam) + 3) & ~3);
@@ -90,6 +99,10 @@ GL_HD int kind_num_acc(int kind, int iparam) {
     case K_NFW: return NFW_NACC;
     case K_SHEAR: return SHR_NACC;
     case K_SIS: return SIS_NACC;
+    case K_DPIS:
+    case K_DPIE:
+    case K_DPIEP: return 7;  // DP_NACC
+    case K_SCALED: return 3;
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_NACC;
     case K_SHAPELETS: return SHPA_AMP + sh_layers(iparam);
@@ -130,6 +143,20 @@ template <class R> GL_HD R einstein_b(R theta_E, R q) {
   R conv = theta_E / p_sqrt(((R)1 + q * q) / ((R)2 * q));
   return conv * p_sqrt(((R)1 + q * q) / (R)2);
 }
+// chain (g_c, g_phi) -> (g_e1, g_e2), c = min(|e|, cmax), phi = atan2(e2, e1)/2
+template <class R> GL_HD void ellip_chain_c(R e1, R e2, R cmax, R g_c, R g_phi, R& g_e1, R& g_e2) {
+  R ee = p_sqrt(e1 * e1 + e2 * e2);
+  R g_ee = (ee <= cmax) ? g_c : (R)0;
+  if (ee > (R)0) {
+    R ie = (R)1 / ee;
+    R h = (R)0.5 * ie * ie;
+    g_e1 = g_ee * e1 * ie - g_phi * e2 * h;
+    g_e2 = g_ee * e2 * ie + g_phi * e1 * h;
+  } else {
+    g_e1 = (R)0;
+    g_e2 = (R)0;
+  }
+}
 // chain (g_b, g_q, g_phi) -> (g_theta_E, g_e1, g_e2)
 template <class R>
 GL_HD void ellip_chain(R theta_E, R e1, R e2, R cmax, R g_b, R g_q, R g_phi, R& g_te, R& g_e1, R& g_e2) {
@@ -139,16 +166,7 @@ GL_HD void ellip_chain(R theta_E, R e1, R e2, R cmax, R g_b, R g_q, R g_phi, R& 
   if (sq > (R)0) g_q += g_b * theta_E / ((R)2 * sq);
   R opc = (R)1 + el.c;
   R g_c = g_q * ((R)-2 / (opc * opc));
-  R g_ee = (el.ee <= cmax) ? g_c : (R)0;
-  if (el.ee > (R)0) {
-    R ie = (R)1 / el.ee;
-    R h = (R)0.5 * ie * ie;
-    g_e1 = g_ee * e1 * ie - g_phi * e2 * h;
-    g_e2 = g_ee * e2 * ie + g_phi * e1 * h;
-  } else {
-    g_e1 = (R)0;
-    g_e2 = (R)0;
-  }
+  ellip_chain_c(e1, e2, cmax, g_c, g_phi, g_e1, g_e2);
 }
 
 // =============================================================================================

@@ -14,6 +14,8 @@ functions, through code paths that share nothing with ``ref_torch.py``):
 * NFW   -- alpha_r(R) = (2/R) int_0^R kappa(r) r dr with the NFW convergence
            (Bartelmann 1996), integrated numerically.
 * Shapelets -- Refregier 2003: phi_n via scipy's physicists' Hermite polynomials.
+* dPIS  -- Eliasdottir et al. 2007, appendix A: projected surface density of the dual pseudo-isothermal
+           sphere, deflection by numerical quadrature of it (alpha_r = (2/R) int kappa r dr).
 * Sersic -- the reference's single executable known-answer test.
 """
 import math
@@ -79,6 +81,23 @@ def nfw_alpha_r_numeric(R, Rs, alpha_Rs):
     pts = [Rs] if R > Rs else None
     val, _ = integrate.quad(lambda r: nfw_kappa(r, Rs, alpha_Rs) * r, 0.0, R, points=pts, epsabs=1e-13, epsrel=1e-12, limit=200)
     return 2.0 * val / R
+
+
+def dpis_kappa(r, theta_E, r_core, r_cut):
+    """Eliasdottir et al. (2007) appendix A:  Sigma(R) = Sigma_0 a s/(s-a) [1/sqrt(a^2+R^2) - 1/sqrt(s^2+R^2)];
+    in the reference's normalisation the central convergence is theta_E/(2 a) (piemd.py:11-12)."""
+    a, s = r_core, r_cut
+    return theta_E / (2 * a) * a * s / (s - a) * (1 / math.sqrt(a * a + r * r) - 1 / math.sqrt(s * s + r * r))
+
+
+def dpis_deriv(x, y, theta_E, r_core, r_cut, center_x=0.0, center_y=0.0):
+    """alpha_r(R) = (2/R) int_0^R kappa(r) r dr, integrated numerically (independent of the closed form A20)."""
+    x = np.asarray(x, dtype=np.float64) - center_x
+    y = np.asarray(y, dtype=np.float64) - center_y
+    R = np.hypot(x, y)
+    ar = np.array([2.0 / r * integrate.quad(lambda u: dpis_kappa(u, theta_E, r_core, r_cut) * u, 0.0, r,
+                                            epsabs=1e-14, epsrel=1e-13, limit=200)[0] for r in R.ravel()]).reshape(R.shape)
+    return ar * x / R, ar * y / R
 
 
 def shapelet_phi_n(n, x):

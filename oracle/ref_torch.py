@@ -194,6 +194,226 @@ def sis_deriv(x, y, theta_E, center_x, center_y):
 
 
 # --------------------------------------------------------------------------
+# dPIE family (tf/profiles/mass/piemd.py, piep.py) and ScalingRelation (scaling_relation.py)
+# --------------------------------------------------------------------------
+DPIE_R_MIN = 0.0001  # piemd.py:28,100
+
+
+def _sort_ra_rs(r_core, r_cut):
+    """piemd.py:52-60 / :191-199, statement by statement (note: after the first line r_core <= r_cut, so the
+    second ``where`` never fires -- kept as written)."""
+    r_core = torch.where(r_core < r_cut, r_core, r_cut)
+    r_cut = torch.where(r_core > r_cut, r_core, r_cut)
+    r_core = torch.clamp(r_core, min=DPIE_R_MIN)
+    r_cut = torch.where(r_cut > r_core + DPIE_R_MIN, r_cut, r_cut + DPIE_R_MIN)
+    return r_core, r_cut
+
+
+def dpis_deriv(x, y, theta_E, r_core, r_cut, center_x, center_y):
+    """piemd.py:33-49."""
+    theta_E, r_core, r_cut, center_x, center_y = (_t(v, x) for v in (theta_E, r_core, r_cut, center_x, center_y))
+    r_core, r_cut = _sort_ra_rs(r_core, r_cut)
+    x, y = x - center_x, y - center_y
+    r2 = x ** 2 + y ** 2
+    scale = theta_E * r_cut / (r_cut - r_core)
+    f_a20 = torch.sqrt(r2 + r_core ** 2) - r_core - torch.sqrt(r2 + r_cut ** 2) + r_cut
+    alpha_r = scale / r2 * f_a20
+    return alpha_r * x, alpha_r * y
+
+
+def dpis_convergence(x, y, theta_E, r_core, r_cut, center_x=0, center_y=0):
+    """piemd.py:85-94 (carries a factor (r_core + r_cut)/r_cut that the deflection does not have -- as written)."""
+    theta_E, r_core, r_cut, center_x, center_y = (_t(v, x) for v in (theta_E, r_core, r_cut, center_x, center_y))
+    r_core, r_cut = _sort_ra_rs(r_core, r_cut)
+    x, y = x - center_x, y - center_y
+    r = torch.clamp(torch.sqrt(x ** 2 + y ** 2), min=DPIE_R_MIN)
+    scale = theta_E * r_cut / (r_cut - r_core)
+    return scale / 2 * (r_core + r_cut) / r_cut * (
+        1 / torch.sqrt(r_core ** 2 + r ** 2) - 1 / torch.sqrt(r_cut ** 2 + r ** 2))
+
+
+def dpis_hessian(x, y, theta_E, r_core, r_cut, center_x, center_y):
+    """piemd.py:62-83."""
+    theta_E, r_core, r_cut, center_x, center_y = (_t(v, x) for v in (theta_E, r_core, r_cut, center_x, center_y))
+    r_core, r_cut = _sort_ra_rs(r_core, r_cut)
+    x, y = x - center_x, y - center_y
+    r = torch.clamp(torch.sqrt(x ** 2 + y ** 2), min=DPIE_R_MIN)
+    scale = theta_E * r_cut / (r_cut - r_core)
+    gamma = scale / 2 * (
+        2 * (1. / (r_core + torch.sqrt(r_core ** 2 + r ** 2)) - 1. / (r_cut + torch.sqrt(r_cut ** 2 + r ** 2)))
+        - (1 / torch.sqrt(r_core ** 2 + r ** 2) - 1 / torch.sqrt(r_cut ** 2 + r ** 2)))
+    kappa = scale / 2 * (r_core + r_cut) / r_cut * (
+        1 / torch.sqrt(r_core ** 2 + r ** 2) - 1 / torch.sqrt(r_cut ** 2 + r ** 2))
+    sin_imphi = -2 * x * y / r ** 2
+    cos_imphi = (y ** 2 - x ** 2) / r ** 2
+    gamma1 = cos_imphi * gamma
+    gamma2 = sin_imphi * gamma
+    return kappa + gamma1, gamma2, gamma2, kappa - gamma1
+
+
+def _dpie_param_conv(e1, e2):
+    """piemd.py:183-188."""
+    phi = torch.atan2(e2, e1) / 2
+    e = torch.clamp(torch.sqrt(e1 ** 2 + e2 ** 2), max=0.9999)
+    q = (1 - e) / (1 + e)
+    return e, q, phi
+
+
+def _dpie_complex_deriv_dual(x, y, r_core, r_cut, e, q):
+    """piemd.py:201-255 (Kassiola & Kovner 1993 eq. 4.1.2 for the two radii, ratio taken before the log)."""
+    sqe = torch.sqrt(e)
+    rem2 = x ** 2 / (1. + e) ** 2 + y ** 2 / (1. - e) ** 2
+    zci_re = 0
+    zci_im = -0.5 * (1. - e ** 2) / sqe
+    znum_rc_re = q * x
+    znum_rc_im = 2. * sqe * torch.sqrt(r_core ** 2 + rem2) - y / q
+    zden_rc_re = x
+    zden_rc_im = 2. * r_core * sqe - y
+    znum_rcut_im = 2. * sqe * torch.sqrt(r_cut ** 2 + rem2) - y / q
+    zden_rcut_im = 2. * r_cut * sqe - y
+    aa = (znum_rc_re * zden_rc_re - znum_rc_im * zden_rcut_im)
+    bb = (znum_rc_re * zden_rcut_im + znum_rc_im * zden_rc_re)
+    cc = (znum_rc_re * zden_rc_re - zden_rc_im * znum_rcut_im)
+    dd = (znum_rc_re * zden_rc_im + zden_rc_re * znum_rcut_im)
+    norm = (cc ** 2 + dd ** 2)
+    aaa = (aa * cc + bb * dd) / norm
+    bbb = (bb * cc - aa * dd) / norm
+    norm2 = aaa ** 2 + bbb ** 2
+    zr_re = torch.log(torch.sqrt(norm2))
+    zr_im = torch.atan2(bbb, aaa)
+    zres_re = zci_re * zr_re - zci_im * zr_im
+    zres_im = zci_im * zr_re + zci_re * zr_im
+    return zres_re, zres_im
+
+
+def dpie_deriv(x, y, theta_E, r_core, r_cut, e1, e2, center_x=0, center_y=0):
+    """piemd.py:105-119."""
+    theta_E, r_core, r_cut, e1, e2, center_x, center_y = (
+        _t(v, x) for v in (theta_E, r_core, r_cut, e1, e2, center_x, center_y))
+    e, q, phi = _dpie_param_conv(e1, e2)
+    x, y = x - center_x, y - center_y
+    x, y = _rotate(x, y, phi)
+    r_core, r_cut = _sort_ra_rs(r_core, r_cut)
+    scale = theta_E * r_cut / (r_cut - r_core)
+    ax, ay = _dpie_complex_deriv_dual(x, y, r_core, r_cut, e, q)
+    ax, ay = _rotate(ax, ay, -phi)
+    return scale * ax, scale * ay
+
+
+def _dpie_complex_hessian_single(x, y, r_w, e, q):
+    """piemd.py:257-300."""
+    sqe = torch.sqrt(e)
+    qinv = 1. / q
+    cxro = (1. + e) * (1. + e)
+    cyro = (1. - e) * (1. - e)
+    ci = 0.5 * (1. - e ** 2) / sqe
+    wrem = torch.sqrt(r_w ** 2 + x ** 2 / cxro + y ** 2 / cyro)
+    den1 = 2. * sqe * wrem - y * qinv
+    den1 = q ** 2 * x ** 2 + den1 ** 2
+    num2 = 2. * r_w * sqe - y
+    den2 = x ** 2 + num2 ** 2
+    didxre = ci * (q * (2. * sqe * x ** 2 / cxro / wrem - 2. * sqe * wrem + y * qinv) / den1 + num2 / den2)
+    didyre = ci * ((2 * sqe * x * y * q / cyro / wrem - x) / den1 + x / den2)
+    didyim = ci * ((2 * sqe * wrem * qinv - y * qinv ** 2 - 4 * e * y / cyro
+                    + 2 * sqe * y ** 2 / cyro / wrem * qinv) / den1 - num2 / den2)
+    return didxre, didyre, didyim
+
+
+def _hessian_rotate(f_xx, f_xy, f_yx, f_yy, phi):
+    """piemd.py:157-181."""
+    cos_2phi = torch.cos(2 * phi)
+    sin_2phi = torch.sin(2 * phi)
+    a = 1 / 2 * (f_xx + f_yy)
+    b = 1 / 2 * (f_xx - f_yy) * cos_2phi
+    c = f_xy * sin_2phi
+    d = f_xy * cos_2phi
+    e = 1 / 2 * (f_xx - f_yy) * sin_2phi
+    return a + b + c, d - e, d - e, a - b - c
+
+
+def dpie_hessian(x, y, theta_E, r_core, r_cut, e1, e2, center_x=0, center_y=0):
+    """piemd.py:121-138."""
+    theta_E, r_core, r_cut, e1, e2, center_x, center_y = (
+        _t(v, x) for v in (theta_E, r_core, r_cut, e1, e2, center_x, center_y))
+    e, q, phi = _dpie_param_conv(e1, e2)
+    x, y = x - center_x, y - center_y
+    x, y = _rotate(x, y, phi)
+    r_core, r_cut = _sort_ra_rs(r_core, r_cut)
+    scale = theta_E * r_cut / (r_cut - r_core)
+    a1, b1, c1 = _dpie_complex_hessian_single(x, y, r_core, e, q)
+    a2, b2, c2 = _dpie_complex_hessian_single(x, y, r_cut, e, q)
+    f_xx = scale * (a1 - a2)
+    f_xy = f_yx = scale * (b1 - b2)
+    f_yy = scale * (c1 - c2)
+    return _hessian_rotate(f_xx, f_xy, f_yx, f_yy, -phi)
+
+
+def dpie_convergence(x, y, theta_E, r_core, r_cut, e1, e2, center_x=0, center_y=0):
+    """piemd.py:140-149."""
+    theta_E, r_core, r_cut, e1, e2, center_x, center_y = (
+        _t(v, x) for v in (theta_E, r_core, r_cut, e1, e2, center_x, center_y))
+    e, q, phi = _dpie_param_conv(e1, e2)
+    x, y = x - center_x, y - center_y
+    x, y = _rotate(x, y, phi)
+    r_core, r_cut = _sort_ra_rs(r_core, r_cut)
+    scale = theta_E * r_cut / (r_cut - r_core)
+    rem2 = x ** 2 / (1. + e) ** 2 + y ** 2 / (1. - e) ** 2
+    return scale / 2 * (1 / torch.sqrt(rem2 + r_core ** 2) - 1 / torch.sqrt(rem2 + r_cut ** 2))
+
+
+def dpiep_deriv(x, y, theta_E, Ra, Rs, e1, e2, center_x=0, center_y=0):
+    """piep.py:31-55: the spherical dPIS evaluated on coordinates stretched by sqrt(1 -+ e)."""
+    theta_E, Ra, Rs, e1, e2, center_x, center_y = (_t(v, x) for v in (theta_E, Ra, Rs, e1, e2, center_x, center_y))
+    phi = torch.atan2(e2, e1) / 2
+    c = torch.clamp(torch.sqrt(e1 ** 2 + e2 ** 2), max=0.9999)
+    q = (1 - c) / (1 + c)
+    e = torch.abs(1 - q ** 2) / (1 + q ** 2)
+    x, y = x - center_x, y - center_y
+    x, y = _rotate(x, y, phi)
+    x, y = x * torch.sqrt(1 - e), y * torch.sqrt(1 + e)
+    fx, fy = dpis_deriv(x, y, theta_E, Ra, Rs, 0.0, 0.0)
+    fx = fx * torch.sqrt(1 - e)
+    fy = fy * torch.sqrt(1 + e)
+    return _rotate(fx, fy, -phi)
+
+
+_SCALED_BASE = {"dPIS": (dpis_deriv, dpis_hessian), "dPIE": (dpie_deriv, dpie_hessian)}
+
+
+def scaled_unscaled_factors(profile):
+    """(L/L*)^power per scaling parameter, in float32 like the reference's constants (scaling_relation.py:27-30,53)."""
+    lum = torch.as_tensor(np.asarray(profile.galaxy_cat["lum"], dtype=np.float32))
+    lum_star = torch.tensor(float(profile.lum_star), dtype=torch.float32)
+    return {k: (lum / lum_star) ** torch.tensor(float(profile.power[k]), dtype=torch.float32)
+            for k in profile.scaling_params}
+
+
+def _scaled_galaxy_kwargs(profile, scales, like):
+    """scaling_relation.py:27-59: per-galaxy parameters = (L/L*)^power * scale for the scaling parameters, catalogue
+    columns for the rest; a trailing galaxy axis is appended (x, y, b) -> (x, y, b, g), :64."""
+    kw = {k: u.to(like.dtype) * _t(scales[k], like).unsqueeze(-1) for k, u in scaled_unscaled_factors(profile).items()}
+    for k in profile.not_scaling_params:
+        kw[k] = torch.as_tensor(np.asarray(profile.galaxy_cat[k], dtype=np.float32)).to(like.dtype)
+    return kw
+
+
+def scaled_deriv(profile, x, y, **scales):
+    """scaling_relation.py:61-70 (chunking only bounds memory; the sum is the same)."""
+    base = profile.profile
+    kw = _scaled_galaxy_kwargs(profile, scales, x)
+    fx, fy = mass_deriv(base, x.unsqueeze(-1), y.unsqueeze(-1), **kw)
+    return fx.sum(-1), fy.sum(-1)
+
+
+def scaled_hessian(profile, x, y, **scales):
+    """scaling_relation.py:72-83."""
+    base = profile.profile
+    kw = _scaled_galaxy_kwargs(profile, scales, x)
+    h = mass_hessian(base, x.unsqueeze(-1), y.unsqueeze(-1), **kw)
+    return tuple(t.sum(-1) for t in h)
+
+
+# --------------------------------------------------------------------------
 # light profiles
 # --------------------------------------------------------------------------
 def sersic_distance(x, y, cx, cy, e1=None, e2=None):
@@ -331,7 +551,35 @@ def mass_deriv(profile, x, y, **kw):
         return shear_deriv(x, y, **kw)
     if name == "SIS":
         return sis_deriv(x, y, **kw)
+    if name == "dPIS":
+        return dpis_deriv(x, y, **kw)
+    if name == "dPIE" and "Ra" in profile.params:  # piep.py:22 reuses the name "dPIE"
+        return dpiep_deriv(x, y, **kw)
+    if name == "dPIE":
+        return dpie_deriv(x, y, **kw)
+    if name.startswith("Scaled-"):
+        return scaled_deriv(profile, x, y, **kw)
     raise NotImplementedError(name)
+
+
+def mass_hessian(profile, x, y, **kw):
+    """``lens.hessian`` as the reference resolves it: the analytic overrides of dPIS / dPIE (piemd.py:62-83,
+    :121-138) and of ScalingRelation (sum of the base profile's), autodiff of ``deriv`` otherwise
+    (tf/profile.py:9-27; the NFW / Shear / SIS overrides equal that derivative)."""
+    name = profile.name
+    if name == "dPIS":
+        return dpis_hessian(x, y, **kw)
+    if name == "dPIE" and "Ra" not in profile.params:
+        return dpie_hessian(x, y, **kw)
+    if name.startswith("Scaled-"):
+        return scaled_hessian(profile, x, y, **kw)
+    if not x.requires_grad:
+        x = x.clone().requires_grad_(True)
+        y = y.clone().requires_grad_(True)
+    fx, fy = mass_deriv(profile, x, y, **kw)
+    a, b = torch.autograd.grad(fx.sum(), [x, y], create_graph=True)
+    cc, d = torch.autograd.grad(fy.sum(), [x, y], create_graph=True)
+    return a, b, cc, d
 
 
 def light_eval(profile, x, y, **kw):

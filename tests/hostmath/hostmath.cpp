@@ -9,6 +9,7 @@
 
 #include "../../gigalens_amd/csrc/gl_host_tables.h"
 #include "../../gigalens_amd/csrc/gl_profiles.h"
+#include "../../gigalens_amd/csrc/gl_dpie.h"
 #include "../../gigalens_amd/csrc/gl_dual.h"
 
 using namespace glp;
@@ -31,6 +32,7 @@ void run_mass(int kind, int iparam, const R* p, int n, const R* x, const R* y, c
     case K_NFW: nfw_prep<R>(p, d.data()); break;
     case K_SHEAR: shear_prep<R>(p, d.data()); break;
     case K_SIS: sis_prep<R>(p, d.data()); break;
+    case K_DPIS: case K_DPIE: case K_DPIEP: dpie_prep<R>(kind, p, d.data()); break;
   }
   for (int i = 0; i < n; ++i) {
     switch (kind) {
@@ -39,6 +41,8 @@ void run_mass(int kind, int iparam, const R* p, int n, const R* x, const R* y, c
       case K_NFW: nfw_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); nfw_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
       case K_SHEAR: shear_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); shear_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
       case K_SIS: sis_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); sis_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
+      case K_DPIS: case K_DPIE: case K_DPIEP:
+        dpie_fwd<R>(kind, d.data(), x[i], y[i], ax[i], ay[i]); dpie_vjp<R>(kind, d.data(), x[i], y[i], gx[i], gy[i], acc); break;
     }
   }
   switch (kind) {
@@ -47,7 +51,37 @@ void run_mass(int kind, int iparam, const R* p, int n, const R* x, const R* y, c
     case K_NFW: nfw_finalize<R>(p, acc, grad); break;
     case K_SHEAR: shear_finalize<R>(p, acc, grad); break;
     case K_SIS: sis_finalize<R>(p, acc, grad); break;
+    case K_DPIS: case K_DPIE: case K_DPIEP: dpie_finalize<R>(kind, p, acc, grad); break;
   }
+}
+
+// ScalingRelation over a catalogue: deflection and the gradient w.r.t. the population scales
+template <class R>
+void run_scaled(int base_kind, int n_gal, const float* table, const int* cols, const R* scales, int n, const R* x,
+                const R* y, const R* gx, const R* gy, R* ax, R* ay, R* gscales) {
+  ScaledDesc sd{base_kind, n_gal, {cols[0], cols[1], cols[2]}};
+  R gs[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) { ax[i] = 0; ay[i] = 0; }
+  for (int g = 0; g < n_gal; ++g) {
+    R ds[DP_NS], dd[DP_ND];
+    scaled_static<R>(base_kind, table + 7 * g, ds);
+    scaled_dyn<R>(sd, table + 7 * g, scales, dd);
+    R a[DP_NACC] = {0};
+    for (int i = 0; i < n; ++i) {
+      R fx, fy;
+      if (base_kind == K_DPIE) {
+        piemd_fwd<R>(ds, dd, x[i], y[i], fx, fy);
+        piemd_vjp<R, false>(ds, dd, nullptr, x[i], y[i], gx[i], gy[i], a);
+      } else {
+        piep_fwd<R>(ds, dd, x[i], y[i], fx, fy);
+        piep_vjp<R, false>(ds, dd, x[i], y[i], gx[i], gy[i], a);
+      }
+      ax[i] += fx;
+      ay[i] += fy;
+    }
+    scaled_fold<R>(dd, a, gs);
+  }
+  for (int k = 0; k < 3; ++k) gscales[k] = gs[k];
 }
 
 template <class R>
@@ -100,7 +134,16 @@ template <int PL> static void lens_jet(int kind, int iparam, const double* p0, d
     case K_SIE: { R d[SIE_ND + 1]; sie_prep<R>(p, d); sie_fwd<R>(d, x, y, ax, ay); } break;
     case K_NFW: { R d[NFW_ND]; nfw_prep<R>(p, d); nfw_fwd<R>(d, x, y, ax, ay); } break;
     case K_SHEAR: { R d[4]; shear_prep<R>(p, d); shear_fwd<R>(d, x, y, ax, ay); } break;
+    case K_DPIS: case K_DPIE: case K_DPIEP: { R d[DPX_ND]; dpie_prep<R>(kind, p, d); dpie_fwd<R>(kind, d, x, y, ax, ay); } break;
     default: { R d[4]; sis_prep<R>(p, d); sis_fwd<R>(d, x, y, ax, ay); } break;
+  }
+  if (kind == K_DPIS) {  // the reference's analytic override (piemd.py:62-83), see dpis_kappa_excess
+    R1 d1[DPX_ND], p1[PL];
+    for (int k = 0; k < PL; ++k) p1[k] = p[k].v;
+    dpie_prep<R1>(kind, p1, d1);
+    R1 ex = dpis_kappa_excess<R1>(d1, d1 + DP_NS, R1(x0), R1(y0));
+    ax.d[0] += ex;
+    ay.d[1] += ex;
   }
   const R1 q[6] = {ax.v, ay.v, ax.d[0], ax.d[1], ay.d[0], ay.d[1]};
   for (int i = 0; i < 6; ++i) {
@@ -147,7 +190,19 @@ void hm_lens_jet_f64(int kind, int iparam, const double* p, double x, double y, 
     case K_SIE: lens_jet<5>(kind, iparam, p, x, y, out); break;
     case K_NFW: lens_jet<4>(kind, iparam, p, x, y, out); break;
     case K_SHEAR: lens_jet<2>(kind, iparam, p, x, y, out); break;
+    case K_DPIS: lens_jet<5>(kind, iparam, p, x, y, out); break;
+    case K_DPIE: case K_DPIEP: lens_jet<7>(kind, iparam, p, x, y, out); break;
     default: lens_jet<3>(kind, iparam, p, x, y, out); break;
   }
+}
+void hm_scaled_f64(int base_kind, int n_gal, const float* table, const int* cols, const double* scales, int n,
+                   const double* x, const double* y, const double* gx, const double* gy, double* ax, double* ay,
+                   double* gscales) {
+  run_scaled<double>(base_kind, n_gal, table, cols, scales, n, x, y, gx, gy, ax, ay, gscales);
+}
+void hm_scaled_f32(int base_kind, int n_gal, const float* table, const int* cols, const float* scales, int n,
+                   const float* x, const float* y, const float* gx, const float* gy, float* ax, float* ay,
+                   float* gscales) {
+  run_scaled<float>(base_kind, n_gal, table, cols, scales, n, x, y, gx, gy, ax, ay, gscales);
 }
 }
