@@ -60,6 +60,9 @@ SYMBOLS = {
                                        POINTER(c_float), POINTER(c_float)]),
     "gl_positions_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
+    "gl_model_set_catalogue": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int32), POINTER(c_float)]),
+    "gl_scaled_eval": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                               c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     "gl_kind_num_params": (c_int, [POINTER(gl_component)]),
@@ -126,6 +129,39 @@ def device():
 # --------------------------------------------------------------------------------------------------
 # plugin-level point evaluation (MassProfile.deriv / LightProfile.light)
 # --------------------------------------------------------------------------------------------------
+def _broadcast_points(profile, x, y, kwargs, names, dev):
+    missing = [n for n in names if n not in kwargs]
+    if missing:
+        raise TypeError(f"{profile.name}: missing parameters {missing}")
+    x = torch.as_tensor(x, dtype=torch.float32, device=dev)
+    y = torch.as_tensor(y, dtype=torch.float32, device=dev)
+    vals = [torch.as_tensor(kwargs[n], dtype=torch.float32, device=dev) for n in names]
+    out_shape = torch.broadcast_shapes(x.shape, y.shape, *[v.shape for v in vals])
+    B = out_shape[-1] if len(out_shape) else 1
+    for n, v in zip(names, vals):
+        if v.dim() > 1 and any(s != 1 for s in v.shape[:-1]):
+            raise NativeLibraryError(f"{profile.name}.{n}: parameters may only vary along the last (batch) axis")
+    P = torch.stack([v.reshape(-1)[-B:].expand(B) if v.numel() > 1 else v.reshape(()).expand(B) for v in vals],
+                    dim=1).contiguous()
+    xb = x.expand(out_shape).reshape(-1, B).contiguous()
+    yb = y.expand(out_shape).reshape(-1, B).contiguous()
+    return xb, yb, P, B, out_shape
+
+
+def scaled_eval(profile, x, y, scales):
+    """ScalingRelation.deriv (scaling_relation.py:61-70) through gl_scaled_eval."""
+    dev = device()
+    xb, yb, P, B, out_shape = _broadcast_points(profile, x, y, scales, list(profile.params), dev)
+    base_kind, cols, table = profile._catalogue()
+    if profile._dev_table is None or profile._dev_table.device != dev:
+        profile._dev_table = torch.from_numpy(table).to(dev)
+    col_arr = (c_int32 * 3)(*cols)
+    out0, out1 = torch.empty_like(xb), torch.empty_like(xb)
+    _check(lib().gl_scaled_eval(base_kind, table.shape[0], col_arr, _ptr(profile._dev_table), _ptr(xb), _ptr(yb),
+                                xb.shape[0], B, 1, _ptr(P), P.shape[1], _ptr(out0), _ptr(out1), _stream()))
+    return out0.reshape(out_shape), out1.reshape(out_shape)
+
+
 def profile_eval(profile, x, y, kwargs):
     dev = device()
     comp = component_of(profile)
@@ -147,7 +183,7 @@ def profile_eval(profile, x, y, kwargs):
     yb = y.expand(out_shape).reshape(-1, B).contiguous()
     n_pts = xb.shape[0]
     out0 = torch.empty_like(xb)
-    is_mass = comp.kind <= 5
+    is_mass = comp.kind <= 8
     out1 = torch.empty_like(xb) if is_mass else None
     _check(lib().gl_profile_eval(ctypes.byref(comp), _ptr(xb), _ptr(yb), n_pts, B, 1, _ptr(P), _ptr(out0),
                                  _ptr(out1), _stream()))
@@ -196,6 +232,15 @@ class Model:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.gl_model_destroy(h)
+
+    def set_catalogue(self, component, base_kind, cols, table):
+        """Attach the galaxy catalogue of a GL_SCALED lens (gl_model_set_catalogue)."""
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        col_arr = (c_int32 * 3)(*[int(c) for c in cols])
+        with torch.cuda.device(self.device):
+            _check(lib().gl_model_set_catalogue(self._h, int(component), int(base_kind), int(t.shape[0]), col_arr,
+                                                t.ctypes.data_as(POINTER(c_float))))
+        self._ws = {}  # the workspace grows with the catalogue
 
     def set_prior(self, columns, const_row):
         """columns: list of (param_col, bijector, prior, a, b, lo, hi, log_norm); const_row: [P] floats."""

@@ -80,9 +80,18 @@ struct gl_model {
   float* d_pos = nullptr;  // [4][J]: x, y, err_x, err_y
   int* d_fam = nullptr;    // [F+1]
   bool has_epl = false;
+  bool has_dpie = false;  // any dPIE-family lens or galaxy catalogue
   bool use_order = true;
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // galaxy catalogues of the GL_SCALED components (gl_model_set_catalogue)
+  struct Cat { CatDev dev; std::vector<float> table; };
+  std::vector<Cat> cats;
+  int G = 0;           // galaxies over all catalogues
+  int n_scaled = 0;    // GL_SCALED components
+  CatDev* d_cats = nullptr;
+  float* d_gal_table = nullptr;   // [G][7]
+  float* d_gal_static = nullptr;  // [G][DP_NS]
   int tile = 2;          // pixels per thread per tile (template T) for forward-only launches
   int tile_grad = 2;     // ... and for launches that also produce gradients
   int target_wgs = 2048;  // work decomposition target (>= 8 workgroups per CU)
@@ -106,6 +115,7 @@ struct Workspace {
   float* partial;
   float* params;  // [B,P] constrained rows produced from z (gl_logprob_fwd_bwd)
   int* order;     // [B] cost-ordered dispatch
+  float* gal_dyn;  // [B][G][DP_ND] catalogue members' per-sample constants
   float *pos_w, *pos_adj, *pos_g, *pos_fam, *pos_ll, *pos_chi2, *pos_grad;  // image-position likelihood
   float* img_ss;   // supersampled / pre-PSF image or its cotangent (PSF path only)
   float* img_tmp;  // final-resolution image / its cotangent (PSF path only)
@@ -127,6 +137,10 @@ Workspace carve(const gl_model* m, int B, void* base) {
   off += align_up((size_t)B * std::max(m->P, 1) * sizeof(float), 256);
   w.order = (int*)(p + off);
   off += align_up((size_t)B * sizeof(int), 256);
+  if (m->G) {
+    w.gal_dyn = (float*)(p + off);
+    off += align_up((size_t)B * m->G * DP_ND * sizeof(float), 256);
+  }
   if (m->pos_J) {
     auto take = [&](size_t n) { float* q = (float*)(p + off); off += align_up(n * sizeof(float), 256); return q; };
     w.pos_w = take((size_t)B * m->pos_J * 6);
@@ -233,12 +247,14 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
   if (m->timing) GL_HIP(hipEventRecord(m->ev0, stream));
   if (m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
     // specialised kernel launched
-  } else if (const int Tg = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile; m->has_shapelets) {
-    if (Tg == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, true>), grid, block, shmem, stream, a);
-    else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true>), grid, block, shmem, stream, a);
   } else {
-    if (Tg == 4) hipLaunchKernelGGL((gl_main_kernel<MODE, 4, false>), grid, block, shmem, stream, a);
-    else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, false>), grid, block, shmem, stream, a);
+    const int Tg = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
+#define GL_MAIN(TT, S_, D_) hipLaunchKernelGGL((gl_main_kernel<MODE, TT, S_, D_>), grid, block, shmem, stream, a)
+    if (m->has_shapelets && m->has_dpie) { if (Tg == 4) GL_MAIN(4, true, true); else GL_MAIN(2, true, true); }
+    else if (m->has_shapelets) { if (Tg == 4) GL_MAIN(4, true, false); else GL_MAIN(2, true, false); }
+    else if (m->has_dpie) { if (Tg == 4) GL_MAIN(4, false, true); else GL_MAIN(2, false, true); }
+    else { if (Tg == 4) GL_MAIN(4, false, false); else GL_MAIN(2, false, false); }
+#undef GL_MAIN
   }
   if (m->timing) GL_HIP(hipEventRecord(m->ev1, stream));
   GL_HIP(hipGetLastError());
@@ -267,6 +283,10 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.shp_tab = m->d_shp_tab;
   a.shp_stride = m->shp_stride;
   a.parts = 7u;
+  a.cats = m->d_cats;
+  a.gal_static = m->d_gal_static;
+  a.gal_dyn = w.gal_dyn;
+  a.G = m->G;
   return a;
 }
 
@@ -274,9 +294,22 @@ int check_call(const gl_model* m, const void* params, int B, void* ws, size_t ws
   if (!m) return fail(GL_EINVAL, "model is null");
   if (!params) return fail(GL_EINVAL, "params is null");
   if (B <= 0 || B > 65535) return fail(GL_EINVAL, "batch size %d outside [1, 65535]", B);
+  if ((int)m->cats.size() != m->n_scaled)
+    return fail(GL_EINVAL, "%d GL_SCALED component(s) without a catalogue (gl_model_set_catalogue)",
+                m->n_scaled - (int)m->cats.size());
   if (!ws) return fail(GL_EINVAL, "workspace is null");
   size_t need = gl_workspace_bytes(m, B);
   if (ws_bytes < need) return fail(GL_ENOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+  return GL_OK;
+}
+
+// per (sample, galaxy) constants of the catalogue members, from the constrained parameter rows
+int run_galprep(const gl_model* m, const float* params, int B, const Workspace& w, hipStream_t stream) {
+  if (!m->G) return GL_OK;
+  long long total = (long long)B * m->G;
+  hipLaunchKernelGGL(gl_galprep_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, m->d_comps,
+                     m->d_cats, (int)m->cats.size(), params, m->P, B, m->d_gal_table, w.gal_dyn, m->G);
+  GL_HIP(hipGetLastError());
   return GL_OK;
 }
 
@@ -286,7 +319,7 @@ int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, 
   hipLaunchKernelGGL(gl_prep_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, params,
                      m->P, B, w.derived, m->D);
   GL_HIP(hipGetLastError());
-  return GL_OK;
+  return run_galprep(m, params, B, w, stream);
 }
 
 int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, const Workspace& w, float* loglike,
@@ -298,7 +331,7 @@ int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, co
                      m->P, w.partial, n_chunks, m->A, loglike, chi2, grad, z, m->d_z, z ? m->d_zcols : nullptr, logprob,
                      grad_z, chi2_scale, extra_stats, use_partial, with_positions ? w.pos_ll : nullptr,
                      with_positions ? w.pos_chi2 : nullptr,
-                     with_positions && (grad || grad_z) ? w.pos_grad : nullptr, pos_chi2_scale);
+                     with_positions && (grad || grad_z) ? w.pos_grad : nullptr, pos_chi2_scale, m->d_cats);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -337,11 +370,15 @@ int run_positions(const gl_model* m, const float* params, int B, const Workspace
   a.ll = w.pos_ll;
   a.chi2 = w.pos_chi2;
   a.grad = want_grad ? w.pos_grad : nullptr;
+  a.cats = m->d_cats;
+  a.gal_table = m->d_gal_table;
+  a.gal_static = m->d_gal_static;
   auto blocks = [](long long n) { return dim3((unsigned)((n + 63) / 64)); };
   hipLaunchKernelGGL(gl_pos_p1_kernel, blocks((long long)B * a.J), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(gl_pos_p2_kernel, blocks((long long)B * a.F), dim3(64), 0, stream, a);
-  if (want_grad && m->n_lens)
-    hipLaunchKernelGGL(gl_pos_p3_kernel, blocks((long long)B * a.J * a.n_lens), dim3(64), 0, stream, a);
+  if (want_grad && m->lens_params)
+    hipLaunchKernelGGL(gl_pos_p3_kernel, blocks((long long)B * a.J * m->lens_params), dim3(64), 0, stream, a,
+                       m->lens_params);
   hipLaunchKernelGGL(gl_pos_p4_kernel, blocks((long long)B * (a.P + 1)), dim3(64), 0, stream, a, m->lens_params);
   GL_HIP(hipGetLastError());
   return GL_OK;
@@ -426,7 +463,7 @@ const char* gl_version(void) { return "gigalens_hip 0.1 (gfx950)"; }
 int gl_kind_num_params(const gl_component* comp) {
   if (!comp) return fail(GL_EINVAL, "component is null");
   int n = kind_num_params(comp->kind, comp->iparam);
-  if (n < 0) return fail(GL_EINVAL, "unknown profile kind %d", comp->kind);
+  if (n < 0) return fail(GL_EINVAL, "unknown profile kind %d (iparam %d)", comp->kind, comp->iparam);
   return n;
 }
 
@@ -460,7 +497,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   for (int i = 0; i < n_comp; ++i) {
     const gl_component& c = comps[i];
     const bool mass = i < n_lens;
-    const bool is_mass_kind = c.kind >= GL_EPL && c.kind <= GL_SIS;
+    const bool is_mass_kind = c.kind >= GL_EPL && c.kind <= GL_SCALED;
     const bool is_light_kind = c.kind >= GL_SERSIC && c.kind <= GL_SHAPELETS;
     if ((mass && !is_mass_kind) || (!mass && !is_light_kind)) {
       delete m;
@@ -472,6 +509,11 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
       if (iparam > 1000) { delete m; return fail(GL_EINVAL, "EPL niter %d too large", iparam); }
     }
     if (c.kind == GL_EPL) m->has_epl = true;
+    if (c.kind >= GL_DPIS && c.kind <= GL_SCALED) m->has_dpie = true;
+    if (c.kind == GL_SCALED) {
+      if (iparam < 1 || iparam > 3) { delete m; return fail(GL_EINVAL, "component %d: GL_SCALED takes 1..3 scales, got %d", i, iparam); }
+      ++m->n_scaled;
+    }
     if (c.kind == GL_SHAPELETS) {
       if (iparam < 0 || iparam > GL_SHAPELETS_NMAX_CAP) {
         delete m;
@@ -489,6 +531,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     cd.a_off = a_off;
     cd.n_par = kind_num_params(c.kind, iparam);
     cd.n_acc = kind_num_acc(c.kind, iparam);
+    if (c.kind == GL_SCALED) cd.iparam = -1;  // catalogue slot, set by gl_model_set_catalogue
     p_off += cd.n_par;
     d_off += (kind_num_derived(c.kind, iparam) + 3) & ~3;
     a_off += cd.n_acc;
@@ -517,7 +560,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   if (!m->tile_grad) m->tile_grad = m->static_id ? 1 : 2;  // measured: T=1 wins once the VJP state lives in registers
   if (!m->static_id) {  // the interpreter kernel is built for T = 2 and 4
     const bool env_tile = env_int("GIGALENS_HIP_TILE", 0) != 0;
-    if (!env_tile && !m->has_epl && !m->has_shapelets) m->tile = m->tile_grad = 4;  // cheap profiles: amortise the per-tile accumulation
+    if (!env_tile && !m->has_epl && !m->has_shapelets && !m->has_dpie) m->tile = m->tile_grad = 4;  // cheap profiles: amortise the per-tile accumulation
     if (m->tile == 1) m->tile = 2;
     if (m->tile_grad == 1) m->tile_grad = 2;
   }
@@ -609,6 +652,9 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_zcols) (void)hipFree(m->d_zcols);
   if (m->d_src) (void)hipFree(m->d_src);
   if (m->d_const) (void)hipFree(m->d_const);
+  if (m->d_cats) (void)hipFree(m->d_cats);
+  if (m->d_gal_table) (void)hipFree(m->d_gal_table);
+  if (m->d_gal_static) (void)hipFree(m->d_gal_static);
   delete m;
 }
 
@@ -711,6 +757,79 @@ int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs,
                       1.f, extra, use_partial);
 }
 
+int gl_model_set_catalogue(gl_model* m, int component, int base_kind, int n_galaxies, const int32_t scale_col[3],
+                           const float* table) {
+  if (!m) return fail(GL_EINVAL, "model is null");
+  if (component < 0 || component >= m->n_lens || m->comps[component].kind != K_SCALED)
+    return fail(GL_EINVAL, "component %d is not a GL_SCALED lens", component);
+  if (base_kind != GL_DPIS && base_kind != GL_DPIE && base_kind != GL_DPIEP)
+    return fail(GL_EUNSUPPORTED, "ScalingRelation over profile kind %d is not built (dPIS, dPIE, dPIEP are)", base_kind);
+  if (n_galaxies <= 0 || !scale_col || !table) return fail(GL_EINVAL, "empty catalogue");
+  CompDesc& cd = m->comps[component];
+  int used = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (scale_col[k] >= cd.n_par) return fail(GL_EINVAL, "scale_col[%d]=%d outside the component's %d scales", k, scale_col[k], cd.n_par);
+    if (scale_col[k] >= 0) {
+      if (used & (1 << scale_col[k])) return fail(GL_EINVAL, "scale column %d used twice", scale_col[k]);
+      used |= 1 << scale_col[k];
+    }
+  }
+  if (used != (1 << cd.n_par) - 1) return fail(GL_EINVAL, "every one of the %d scales must drive one of theta_E, r_core, r_cut", cd.n_par);
+  gl_model::Cat cat{};
+  cat.dev.base_kind = base_kind;
+  cat.dev.n_gal = n_galaxies;
+  cat.dev.comp = component;
+  for (int k = 0; k < 3; ++k) cat.dev.col[k] = scale_col[k];
+  cat.table.assign(table, table + (size_t)7 * n_galaxies);
+  if (cd.iparam >= 0) m->cats[cd.iparam] = cat;
+  else { cd.iparam = (int)m->cats.size(); m->cats.push_back(cat); }
+  // rebuild the model-wide galaxy arrays
+  std::vector<CatDev> devs;
+  std::vector<float> tab, stat;
+  int G = 0;
+  for (auto& c : m->cats) {
+    c.dev.g_off = G;
+    G += c.dev.n_gal;
+    devs.push_back(c.dev);
+    tab.insert(tab.end(), c.table.begin(), c.table.end());
+    for (int g = 0; g < c.dev.n_gal; ++g) {
+      float ds[DP_NS];
+      scaled_static<float>(c.dev.base_kind, c.table.data() + (size_t)7 * g, ds);
+      stat.insert(stat.end(), ds, ds + DP_NS);
+    }
+  }
+  m->G = G;
+  if (m->d_cats) { (void)hipFree(m->d_cats); m->d_cats = nullptr; }
+  if (m->d_gal_table) { (void)hipFree(m->d_gal_table); m->d_gal_table = nullptr; }
+  if (m->d_gal_static) { (void)hipFree(m->d_gal_static); m->d_gal_static = nullptr; }
+  GL_HIP(hipMalloc((void**)&m->d_cats, sizeof(CatDev) * devs.size()));
+  GL_HIP(hipMalloc((void**)&m->d_gal_table, sizeof(float) * tab.size()));
+  GL_HIP(hipMalloc((void**)&m->d_gal_static, sizeof(float) * stat.size()));
+  GL_HIP(hipMemcpy(m->d_cats, devs.data(), sizeof(CatDev) * devs.size(), hipMemcpyHostToDevice));
+  GL_HIP(hipMemcpy(m->d_gal_table, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
+  GL_HIP(hipMemcpy(m->d_gal_static, stat.data(), sizeof(float) * stat.size(), hipMemcpyHostToDevice));
+  GL_HIP(hipMemcpy(m->d_comps, m->comps.data(), sizeof(CompDesc) * m->comps.size(), hipMemcpyHostToDevice));
+  return GL_OK;
+}
+
+int gl_scaled_eval(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev, const float* x,
+                   const float* y, int64_t n_pts, int B, int xy_batched, const float* scales, int n_scales,
+                   float* out0, float* out1, void* hip_stream) {
+  if (!scale_col || !table_dev || !x || !y || !scales || !out0 || !out1) return fail(GL_EINVAL, "null argument");
+  if (base_kind != GL_DPIS && base_kind != GL_DPIE && base_kind != GL_DPIEP)
+    return fail(GL_EUNSUPPORTED, "ScalingRelation over profile kind %d is not built (dPIS, dPIE, dPIEP are)", base_kind);
+  if (n_galaxies <= 0 || n_pts <= 0 || B <= 0 || n_scales < 1 || n_scales > 3) return fail(GL_EINVAL, "bad sizes");
+  for (int k = 0; k < 3; ++k)
+    if (scale_col[k] >= n_scales) return fail(GL_EINVAL, "scale_col[%d]=%d outside the %d scales", k, scale_col[k], n_scales);
+  ScaledDesc sd{base_kind, n_galaxies, {scale_col[0], scale_col[1], scale_col[2]}};
+  long long total = (long long)n_pts * B;
+  hipLaunchKernelGGL(gl_scaled_point_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)hip_stream, sd, table_dev, x, y, (long long)n_pts, B, xy_batched, scales, n_scales,
+                     out0, out1);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
 int gl_model_set_positions(gl_model* m, int n_families, const int* family_sizes, const float* x, const float* y,
                            const float* err_x, const float* err_y) {
   if (!m) return fail(GL_EINVAL, "model is null");
@@ -803,6 +922,7 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   hipLaunchKernelGGL(gl_zprep_kernel, dim3((B * n_comp + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, z,
                      m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D);
   GL_HIP(hipGetLastError());
+  if ((rc = run_galprep(m, w.params, B, w, stream))) return rc;
   const float* extra = nullptr;
   int use_partial = 0;
   if (pix && (rc = run_likelihood(m, B, w, chunk, n_chunks, obs, err_or_null, mask_or_null, bg_rms, exp_time,
@@ -822,7 +942,8 @@ int gl_profile_eval(const gl_component* comp, const float* x, const float* y, in
   if (n_pts <= 0 || B <= 0) return fail(GL_EINVAL, "n_pts and B must be positive");
   int npar = kind_num_params(comp->kind, comp->iparam);
   if (npar < 0) return fail(GL_EINVAL, "unknown profile kind %d", comp->kind);
-  const bool mass = comp->kind <= GL_SIS;
+  if (comp->kind == GL_SCALED) return fail(GL_EINVAL, "GL_SCALED needs its catalogue: use gl_scaled_eval");
+  const bool mass = comp->kind <= GL_DPIEP;
   if (mass && !out1) return fail(GL_EINVAL, "out1 is required for mass profiles");
   CompDesc cd{};
   cd.kind = comp->kind;

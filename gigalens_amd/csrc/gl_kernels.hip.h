@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gl_profiles.h"
+#include "gl_dpie.h"
 #include "gl_vec.hip.h"
 
 namespace glk {
@@ -25,6 +26,15 @@ struct CompDesc {
   int a_off;  // offset of the accumulators inside the per-sample accumulator row
   int n_acc;
   int n_par;
+};
+
+// one galaxy catalogue of a K_SCALED component (gl_model_set_catalogue)
+struct CatDev {
+  int base_kind, n_gal;
+  int g_off;   // first galaxy inside the model-wide galaxy arrays
+  int comp;    // component index
+  int col[3];  // theta_E, r_core, r_cut: column of the scale inside the component's parameter row, or -1
+  int pad;
 };
 
 enum Mode : int { IMG_FWD = 0, IMG_BWD = 1, LL_FWD = 2, LL_GRAD = 3 };
@@ -53,6 +63,11 @@ struct MainArgs {
   int shp_stride;
   const int* order;  // cost-ordered dispatch: blockIdx.y -> sample index (heaviest first), or null
   unsigned parts;    // forward-only partial renders (tf/simulator.py:242-328): bit0 deflect, bit1 lens light, bit2 sources
+  // galaxy catalogues (K_SCALED): per-galaxy static blocks [G][DP_NS], per-(sample, galaxy) blocks [B][G][DP_ND]
+  const CatDev* cats;
+  const float* gal_static;
+  const float* gal_dyn;
+  int G;
 };
 
 // ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
@@ -146,6 +161,8 @@ __global__ void __launch_bounds__(128) gl_prep_kernel(const CompDesc* __restrict
     case K_NFW: nfw_prep<float>(p, d); break;
     case K_SHEAR: shear_prep<float>(p, d); break;
     case K_SIS: sis_prep<float>(p, d); break;
+    case K_DPIS: case K_DPIE: case K_DPIEP: dpie_prep<float>(cd.kind, p, d); break;
+    case K_SCALED: d[0] = d[1] = d[2] = d[3] = 0.f; break;
     case K_SERSIC: sersic_prep<float>(p, false, d); break;
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, d); break;
@@ -227,10 +244,29 @@ __global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restric
     case K_NFW: nfw_prep<float>(p, dd); break;
     case K_SHEAR: shear_prep<float>(p, dd); break;
     case K_SIS: sis_prep<float>(p, dd); break;
+    case K_DPIS: case K_DPIE: case K_DPIEP: dpie_prep<float>(cd.kind, p, dd); break;
+    case K_SCALED: dd[0] = dd[1] = dd[2] = dd[3] = 0.f; break;
     case K_SERSIC: sersic_prep<float>(p, false, dd); break;
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, dd); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, dd); break;
   }
+}
+
+// per (sample, galaxy) constants of the catalogue members: radii, amplitude and the map to the scale gradients
+__global__ void __launch_bounds__(128) gl_galprep_kernel(const CompDesc* __restrict__ comps,
+                                                         const CatDev* __restrict__ cats, int n_cats,
+                                                         const float* __restrict__ params, int P, int B,
+                                                         const float* __restrict__ table, float* __restrict__ gal_dyn,
+                                                         int G) {
+  int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= B * G) return;
+  int b = i / G, g = i - b * G;
+  int c = 0;
+  while (c + 1 < n_cats && g >= cats[c + 1].g_off) ++c;
+  const CatDev cat = cats[c];
+  ScaledDesc sd{cat.base_kind, cat.n_gal, {cat.col[0], cat.col[1], cat.col[2]}};
+  scaled_dyn<float>(sd, table + (size_t)7 * g, params + (size_t)b * P + comps[cat.comp].p_off,
+                    gal_dyn + ((size_t)b * G + g) * DP_ND);
 }
 
 // cost-ordered dispatch: samples sorted by descending EPL trip count (the only data-dependent cost on the
@@ -379,8 +415,10 @@ template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const
 }
 
 // ---- the main kernel ----------------------------------------------------------------------------
-template <int MODE, int T, bool SHP>
-__global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
+// SHP / DP: the model contains shapelets / dPIE-family lenses -- their code (and register budget) is compiled only
+// into the variants that need it, so the common compositions keep their occupancy.
+template <int MODE, int T, bool SHP, bool DP>
+__global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainArgs a) {
   extern __shared__ float smem[];
   float* s_d = smem;
   float* s_acc = smem + ((a.D + 3) & ~3);
@@ -445,6 +483,43 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
 #pragma unroll
           for (int t = 0; t < T; ++t) { float ax, ay; sis_fwd(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
           break;
+        case K_DPIE:
+          if constexpr (DP) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) { float ax, ay; piemd_fwd<float>(d, d + DP_NS, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          }
+          break;
+        case K_DPIS:
+        case K_DPIEP:
+          if constexpr (DP) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) { float ax, ay; piep_fwd<float>(d, d + DP_NS, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          }
+          break;
+        case K_SCALED: if constexpr (DP) {  // sum over the catalogue (scaling_relation.py:61-70); member constants via wave-uniform loads
+          const CatDev cat = a.cats[comps[l].iparam];
+          const float* __restrict__ gs = a.gal_static + (size_t)cat.g_off * DP_NS;
+          const float* __restrict__ gd = a.gal_dyn + ((size_t)b * a.G + cat.g_off) * DP_ND;
+          if (cat.base_kind == K_DPIE) {
+            for (int g = 0; g < cat.n_gal; ++g) {
+#pragma unroll
+              for (int t = 0; t < T; ++t) {
+                float ax, ay;
+                piemd_fwd<float>(gs + g * DP_NS, gd + g * DP_ND, x[t], y[t], ax, ay);
+                bx[t] -= ax; by[t] -= ay;
+              }
+            }
+          } else {
+            for (int g = 0; g < cat.n_gal; ++g) {
+#pragma unroll
+              for (int t = 0; t < T; ++t) {
+                float ax, ay;
+                piep_fwd<float>(gs + g * DP_NS, gd + g * DP_ND, x[t], y[t], ax, ay);
+                bx[t] -= ax; by[t] -= ay;
+              }
+            }
+          }
+        } break;
       }
     }
     // ---- phase 2: render lens light at the grid, sources at beta (tf/simulator.py:128-138) ----
@@ -616,6 +691,41 @@ __global__ void __launch_bounds__(WG, SHP ? 2 : 4) gl_main_kernel(MainArgs a) {
             for (int t = 0; t < T; ++t) sis_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
             wave_acc<SIS_NACC>(acc, ac, cd.a_off);
           } break;
+          case K_DPIS:
+          case K_DPIE:
+          case K_DPIEP: if constexpr (DP) {
+            float acc[DP_NACC];
+#pragma unroll
+            for (int k = 0; k < DP_NACC; ++k) acc[k] = 0.f;
+            if (cd.kind == K_DPIE) {
+#pragma unroll
+              for (int t = 0; t < T; ++t) piemd_vjp<float, true>(d, d + DP_NS, d + DPX_DE, x[t], y[t], gbx[t], gby[t], acc);
+            } else {
+#pragma unroll
+              for (int t = 0; t < T; ++t) piep_vjp<float, true>(d, d + DP_NS, x[t], y[t], gbx[t], gby[t], acc);
+            }
+            wave_acc<DP_NACC>(acc, ac, cd.a_off);
+          } break;
+          case K_SCALED: if constexpr (DP) {
+            const CatDev cat = a.cats[cd.iparam];
+            const float* __restrict__ gs = a.gal_static + (size_t)cat.g_off * DP_NS;
+            const float* __restrict__ gd = a.gal_dyn + ((size_t)b * a.G + cat.g_off) * DP_ND;
+            float sc[3] = {0.f, 0.f, 0.f};  // gradients of the three scales
+            for (int g = 0; g < cat.n_gal; ++g) {
+              float am[3] = {0.f, 0.f, 0.f};  // this member's (dS, d rc, d rt) over the thread's pixels
+              if (cat.base_kind == K_DPIE) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                  piemd_vjp<float, false>(gs + g * DP_NS, gd + g * DP_ND, nullptr, x[t], y[t], gbx[t], gby[t], am);
+              } else {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                  piep_vjp<float, false>(gs + g * DP_NS, gd + g * DP_ND, x[t], y[t], gbx[t], gby[t], am);
+              }
+              scaled_fold<float>(gd + g * DP_ND, am, sc);
+            }
+            wave_acc<3>(sc, ac, cd.a_off);
+          } break;
         }
       }
     }
@@ -644,7 +754,8 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
                                                           float chi2_scale, const float* __restrict__ extra_stats,
                                                           int use_partial, const float* __restrict__ pos_ll,
                                                           const float* __restrict__ pos_chi2,
-                                                          const float* __restrict__ pos_grad, float pos_chi2_scale) {
+                                                          const float* __restrict__ pos_grad, float pos_chi2_scale,
+                                                          const CatDev* __restrict__ cats) {
   extern __shared__ float s[];  // [A] accumulators, then [P] parameter gradients, then [d_z] prior terms
   float* s_g = s + ((A + 3) & ~3);
   float* s_t = s_g + ((P + 3) & ~3);
@@ -671,6 +782,12 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
         case K_NFW: nfw_finalize<float>(p, acc, g); break;
         case K_SHEAR: shear_finalize<float>(p, acc, g); break;
         case K_SIS: sis_finalize<float>(p, acc, g); break;
+        case K_DPIS: case K_DPIE: case K_DPIEP: dpie_finalize<float>(cd.kind, p, acc, g); break;
+        case K_SCALED: {
+          const CatDev cat = cats[cd.iparam];
+          for (int k = 0; k < 3; ++k)
+            if (cat.col[k] >= 0) g[cat.col[k]] = acc[k];
+        } break;
         case K_SERSIC: sersic_finalize<float>(p, false, acc, g); break;
         case K_SERSIC_ELLIPSE: sersic_finalize<float>(p, true, acc, g); break;
         case K_SHAPELETS: shapelets_finalize<float>(p, cd.iparam, acc, g); break;
@@ -729,6 +846,7 @@ __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float*
     case K_NFW: { float d[NFW_ND]; nfw_prep<float>(p, d); nfw_fwd(d, px, py, o0, o1); } break;
     case K_SHEAR: { float d[4]; shear_prep<float>(p, d); shear_fwd(d, px, py, o0, o1); } break;
     case K_SIS: { float d[4]; sis_prep<float>(p, d); sis_fwd(d, px, py, o0, o1); } break;
+    case K_DPIS: case K_DPIE: case K_DPIEP: { float d[DPX_ND]; dpie_prep<float>(cd.kind, p, d); dpie_fwd<float>(cd.kind, d, px, py, o0, o1); } break;
     case K_SERSIC: { float d[SER_ND + 2]; sersic_prep<float>(p, false, d); o0 = sersic_fwd(d, px, py); } break;
     case K_SERSIC_ELLIPSE: { float d[SER_ND + 2]; sersic_prep<float>(p, true, d); o0 = sersic_fwd(d, px, py); } break;
     case K_SHAPELETS: {
@@ -739,6 +857,32 @@ __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float*
   }
   out0[i] = o0;
   if (out1) out1[i] = o1;
+}
+
+// ScalingRelation.deriv on arbitrary points (scaling_relation.py:61-70)
+__global__ void __launch_bounds__(256) gl_scaled_point_kernel(ScaledDesc sd, const float* __restrict__ table,
+                                                              const float* __restrict__ x, const float* __restrict__ y,
+                                                              long long n_pts, int B, int xy_batched,
+                                                              const float* __restrict__ scales, int n_scales,
+                                                              float* __restrict__ out0, float* __restrict__ out1) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pts * B) return;
+  long long pt = i / B;
+  int b = (int)(i - pt * B);
+  float px = xy_batched ? x[i] : x[pt], py = xy_batched ? y[i] : y[pt];
+  const float* sc = scales + (size_t)b * n_scales;
+  float sx = 0.f, sy = 0.f;
+  for (int g = 0; g < sd.n_gal; ++g) {
+    float ds[DP_NS], dd[DP_ND], ax, ay;
+    scaled_static<float>(sd.base_kind, table + (size_t)7 * g, ds);
+    scaled_dyn<float>(sd, table + (size_t)7 * g, sc, dd);
+    if (sd.base_kind == K_DPIE) piemd_fwd<float>(ds, dd, px, py, ax, ay);
+    else piep_fwd<float>(ds, dd, px, py, ax, ay);
+    sx += ax;
+    sy += ay;
+  }
+  out0[i] = sx;
+  out1[i] = sy;
 }
 
 }  // namespace glk

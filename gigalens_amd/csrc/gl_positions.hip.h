@@ -8,7 +8,7 @@
 // therefore needs mixed second derivatives.  Tensors are tiny (images x batch), so this is four small kernels:
 //   P1  (sample, image):        beta and Hessian           -- profile templates on Dual<float,2>
 //   P2  (sample, family):       statistics + adjoints d loglike / d(beta, det A)
-//   P3  (sample, image, lens):  parameter gradient         -- profile templates on Dual<Dual<float,P>,2>
+//   P3  (sample, image, lens parameter):  gradient         -- profile templates on Dual<Dual<float,1>,2>
 //   P4  (sample, parameter):    sum over images
 #pragma once
 #include <hip/hip_runtime.h>
@@ -34,18 +34,66 @@ struct PosArgs {
   float* ll;            // [B]
   float* chi2;          // [B]
   float* grad;          // [B][P] or null
+  // galaxy catalogues of K_SCALED lenses
+  const CatDev* cats;
+  const float* gal_table;   // [G][7]
+  const float* gal_static;  // [G][DP_NS]
 };
 
-// deflection of one lens at (x, y) with raw parameters p, generic in the real type
-template <class R> __device__ void lens_point(int kind, int iparam, const R* p, R x, R y, R& ax, R& ay) {
+// deflection of one lens at (x, y) with raw parameters p, generic in the real type (catalogues are summed)
+template <class R> __device__ void lens_point(const PosArgs& a, const CompDesc& cd, const R* p, R x, R y, R& ax, R& ay) {
   using namespace glp;
-  switch (kind) {
-    case K_EPL: epl_point<R>(p, iparam, x, y, ax, ay); break;
+  switch (cd.kind) {
+    case K_EPL: epl_point<R>(p, cd.iparam, x, y, ax, ay); break;
     case K_SIE: { R d[SIE_ND + 1]; sie_prep<R>(p, d); sie_fwd<R>(d, x, y, ax, ay); } break;
     case K_NFW: { R d[NFW_ND]; nfw_prep<R>(p, d); nfw_fwd<R>(d, x, y, ax, ay); } break;
     case K_SHEAR: { R d[4]; shear_prep<R>(p, d); shear_fwd<R>(d, x, y, ax, ay); } break;
+    case K_DPIS:
+    case K_DPIE:
+    case K_DPIEP: { R d[DPX_ND]; dpie_prep<R>(cd.kind, p, d); dpie_fwd<R>(cd.kind, d, x, y, ax, ay); } break;
+    case K_SCALED: {
+      const CatDev cat = a.cats[cd.iparam];
+      const ScaledDesc sd{cat.base_kind, cat.n_gal, {cat.col[0], cat.col[1], cat.col[2]}};
+      ax = R(0.f);
+      ay = R(0.f);
+      for (int g = 0; g < cat.n_gal; ++g) {
+        const float* gs = a.gal_static + (size_t)(cat.g_off + g) * DP_NS;
+        R ds[DP_NS], dd[DP_ND], fx, fy;
+        for (int i = 0; i < DP_NS; ++i) ds[i] = R(gs[i]);
+        scaled_dyn<R>(sd, a.gal_table + (size_t)(cat.g_off + g) * 7, p, dd);
+        if (cat.base_kind == K_DPIE) piemd_fwd<R>(ds, dd, x, y, fx, fy);
+        else piep_fwd<R>(ds, dd, x, y, fx, fy);
+        ax += fx;
+        ay += fy;
+      }
+    } break;
     default: { R d[4]; sis_prep<R>(p, d); sis_fwd<R>(d, x, y, ax, ay); } break;
   }
+}
+// what the reference's analytic dPIS Hessian adds to f_xx and f_yy on top of the derivative of the deflection
+// (piemd.py:62-83, see dpis_kappa_excess); zero for every other profile
+template <class R1> __device__ R1 lens_kappa_excess(const PosArgs& a, const CompDesc& cd, const R1* p, float x, float y) {
+  using namespace glp;
+  if (cd.kind == K_DPIS) {
+    R1 d[DPX_ND];
+    dpie_prep<R1>(cd.kind, p, d);
+    return dpis_kappa_excess<R1>(d, d + DP_NS, R1(x), R1(y));
+  }
+  if (cd.kind == K_SCALED) {
+    const CatDev cat = a.cats[cd.iparam];
+    if (cat.base_kind != K_DPIS) return R1(0.f);
+    const ScaledDesc sd{cat.base_kind, cat.n_gal, {cat.col[0], cat.col[1], cat.col[2]}};
+    R1 ex(0.f);
+    for (int g = 0; g < cat.n_gal; ++g) {
+      const float* gs = a.gal_static + (size_t)(cat.g_off + g) * DP_NS;
+      R1 ds[DP_NS], dd[DP_ND];
+      for (int i = 0; i < DP_NS; ++i) ds[i] = R1(gs[i]);
+      scaled_dyn<R1>(sd, a.gal_table + (size_t)(cat.g_off + g) * 7, p, dd);
+      ex += dpis_kappa_excess<R1>(ds, dd, R1(x), R1(y));
+    }
+    return ex;
+  }
+  return R1(0.f);
 }
 
 __global__ void __launch_bounds__(64) gl_pos_p1_kernel(PosArgs a) {
@@ -59,12 +107,14 @@ __global__ void __launch_bounds__(64) gl_pos_p1_kernel(PosArgs a) {
   float bx = a.px[j], by = a.py[j], fxx = 0.f, fxy = 0.f, fyx = 0.f, fyy = 0.f;
   for (int l = 0; l < a.n_lens; ++l) {
     CompDesc cd = a.comps[l];
-    R p[6];
-    for (int k = 0; k < cd.n_par; ++k) p[k] = R(a.params[(size_t)b * a.P + cd.p_off + k]);
+    R p[7];
+    float pf[7];
+    for (int k = 0; k < cd.n_par; ++k) { pf[k] = a.params[(size_t)b * a.P + cd.p_off + k]; p[k] = R(pf[k]); }
     R ax, ay;
-    lens_point<R>(cd.kind, cd.iparam, p, x, y, ax, ay);
+    lens_point<R>(a, cd, p, x, y, ax, ay);
+    const float ex = lens_kappa_excess<float>(a, cd, pf, a.px[j], a.py[j]);
     bx -= ax.v; by -= ay.v;
-    fxx += ax.d[0]; fxy += ax.d[1]; fyx += ay.d[0]; fyy += ay.d[1];
+    fxx += ax.d[0] + ex; fxy += ax.d[1]; fyx += ay.d[0]; fyy += ay.d[1] + ex;
   }
   float* o = a.w_pos + (size_t)i * 6;
   o[0] = bx; o[1] = by; o[2] = fxx; o[3] = fxy; o[4] = fyx; o[5] = fyy;
@@ -111,44 +161,41 @@ __global__ void __launch_bounds__(64) gl_pos_p2_kernel(PosArgs a) {
   }
 }
 
-template <int PL> __device__ void pos_grad_lens(const PosArgs& a, const CompDesc& cd, int b, int j) {
-  using R1 = gld::Dual<float, PL>;
+// one thread per (sample, image, lens-parameter column): the jets carry ONE parameter direction
+// (Dual<Dual<float,1>,2> = 6 floats per value), which keeps every profile's nested-dual code small enough to stay
+// in registers; the (n_params x) repeated evaluation is irrelevant at this size.
+__global__ void __launch_bounds__(64) gl_pos_p3_kernel(PosArgs a, int lens_params) {
+  int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.B * a.J * lens_params) return;
+  const int col = i % lens_params, bj = i / lens_params;
+  const int b = bj / a.J, j = bj - b * a.J;
+  int l = 0;
+  while (l + 1 < a.n_lens && col >= a.comps[l + 1].p_off) ++l;
+  const CompDesc cd = a.comps[l];
+  const int k = col - cd.p_off;
+  using R1 = gld::Dual<float, 1>;
   using R = gld::Dual<R1, 2>;
   R x(R1(a.px[j])), y(R1(a.py[j]));
   x.d[0] = R1(1.f);
   y.d[1] = R1(1.f);
-  R p[PL];
-  for (int k = 0; k < PL; ++k) {
-    R1 v(a.params[(size_t)b * a.P + cd.p_off + k]);
-    v.d[k] = 1.f;
-    p[k] = R(v);
+  R p[7];
+  R1 p1[7];
+  for (int m = 0; m < 7; ++m) {
+    R1 v(m < cd.n_par ? a.params[(size_t)b * a.P + cd.p_off + m] : 0.f);
+    if (m == k) v.d[0] = 1.f;
+    p1[m] = v;
+    p[m] = R(v);
   }
   R ax, ay;
-  lens_point<R>(cd.kind, cd.iparam, p, x, y, ax, ay);
+  lens_point<R>(a, cd, p, x, y, ax, ay);
+  const R1 ex = lens_kappa_excess<R1>(a, cd, p1, a.px[j], a.py[j]);
   const float* q = a.w_pos + ((size_t)b * a.J + j) * 6;
   const float* adj = a.w_adj + ((size_t)b * a.J + j) * 3;
-  float* g = a.w_g + ((size_t)b * a.J + j) * a.P + cd.p_off;
-  for (int k = 0; k < PL; ++k) {
-    // beta = x - sum alpha ;  det = (1-fxx)(1-fyy) - fxy fyx
-    float dbx = -ax.v.d[k], dby = -ay.v.d[k];
-    float ddet = -(1.f - q[5]) * ax.d[0].d[k] - (1.f - q[2]) * ay.d[1].d[k] - q[4] * ax.d[1].d[k] - q[3] * ay.d[0].d[k];
-    g[k] = adj[0] * dbx + adj[1] * dby + adj[2] * ddet;
-  }
-}
-
-__global__ void __launch_bounds__(64) gl_pos_p3_kernel(PosArgs a) {
-  int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= a.B * a.J * a.n_lens) return;
-  int l = i % a.n_lens, bj = i / a.n_lens;
-  int b = bj / a.J, j = bj - b * a.J;
-  CompDesc cd = a.comps[l];
-  switch (cd.kind) {
-    case K_EPL: pos_grad_lens<6>(a, cd, b, j); break;
-    case K_SIE: pos_grad_lens<5>(a, cd, b, j); break;
-    case K_NFW: pos_grad_lens<4>(a, cd, b, j); break;
-    case K_SHEAR: pos_grad_lens<2>(a, cd, b, j); break;
-    default: pos_grad_lens<3>(a, cd, b, j); break;
-  }
+  // beta = x - sum alpha ;  det = (1-fxx)(1-fyy) - fxy fyx
+  const float dbx = -ax.v.d[0], dby = -ay.v.d[0];
+  const float ddet = -(1.f - q[5]) * (ax.d[0].d[0] + ex.d[0]) - (1.f - q[2]) * (ay.d[1].d[0] + ex.d[0]) -
+                     q[4] * ax.d[1].d[0] - q[3] * ay.d[0].d[0];
+  a.w_g[((size_t)b * a.J + j) * a.P + col] = adj[0] * dbx + adj[1] * dby + adj[2] * ddet;
 }
 
 __global__ void __launch_bounds__(64) gl_pos_p4_kernel(PosArgs a, int lens_params) {

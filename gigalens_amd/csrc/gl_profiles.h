@@ -69,6 +69,7 @@ GL_HD int kind_num_params(int kind, int iparam) {
     case K_DPIS: return 5;
     case K_DPIE:
     case K_DPIEP: return 7;
+    case K_SCALED: return (iparam >= 1 && iparam <= 3) ? iparam : -1;  // the population scales
     case K_SERSIC: return 5;
     case K_SERSIC_ELLIPSE: return 7;
     case K_SHAPELETS: return 3 + sh_layers(iparam);

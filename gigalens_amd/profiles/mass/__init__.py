@@ -1,1 +1,2 @@
-from gigalens_amd.profiles.mass import epl, shear, sie, sis, nfw  # noqa: F401
+from gigalens_amd.profiles.mass import (dpie_subhalo, epl, nfw, piemd, piep, scaling_relation, shear, sie,  # noqa: F401
+                                        sis)

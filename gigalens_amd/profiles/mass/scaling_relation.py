@@ -1,0 +1,92 @@
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from gigalens_amd import _native
+from gigalens_amd.profile import MassProfile
+
+_BASE_KINDS = (6, 7, 8)  # dPIS, dPIE, dPIEP
+
+
+class ScalingRelation(MassProfile):
+    """Population of galaxies following luminosity scaling relations
+    (reference: src/gigalens/tf/profiles/mass/scaling_relation.py:6-70).
+
+    Every galaxy ``g`` of ``galaxy_catalogue`` is one ``profile`` whose scaling parameters are
+    ``(lum_g / lum_star) ** power * scale`` and whose other parameters are catalogue columns; the sampled parameters
+    are the scales (``params == scaling_params``).  The native kernels sum the population per pixel inside the fused
+    ray-shooting pass (gl_dpie.h), so no ``(x, y, b, g)`` tensor is ever formed and ``chunk_size`` (the reference's
+    memory bound, :33-36,46) is accepted and unused.
+
+    Built for the dPIE family (``DPIS``, ``DPIE``, ``DPIEP``) with scaling parameters among the amplitude and the
+    two radii -- what ``DPIESubhalo`` (dpie_subhalo.py) uses.
+    """
+
+    _kind = 9
+
+    def __init__(self, profile: MassProfile, scaling_params: List, lum_star: float,
+                 scaling_params_power: Dict[str, float], galaxy_catalogue: Dict[str, List], chunk_size=None, **kwargs):
+        self.profile = profile
+        self._name = f"Scaled-{profile.name}"
+        self._params = list(scaling_params)
+        self.scaling_params = list(scaling_params)
+        super().__init__(**kwargs)
+        if getattr(profile, "_kind", 0) not in _BASE_KINDS:
+            raise NotImplementedError(f"ScalingRelation over {profile.name} is not built (dPIS, dPIE, dPIEP are)")
+        slots = list(profile.params[:3])  # amplitude, inner radius, outer radius
+        bad = [p for p in self.scaling_params if p not in slots]
+        if bad or not self.scaling_params:
+            raise NotImplementedError(f"scaling parameters must be among {slots}, got {self.scaling_params}")
+        self.lum_star = float(lum_star)
+        self.power = {k: float(v) for k, v in scaling_params_power.items()}
+        self.galaxy_cat = galaxy_catalogue
+        self._luminosities = np.asarray(galaxy_catalogue["lum"], dtype=np.float32)
+        self.n_galaxy = len(self._luminosities)
+        self.chunk_size = self.n_galaxy if chunk_size is None else chunk_size
+        constants = getattr(profile, "constants", [])
+        self.not_scaling_params = [p for p in list(profile.params) + list(constants) if p not in self.scaling_params]
+        missing = [p for p in self.not_scaling_params if p not in galaxy_catalogue]
+        if missing:
+            raise KeyError(f"galaxy catalogue lacks the columns {missing}")
+        self._slots = slots
+        self._dev_table = None
+
+    # -- what the native library consumes (include/gigalens_hip.h: gl_model_set_catalogue) --------------------------
+    def _component(self):
+        return (self._kind, len(self.scaling_params), 0)
+
+    def _unscaled(self):
+        """``(L/L*)^power`` in float32 (scaling_relation.py:27-30,52-55)."""
+        lum = torch.from_numpy(self._luminosities)
+        return {k: ((lum / torch.tensor(self.lum_star, dtype=torch.float32))
+                    ** torch.tensor(self.power[k], dtype=torch.float32)).numpy() for k in self.scaling_params}
+
+    def _catalogue(self):
+        """(base_kind, scale_col[3], table [G,7]) in the row layout of gl_dpie.h."""
+        t = np.zeros((self.n_galaxy, 7), dtype=np.float32)
+        unscaled = self._unscaled()
+        cols = []
+        for k, name in enumerate(self._slots):
+            if name in self.scaling_params:
+                t[:, k] = unscaled[name]
+                cols.append(self.scaling_params.index(name))
+            else:
+                t[:, k] = np.asarray(self.galaxy_cat[name], dtype=np.float32)
+                cols.append(-1)
+        t[:, 3] = np.asarray(self.galaxy_cat["center_x"], dtype=np.float32)
+        t[:, 4] = np.asarray(self.galaxy_cat["center_y"], dtype=np.float32)
+        if "e1" in self.profile.params:
+            t[:, 5] = np.asarray(self.galaxy_cat["e1"], dtype=np.float32)
+            t[:, 6] = np.asarray(self.galaxy_cat["e2"], dtype=np.float32)
+        return self.profile._kind, cols, t
+
+    def deriv(self, x, y, **scales):
+        """scaling_relation.py:61-70."""
+        return _native.scaled_eval(self, x, y, scales)
+
+    def hessian(self, x, y, **scales):
+        raise NotImplementedError("hessian / convergence / shear maps are not built; the image-position likelihood "
+                                  "evaluates the catalogue's Hessian natively (gl_positions.hip.h)")
+
+    convergence = shear = hessian

@@ -143,6 +143,9 @@ class LensSimulator(LensSimulatorInterface):
         self._model = _native.Model(comps, len(phys_model.lenses), len(phys_model.lens_light),
                                     len(phys_model.source_light), Hs, Ws, ss, img_X, img_Y, pix_index,
                                     self.conversion_factor, psf)
+        for i, lens in enumerate(phys_model.lenses):  # galaxy catalogues of ScalingRelation lenses
+            if hasattr(lens, "_catalogue"):
+                self._model.set_catalogue(i, *lens._catalogue())
         self._layout = phys_model._packing()
         assert self._layout.P == self._model.P
 

@@ -16,7 +16,9 @@ from gigalens_amd.model import PhysicalModel
 from gigalens_amd.profiles.light.sersic import Sersic, SersicEllipse
 from gigalens_amd.profiles.light.shapelets import Shapelets
 from gigalens_amd.profiles.mass.epl import EPL
+from gigalens_amd.profiles.mass.dpie_subhalo import DPIESubhalo
 from gigalens_amd.profiles.mass.nfw import NFW
+from gigalens_amd.profiles.mass.piemd import DPIE
 from gigalens_amd.profiles.mass.shear import Shear
 from gigalens_amd.profiles.mass.sie import SIE
 from gigalens_amd.simulator import SimulatorConfig
@@ -56,7 +58,7 @@ def _sersic_src_prior(center_sigma=0.25, uniform_center=None):
 
 
 def make(name: str, num_pix: Optional[int] = None, batch: Optional[int] = None, interpolate: bool = True,
-         n_max: int = 10, n_halos: int = 8, n_sources: int = 20) -> Workload:
+         n_max: int = 10, n_halos: int = 8, n_sources: int = 20, n_galaxies: int = 200) -> Workload:
     name = name.upper()
     if name == "C1":  # SIE + Sersic source, 64x64, B=1
         phys = PhysicalModel([SIE()], [], [Sersic()])
@@ -96,7 +98,34 @@ def make(name: str, num_pix: Optional[int] = None, batch: Optional[int] = None, 
             source_light=tfd.JointDistributionSequential([_sersic_src_prior(uniform_center=4.0) for _ in range(n_sources)])))
         return Workload("C4", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 256), batch or 512,
                         description=f"cluster: {n_halos} NFW halos + {n_sources} Sersic sources")
+    if name == "C6":  # cluster with member galaxies: dPIE halo + DPIESubhalo catalogue + Sersic sources
+        cat = galaxy_catalogue(n_galaxies, half_width=0.5 * 0.065 * (num_pix or 256))
+        phys = PhysicalModel([DPIE(), DPIESubhalo(lum_star=1.0, galaxy_catalogue=cat)], [],
+                             [Sersic() for _ in range(n_sources)])
+        halo = tfd.JointDistributionNamed(dict(
+            theta_E=tfd.LogNormal(math.log(12.0), 0.1), r_core=tfd.LogNormal(math.log(3.0), 0.2),
+            r_cut=tfd.LogNormal(math.log(150.0), 0.1), center_x=tfd.Normal(0, 0.3), center_y=tfd.Normal(0, 0.3),
+            e1=tfd.Normal(0.15, 0.05), e2=tfd.Normal(-0.1, 0.05)))
+        members = tfd.JointDistributionNamed(dict(
+            theta_E=tfd.LogNormal(math.log(0.3), 0.2), r_core=tfd.LogNormal(math.log(0.02), 0.2),
+            r_cut=tfd.LogNormal(math.log(2.0), 0.3)))
+        prior = tfd.JointDistributionNamed(dict(
+            lens_mass=tfd.JointDistributionSequential([halo, members]),
+            source_light=tfd.JointDistributionSequential([_sersic_src_prior(uniform_center=3.0) for _ in range(n_sources)])))
+        return Workload("C6", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 256), batch or 128,
+                        description=f"cluster: dPIE halo + {n_galaxies} scaled dPIE member galaxies + {n_sources} "
+                        "Sersic sources")
     raise ValueError(f"unknown workload {name}")
+
+
+def galaxy_catalogue(n_galaxies: int, half_width: float, seed: int = 11):
+    """Synthetic cluster-member catalogue (luminosities, positions, ellipticities) for ScalingRelation workloads."""
+    r = np.random.default_rng(seed)
+    return dict(lum=r.lognormal(-0.3, 0.6, n_galaxies).astype(np.float32),
+                center_x=r.uniform(-half_width, half_width, n_galaxies).astype(np.float32),
+                center_y=r.uniform(-half_width, half_width, n_galaxies).astype(np.float32),
+                e1=np.clip(r.normal(0, 0.15, n_galaxies), -0.5, 0.5).astype(np.float32),
+                e2=np.clip(r.normal(0, 0.15, n_galaxies), -0.5, 0.5).astype(np.float32))
 
 
 def synthetic_observation(wl: Workload, simulator_cls, seed_truth=1, seed_noise=2):

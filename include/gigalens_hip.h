@@ -44,6 +44,13 @@ typedef enum gl_kind {
   GL_NFW = 3,   /* tf/profiles/mass/nfw.py:8    [Rs,alpha_Rs,center_x,center_y] */
   GL_SHEAR = 4, /* tf/profiles/mass/shear.py:8  [gamma1,gamma2] */
   GL_SIS = 5,   /* tf/profiles/mass/sis.py:7    [theta_E,center_x,center_y] */
+  GL_DPIS = 6,  /* tf/profiles/mass/piemd.py:27 [theta_E,r_core,r_cut,center_x,center_y] */
+  GL_DPIE = 7,  /* tf/profiles/mass/piemd.py:99 [theta_E,r_core,r_cut,center_x,center_y,e1,e2] */
+  GL_DPIEP = 8, /* tf/profiles/mass/piep.py:23  [theta_E,Ra,Rs,center_x,center_y,e1,e2] */
+  GL_SCALED = 9, /* tf/profiles/mass/scaling_relation.py:6-70 (DPIESubhalo, dpie_subhalo.py:6-21): a catalogue of
+                    galaxies of one dPIE-family profile whose theta_E / r_core / r_cut follow (L/L*)^power * scale;
+                    the packed parameters are the scales, in the order of the reference's `scaling_params`;
+                    iparam = their number (1..3); the catalogue is attached with gl_model_set_catalogue */
   /* light profiles: LightProfile.light (profile.py:24-60) */
   GL_SERSIC = 16,         /* tf/profiles/light/sersic.py:23-24 [R_sersic,n_sersic,center_x,center_y,Ie] */
   GL_SERSIC_ELLIPSE = 17, /* sersic.py:68-69 [R_sersic,n_sersic,e1,e2,center_x,center_y,Ie] */
@@ -56,7 +63,7 @@ typedef enum gl_kind {
 
 typedef struct gl_component {
   int32_t kind;   /* gl_kind */
-  int32_t iparam; /* EPL: niter cap (epl.py:15, default 50); SHAPELETS: n_max; else 0 */
+  int32_t iparam; /* EPL: niter cap (epl.py:15, default 50); SHAPELETS: n_max; SCALED: number of scales; else 0 */
   uint32_t flags; /* GL_FLAG_* */
   int32_t reserved;
 } gl_component;
@@ -156,6 +163,24 @@ int gl_model_set_positions(gl_model* m, int n_families, const int* family_sizes,
                            const float* err_x, const float* err_y);
 int gl_positions_fwd_bwd(const gl_model* m, const float* params, int B, float* loglike, float* chi2,
                          float* grad_params_or_null, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Galaxy catalogue of a GL_SCALED component (ScalingRelation.__init__, scaling_relation.py:27-55).  Must be attached
+ * to every GL_SCALED component before gl_workspace_bytes / any compute call (the workspace holds one block of
+ * constants per sample and galaxy).
+ *   base_kind  GL_DPIS, GL_DPIE or GL_DPIEP (`profile`)
+ *   table      HOST [n_galaxies][7] rows (theta_E, r_core, r_cut, center_x, center_y, e1, e2): for a scaling
+ *              parameter the entry is (L_g/L*)^power (`_unscaled_params`, :52-55), otherwise the catalogue constant
+ *              (`_galaxy_constants`, :48-51; e1, e2 ignored for GL_DPIS)
+ *   scale_col  for theta_E, r_core, r_cut: position of its scale inside the component's parameter row, or -1 when
+ *              the quantity is a catalogue constant */
+int gl_model_set_catalogue(gl_model* m, int component, int base_kind, int n_galaxies, const int32_t scale_col[3],
+                           const float* table);
+
+/* ScalingRelation.deriv on arbitrary points (scaling_relation.py:61-70); arguments as gl_profile_eval, with
+ * table a DEVICE pointer [n_galaxies][7] and scales [B][n_scales]. */
+int gl_scaled_eval(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev, const float* x,
+                   const float* y, int64_t n_pts, int B, int xy_batched, const float* scales, int n_scales,
+                   float* out0, float* out1, void* hip_stream);
 
 /* Plugin-level point evaluation, the reference's MassProfile.deriv / LightProfile.light called on
  * arbitrary coordinates (tests/test_profiles.py calls exactly these):

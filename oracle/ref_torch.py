@@ -704,17 +704,16 @@ def stats_pixels(simulator: RefSimulator, params, observed_image, background_rms
 # image-position likelihood (tf/model.py:103-124, tf/simulator.py:72-91, tf/profile.py:9-43)
 # --------------------------------------------------------------------------
 def lens_hessian_autodiff(simulator: RefSimulator, x, y, lens_params):
-    """Sum over lenses of the autodiff Hessian of ``deriv`` (tf/profile.py:9-27, tf/simulator.py:80-88).
-    The reference overrides it analytically for NFW / Shear / SIS; those closed forms equal the derivative of
-    the deflection away from the clamps, so one autodiff path serves as the oracle for every profile."""
+    """Sum over lenses of ``lens.hessian`` (tf/simulator.py:80-88): autodiff of ``deriv`` by default
+    (tf/profile.py:9-27); the reference overrides it analytically for NFW / Shear / SIS (closed forms equal to that
+    derivative away from the clamps, so autodiff serves) and for dPIS / dPIE / ScalingRelation (``mass_hessian``:
+    the dPIS override is NOT the derivative of its deflection and is restated as written)."""
     x = x.clone().requires_grad_(True)
     y = y.clone().requires_grad_(True)
     fxx = fxy = fyx = fyy = 0
     consts = simulator._consts("lenses_constants", len(simulator.phys_model.lenses))
     for lens, p, c in zip(simulator.phys_model.lenses, lens_params, consts):
-        fx, fy = mass_deriv(lens, x, y, **p, **c)
-        a, b = torch.autograd.grad(fx.sum(), [x, y], create_graph=True)
-        cc, d = torch.autograd.grad(fy.sum(), [x, y], create_graph=True)
+        a, b, cc, d = mass_hessian(lens, x, y, **p, **c)
         fxx, fxy, fyx, fyy = fxx + a, fxy + b, fyx + cc, fyy + d
     return fxx, fxy, fyx, fyy
 

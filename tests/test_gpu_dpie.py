@@ -1,0 +1,209 @@
+"""GPU parity for the dPIE family and ScalingRelation: plugin-level deriv, the fused pixel likelihood
+with a galaxy catalogue, the unconstrained-space entry and the image-position likelihood -- HIP path vs the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.test_gpu_parity import GRAD_RTOL, IMG_RTOL, LL_RTOL, gl  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _pts(n, seed=0, scale=3.0):
+    r = np.random.default_rng(seed)
+    return (r.normal(size=n) * scale).astype(np.float32), (r.normal(size=n) * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("cls,kw", [
+    ("DPIS", dict(theta_E=1.1, r_core=0.2, r_cut=4.0, center_x=0.05, center_y=-0.1)),
+    ("DPIS", dict(theta_E=0.7, r_core=3.0, r_cut=0.5, center_x=0.0, center_y=0.0)),
+    ("DPIE", dict(theta_E=1.3, r_core=0.2, r_cut=5.0, center_x=0.1, center_y=-0.2, e1=0.2, e2=-0.15)),
+    ("DPIE", dict(theta_E=25.0, r_core=8.0, r_cut=300.0, center_x=1.0, center_y=-2.0, e1=-0.3, e2=0.25)),
+    ("DPIEP", dict(theta_E=1.3, Ra=0.2, Rs=5.0, center_x=0.1, center_y=-0.2, e1=0.2, e2=-0.15)),
+])
+def test_dpie_family_deriv(gl, cls, kw):
+    """The reference's profile-test recipe (tests/test_profiles.py:50-58: 10 000 normal points, rtol 1e-5 / atol 1e-4)."""
+    from gigalens_amd.profiles.mass import piemd, piep
+    from oracle import ref_torch as ref
+    prof = {"DPIS": piemd.DPIS, "DPIE": piemd.DPIE, "DPIEP": piep.DPIEP}[cls]()
+    x, y = _pts(10000)
+    fx, fy = prof.deriv(x=x, y=y, **kw)
+    ox, oy = ref.mass_deriv(prof, torch.as_tensor(x, dtype=F64), torch.as_tensor(y, dtype=F64), **kw)
+    sc = float(ox.abs().max())
+    if kw.get("r_core", 0.0) > kw.get("r_cut", 1.0):
+        # swapped radii collapse to rt - rc = r_min = 1e-4 (piemd.py:52-60): the deflection is ~ 1/(rt - rc) with the
+        # difference formed from fp32 radii (ulp(0.5)/1e-4 ~ 3e-4) -- conditioning of the input, in any fp32 evaluation
+        assert np.allclose(fx.cpu().numpy(), ox.numpy(), rtol=2e-3, atol=2e-3 * sc)
+        assert np.allclose(fy.cpu().numpy(), oy.numpy(), rtol=2e-3, atol=2e-3 * sc)
+        return
+    assert np.allclose(fx.cpu().numpy(), ox.numpy(), rtol=1e-5, atol=1e-4)
+    assert np.allclose(fy.cpu().numpy(), oy.numpy(), rtol=1e-5, atol=1e-4)
+    assert np.median(np.abs(fx.cpu().numpy() - ox.numpy())) < 5e-7 * sc
+    # batched parameters on the trailing axis
+    te = np.array([0.5, 1.0, 2.0], dtype=np.float32)
+    kb = dict(kw, theta_E=te)
+    fxb, _ = prof.deriv(x=x[:50, None], y=y[:50, None], **kb)
+    assert fxb.shape == (50, 3)
+    assert torch.allclose(fxb[:, 1] * 2, fxb[:, 2], rtol=1e-5, atol=1e-6)
+
+
+def _subhalo(n_gal, base="dPIE", scaling=("theta_E", "r_core", "r_cut")):
+    from gigalens_amd import workloads
+    from gigalens_amd.profiles.mass.dpie_subhalo import DPIESubhalo
+    from gigalens_amd.profiles.mass.piemd import DPIS
+    from gigalens_amd.profiles.mass.scaling_relation import ScalingRelation
+    cat = workloads.galaxy_catalogue(n_gal, half_width=1.2)
+    if base == "dPIE":
+        return DPIESubhalo(lum_star=1.3, galaxy_catalogue=cat, scaling_params_power={"theta_E": 0.5, "r_core": 0.5, "r_cut": 0.4})
+    cat = dict(cat, r_core=np.full(n_gal, 0.03, dtype=np.float32))
+    return ScalingRelation(DPIS(), list(scaling), 1.3, {"theta_E": 0.5, "r_core": 0.5, "r_cut": 0.4}, cat)
+
+
+@pytest.mark.parametrize("base,scaling", [("dPIE", ("theta_E", "r_core", "r_cut")), ("dPIS", ("r_cut", "theta_E"))])
+def test_scaling_relation_deriv(gl, base, scaling):
+    from oracle import ref_torch as ref
+    prof = _subhalo(23, base, scaling)
+    x, y = _pts(4000, 3, scale=1.0)
+    true = {"theta_E": np.array([0.3, 0.5], np.float32), "r_core": np.array([0.03, 0.05], np.float32),
+            "r_cut": np.array([1.5, 2.5], np.float32)}
+    scales = {k: true[k] for k in prof.params}
+    fx, fy = prof.deriv(x[:, None], y[:, None], **scales)
+    ox, oy = ref.mass_deriv(prof, torch.as_tensor(x, dtype=F64)[:, None], torch.as_tensor(y, dtype=F64)[:, None],
+                            **{k: torch.as_tensor(v, dtype=F64) for k, v in scales.items()})
+    sc = float(ox.abs().max())
+    assert np.allclose(fx.cpu().numpy(), ox.numpy(), rtol=1e-5, atol=2e-5 * sc)
+    assert np.allclose(fy.cpu().numpy(), oy.numpy(), rtol=1e-5, atol=2e-5 * sc)
+
+
+def _mixed_cluster(num_pix, batch):
+    """dPIS + dPIEP halos and a dPIS catalogue scaled in (r_cut, theta_E) -- the members of the family C6 lacks."""
+    from gigalens_amd import prior as tfd
+    from gigalens_amd import workloads
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.profiles.mass.piemd import DPIS
+    from gigalens_amd.profiles.mass.piep import DPIEP
+    from gigalens_amd.simulator import SimulatorConfig
+    J, S = tfd.JointDistributionNamed, tfd.JointDistributionSequential
+    sub = _subhalo(9, "dPIS", ("r_cut", "theta_E"))
+    phys = PhysicalModel([DPIS(), DPIEP(), sub], [], [Sersic(), Sersic()])
+    dpis = J(dict(theta_E=tfd.LogNormal(math.log(0.5), 0.1), r_core=tfd.LogNormal(math.log(0.05), 0.2),
+                  r_cut=tfd.LogNormal(math.log(1.5), 0.2), center_x=tfd.Normal(0.4, 0.05), center_y=tfd.Normal(-0.3, 0.05)))
+    piep = J(dict(theta_E=tfd.LogNormal(math.log(0.9), 0.1), Ra=tfd.LogNormal(math.log(0.1), 0.2),
+                  Rs=tfd.LogNormal(math.log(4.0), 0.2), center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05),
+                  e1=tfd.Normal(0.15, 0.05), e2=tfd.Normal(-0.1, 0.05)))
+    mem = J(dict(r_cut=tfd.LogNormal(math.log(0.8), 0.2), theta_E=tfd.LogNormal(math.log(0.08), 0.2)))
+    src = lambda: J(dict(R_sersic=tfd.LogNormal(math.log(0.2), 0.1), n_sersic=tfd.Uniform(1, 3),
+                         center_x=tfd.Normal(0, 0.15), center_y=tfd.Normal(0, 0.15), Ie=tfd.LogNormal(math.log(50.0), 0.3)))
+    prior = J(dict(lens_mass=S([dpis, piep, mem]), source_light=S([src(), src()])))
+    return workloads.Workload("MIX", phys, prior, SimulatorConfig(delta_pix=0.08, num_pix=num_pix), batch)
+
+
+def _make(gl, name, kw):
+    return _mixed_cluster(**kw) if name == "MIX" else gl.workloads.make(name, **kw)
+
+
+@pytest.mark.parametrize("name,kw", [("C6", dict(num_pix=32, batch=3, n_galaxies=12, n_sources=2)),
+                                     ("C6", dict(num_pix=45, batch=2, n_galaxies=40, n_sources=3)),
+                                     ("MIX", dict(num_pix=36, batch=4))])
+def test_cluster_simulate_loglike_grad_vs_oracle(gl, name, kw):
+    wl = _make(gl, name, kw)
+    obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    packed = H.sample_packed(wl, sim, seed=11)
+    obs_np = obs.cpu().numpy()
+    ll_o, red_o, g_o, img_o = H.oracle_loglike_and_grad(wl, packed.cpu().double(), obs_np, None, wl.batch)
+    img = sim.simulate(packed).cpu().numpy().reshape(img_o.shape)
+    assert np.abs(img - img_o).max() <= 5 * IMG_RTOL * np.abs(img_o).max() + 1e-7
+    pm = gl.ForwardProbModel(wl.prior, obs_np, wl.background_rms, wl.exp_time, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, red = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    # loglike = -(chi2 + norm)/2 with norm < 0 here (sigma^2 < 1/2pi): the two ~N-sized terms nearly cancel, so the
+    # tolerance is relative to chi2, not to their difference
+    n_pix = wl.sim_config.num_pix ** 2
+    assert np.all(np.abs(ll.detach().cpu().numpy() - ll_o) <= 5 * LL_RTOL * np.maximum(np.abs(ll_o), red_o * n_pix))
+    assert np.allclose(red.detach().cpu().numpy(), red_o, rtol=5 * LL_RTOL)
+    g = p.grad.cpu().numpy()
+    scale = np.maximum(np.abs(g_o).max(axis=1, keepdims=True), 1e-3 * np.abs(g_o).max())
+    # per-column scale as well: amplitudes and radii of a cluster halo differ by orders of magnitude
+    bad = np.abs(g - g_o) > GRAD_RTOL * np.maximum(np.abs(g_o), 1e-2 * scale) + 1e-6
+    assert not bad.any(), (np.argwhere(bad)[:5], g[bad][:5], g_o[bad][:5])
+    # image-boundary pair (gl_simulate_fwd / gl_simulate_bwd)
+    p2 = packed.clone().requires_grad_(True)
+    im = sim.simulate(p2).reshape(wl.batch, wl.sim_config.num_pix, wl.sim_config.num_pix)
+    sig2 = wl.background_rms ** 2 + im / wl.exp_time
+    ll3 = -0.5 * (((im - obs) ** 2 / sig2).sum((-2, -1)) + torch.log(2 * math.pi * sig2).sum((-2, -1)))
+    ll3.sum().backward()
+    g3 = p2.grad.cpu().numpy()
+    bad = np.abs(g3 - g_o) > GRAD_RTOL * np.maximum(np.abs(g_o), 1e-2 * scale) + 1e-6
+    assert not bad.any(), (np.argwhere(bad)[:5], g3[bad][:5], g_o[bad][:5])
+
+
+def test_cluster_fused_log_prob_matches_unfused(gl):
+    wl = gl.workloads.make("C6", num_pix=40, batch=6, n_galaxies=30, n_sources=3)
+    obs, _, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    pm = gl.ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time, include_positions=False)
+    z = pm.bij.inverse(wl.prior.sample(wl.batch, seed=4)).to(sim.device)
+    z1 = z.clone().requires_grad_(True)
+    lp1, red1 = pm.log_prob(sim, z1)
+    lp1.sum().backward()
+    z2 = z.clone().requires_grad_(True)
+    lp2, red2 = pm.log_prob_unfused(sim, z2)
+    lp2.sum().backward()
+    assert torch.allclose(lp1, lp2, rtol=2e-5)
+    assert torch.allclose(red1, red2, rtol=2e-5)
+    sc = z2.grad.abs().max(dim=1, keepdim=True).values
+    assert torch.all((z1.grad - z2.grad).abs() <= 2e-4 * sc + 1e-5)
+
+
+def test_catalogue_errors(gl):
+    from gigalens_amd import _native
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.scaling_relation import ScalingRelation
+    with pytest.raises(NotImplementedError):
+        ScalingRelation(EPL(), ["theta_E"], 1.0, {"theta_E": 0.5}, dict(lum=[1.0]))
+    wl = gl.workloads.make("C6", num_pix=16, batch=2, n_galaxies=5, n_sources=1)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=2)
+    with pytest.raises(_native.NativeLibraryError):  # component 0 is the dPIE halo, not a GL_SCALED lens
+        sim._model.set_catalogue(0, 7, [0, 1, 2], np.zeros((3, 7), np.float32))
+    with pytest.raises(_native.NativeLibraryError):  # a scale driving nothing
+        sim._model.set_catalogue(1, 7, [0, 1, -1], np.zeros((3, 7), np.float32))
+
+
+CX = [np.array([2.1, -1.9, 0.3, -0.4], np.float32), np.array([1.5, -1.4], np.float32)]
+CY = [np.array([0.4, -0.2, 2.0, -2.1], np.float32), np.array([-1.5, 1.6], np.float32)]
+EX = [np.array([0.01, 0.02, 0.015, 0.01], np.float32), np.array([0.03, 0.02], np.float32)]
+EY = [np.array([0.012, 0.02, 0.01, 0.02], np.float32), np.array([0.02, 0.025], np.float32)]
+
+
+@pytest.mark.parametrize("name,kw", [("MIX", dict(num_pix=24, batch=4)),
+                                     ("C6", dict(num_pix=24, batch=3, n_galaxies=10, n_sources=1))])
+def test_cluster_stats_positions_vs_oracle(gl, name, kw):
+    """dPIE's analytic Hessian equals the derivative of its deflection; dPIS's carries (rc+rt)/rt on kappa
+    (piemd.py:73-74) -- both as the reference evaluates them (tf/simulator.py:83-84), catalogue members included."""
+    from oracle import ref_torch as ref
+    wl = _make(gl, name, kw)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    packed = H.sample_packed(wl, sim, seed=6)
+    sc = 6.0 if name == "C6" else 1.0  # put the images outside the cluster core
+    cx, cy = [c * sc for c in CX], [c * sc for c in CY]
+    pm = gl.ForwardProbModel(wl.prior, centroids_x=cx, centroids_y=cy, centroids_errors_x=EX, centroids_errors_y=EY,
+                             include_pixels=False, include_positions=True)
+    p = packed.clone().requires_grad_(True)
+    ll, red = pm.stats_positions(sim, p)
+    ll.sum().backward()
+    rs = ref.RefSimulator(wl.phys_model, wl.sim_config, wl.batch, dtype=F64)
+    p64 = packed.cpu().double().requires_grad_(True)
+    ll_o, red_o = ref.stats_positions(rs, H.struct_from_packed(wl.phys_model, p64), cx, cy, EX, EY)
+    (g_o,) = torch.autograd.grad(ll_o.sum(), p64)
+    assert np.allclose(ll.detach().cpu().numpy(), ll_o.detach().numpy(), rtol=1e-4)
+    assert np.allclose(red.detach().cpu().numpy(), red_o.detach().numpy(), rtol=1e-4)
+    g, go = p.grad.cpu().numpy(), g_o.numpy()
+    scale = np.abs(go).max(axis=1, keepdims=True)
+    assert np.all(np.abs(g - go) <= 2e-3 * np.maximum(np.abs(go), 1e-2 * scale) + 1e-6), (np.abs(g - go) / scale).max()
