@@ -139,7 +139,7 @@ Workspace carve(const gl_model* m, int B, void* base) {
   off += align_up((size_t)B * sizeof(int), 256);
   if (m->G) {
     w.gal_dyn = (float*)(p + off);
-    off += align_up((size_t)B * m->G * DP_ND * sizeof(float), 256);
+    off += align_up((size_t)B * m->G * GM_ND * sizeof(float), 256);
   }
   if (m->pos_J) {
     auto take = [&](size_t n) { float* q = (float*)(p + off); off += align_up(n * sizeof(float), 256); return q; };
@@ -287,6 +287,7 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.gal_static = m->d_gal_static;
   a.gal_dyn = w.gal_dyn;
   a.G = m->G;
+  a.scaled_first = m->cats.empty() ? -1 : m->cats[0].dev.comp;
   return a;
 }
 
@@ -308,7 +309,7 @@ int run_galprep(const gl_model* m, const float* params, int B, const Workspace& 
   if (!m->G) return GL_OK;
   long long total = (long long)B * m->G;
   hipLaunchKernelGGL(gl_galprep_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, m->d_comps,
-                     m->d_cats, (int)m->cats.size(), params, m->P, B, m->d_gal_table, w.gal_dyn, m->G);
+                     m->d_cats, (int)m->cats.size(), params, m->P, B, m->d_gal_table, m->d_gal_static, w.gal_dyn, m->G);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

@@ -22,7 +22,7 @@ namespace glp {
 constexpr int DP_NS = 12;  // floats per static block
 constexpr int DP_ND = 12;  // floats per dynamic block
 enum { DPS_CX = 0, DPS_CY, DPS_CPHI, DPS_SPHI,
-       DPS_Q = 4, DPS_IQ, DPS_S2, DPS_IX, DPS_IY, DPS_Z,  // DPIE
+       DPS_Q = 4, DPS_IQ, DPS_S2, DPS_IX, DPS_IY, DPS_Z, DPS_ZL /* Z ln2/2 */,  // DPIE
        DPS_M1 = 4, DPS_P1 };                              // DPIS / DPIEP: 1 - e, 1 + e
 enum { DPD_RC = 0, DPD_RT, DPD_S, DPD_DR2 /* rc^2 - rt^2 */, DPD_W = 4 /* 6 floats */, DPD_DR = 10 /* rt - rc */ };
 // free-standing halo: [static | dynamic | d(static e-terms)/de], see dpie_prep
@@ -83,7 +83,7 @@ template <class R> GL_HD void piemd_static(R e1, R e2, R cx, R cy, R* ds, R* de)
   ds[DPS_IX] = (R)1 / (ope * ope);
   ds[DPS_IY] = (R)1 / (ome * ome);
   ds[DPS_Z] = (R)-0.5 * ((R)1 - e * e) / sqe;  // zci_im; e == 0 -> -inf, the reference's NaN deflection
-  ds[10] = (R)0;
+  ds[DPS_ZL] = ds[DPS_Z] * (R)(0.5 * kLn2);
   ds[11] = (R)0;
   if (de) {
     de[0] = (R)-2 / (ope * ope);

@@ -14,6 +14,7 @@
 #include "gl_profiles.h"
 #include "gl_dpie.h"
 #include "gl_vec.hip.h"
+#include "gl_members.hip.h"
 
 namespace glk {
 using namespace glp;
@@ -63,11 +64,12 @@ struct MainArgs {
   int shp_stride;
   const int* order;  // cost-ordered dispatch: blockIdx.y -> sample index (heaviest first), or null
   unsigned parts;    // forward-only partial renders (tf/simulator.py:242-328): bit0 deflect, bit1 lens light, bit2 sources
-  // galaxy catalogues (K_SCALED): per-galaxy static blocks [G][DP_NS], per-(sample, galaxy) blocks [B][G][DP_ND]
+  // galaxy catalogues (K_SCALED): per-galaxy static blocks [G][DP_NS], per-(sample, galaxy) blocks [B][G][GM_ND]
   const CatDev* cats;
   const float* gal_static;
   const float* gal_dyn;
   int G;
+  int scaled_first;  // the K_SCALED lens whose scale tangents ride along the ray-shooting pass (-1: none)
 };
 
 // ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
@@ -256,8 +258,9 @@ __global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restric
 __global__ void __launch_bounds__(128) gl_galprep_kernel(const CompDesc* __restrict__ comps,
                                                          const CatDev* __restrict__ cats, int n_cats,
                                                          const float* __restrict__ params, int P, int B,
-                                                         const float* __restrict__ table, float* __restrict__ gal_dyn,
-                                                         int G) {
+                                                         const float* __restrict__ table,
+                                                         const float* __restrict__ gal_static,
+                                                         float* __restrict__ gal_dyn, int G) {
   int i = blockIdx.x * 128 + threadIdx.x;
   if (i >= B * G) return;
   int b = i / G, g = i - b * G;
@@ -265,8 +268,8 @@ __global__ void __launch_bounds__(128) gl_galprep_kernel(const CompDesc* __restr
   while (c + 1 < n_cats && g >= cats[c + 1].g_off) ++c;
   const CatDev cat = cats[c];
   ScaledDesc sd{cat.base_kind, cat.n_gal, {cat.col[0], cat.col[1], cat.col[2]}};
-  scaled_dyn<float>(sd, table + (size_t)7 * g, params + (size_t)b * P + comps[cat.comp].p_off,
-                    gal_dyn + ((size_t)b * G + g) * DP_ND);
+  member_dyn(sd, table + (size_t)7 * g, gal_static + (size_t)g * DP_NS, params + (size_t)b * P + comps[cat.comp].p_off,
+             gal_dyn + ((size_t)b * G + g) * GM_ND);
 }
 
 // cost-ordered dispatch: samples sorted by descending EPL trip count (the only data-dependent cost on the
@@ -452,6 +455,12 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
       pidx[t] = a.pix ? a.pix[jj] : jj;
       bx[t] = x[t]; by[t] = y[t]; m[t] = 0.f;
     }
+    constexpr bool GRADMODE = (MODE == IMG_BWD || MODE == LL_GRAD);
+    ScaleTan<v2f> tans[DP ? (T + 1) / 2 : 1];
+    if constexpr (DP && GRADMODE) {
+#pragma unroll
+      for (int t = 0; t < (T + 1) / 2; ++t) tans[t] = ScaleTan<v2f>{v2f(0.f), v2f(0.f), v2f(0.f), v2f(0.f), v2f(0.f), v2f(0.f)};
+    }
     // ---- phase 1: ray-shoot  beta = (x,y) - sum_i alpha_i(x,y)   (tf/simulator.py:72-78) ----
     for (int l = 0; l < ((a.parts & 1u) ? n_lens : 0); ++l) {
       const int kind = comps[l].kind;
@@ -496,28 +505,18 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             for (int t = 0; t < T; ++t) { float ax, ay; piep_fwd<float>(d, d + DP_NS, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
           }
           break;
-        case K_SCALED: if constexpr (DP) {  // sum over the catalogue (scaling_relation.py:61-70); member constants via wave-uniform loads
+        case K_SCALED: if constexpr (DP) {  // sum over the catalogue (scaling_relation.py:61-70), gl_members.hip.h
           const CatDev cat = a.cats[comps[l].iparam];
           const float* __restrict__ gs = a.gal_static + (size_t)cat.g_off * DP_NS;
-          const float* __restrict__ gd = a.gal_dyn + ((size_t)b * a.G + cat.g_off) * DP_ND;
-          if (cat.base_kind == K_DPIE) {
-            for (int g = 0; g < cat.n_gal; ++g) {
+          const float* __restrict__ gm = a.gal_dyn + ((size_t)b * a.G + cat.g_off) * GM_ND;
+          const bool carry = GRADMODE && l == a.scaled_first;
 #pragma unroll
-              for (int t = 0; t < T; ++t) {
-                float ax, ay;
-                piemd_fwd<float>(gs + g * DP_NS, gd + g * DP_ND, x[t], y[t], ax, ay);
-                bx[t] -= ax; by[t] -= ay;
-              }
-            }
-          } else {
-            for (int g = 0; g < cat.n_gal; ++g) {
-#pragma unroll
-              for (int t = 0; t < T; ++t) {
-                float ax, ay;
-                piep_fwd<float>(gs + g * DP_NS, gd + g * DP_ND, x[t], y[t], ax, ay);
-                bx[t] -= ax; by[t] -= ay;
-              }
-            }
+          for (int t = 0; t < T; t += 2) {
+            v2f vbx{bx[t], bx[t + 1]}, vby{by[t], by[t + 1]};
+            const v2f vx{x[t], x[t + 1]}, vy{y[t], y[t + 1]};
+            if (carry) members_v<v2f, true>(cat.base_kind, cat.n_gal, gs, gm, vx, vy, vbx, vby, tans[t / 2]);
+            else members_v<v2f, false>(cat.base_kind, cat.n_gal, gs, gm, vx, vy, vbx, vby, tans[t / 2]);
+            bx[t] = vbx.x; bx[t + 1] = vbx.y; by[t] = vby.x; by[t + 1] = vby.y;
           }
         } break;
       }
@@ -707,22 +706,24 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             wave_acc<DP_NACC>(acc, ac, cd.a_off);
           } break;
           case K_SCALED: if constexpr (DP) {
-            const CatDev cat = a.cats[cd.iparam];
-            const float* __restrict__ gs = a.gal_static + (size_t)cat.g_off * DP_NS;
-            const float* __restrict__ gd = a.gal_dyn + ((size_t)b * a.G + cat.g_off) * DP_ND;
-            float sc[3] = {0.f, 0.f, 0.f};  // gradients of the three scales
-            for (int g = 0; g < cat.n_gal; ++g) {
-              float am[3] = {0.f, 0.f, 0.f};  // this member's (dS, d rc, d rt) over the thread's pixels
-              if (cat.base_kind == K_DPIE) {
+            // gradient of the scales = cotangent . (tangents carried by the ray-shooting pass); a second catalogue in
+            // the same model re-evaluates its members here
+            float sc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < T; ++t)
-                  piemd_vjp<float, false>(gs + g * DP_NS, gd + g * DP_ND, nullptr, x[t], y[t], gbx[t], gby[t], am);
-              } else {
-#pragma unroll
-                for (int t = 0; t < T; ++t)
-                  piep_vjp<float, false>(gs + g * DP_NS, gd + g * DP_ND, x[t], y[t], gbx[t], gby[t], am);
+            for (int t = 0; t < T; t += 2) {
+              ScaleTan<v2f> tn = tans[t / 2];
+              if (l != a.scaled_first) {
+                const CatDev cat = a.cats[cd.iparam];
+                tn = ScaleTan<v2f>{v2f(0.f), v2f(0.f), v2f(0.f), v2f(0.f), v2f(0.f), v2f(0.f)};
+                v2f dbx(0.f), dby(0.f);
+                members_v<v2f, true>(cat.base_kind, cat.n_gal, a.gal_static + (size_t)cat.g_off * DP_NS,
+                                     a.gal_dyn + ((size_t)b * a.G + cat.g_off) * GM_ND, v2f{x[t], x[t + 1]},
+                                     v2f{y[t], y[t + 1]}, dbx, dby, tn);
               }
-              scaled_fold<float>(gd + g * DP_ND, am, sc);
+              const v2f gx{gbx[t], gbx[t + 1]}, gy{gby[t], gby[t + 1]};
+              sc[0] += hsum(gx * tn.tx + gy * tn.ty);
+              sc[1] += hsum(gx * tn.cx + gy * tn.cy);
+              sc[2] += hsum(gx * tn.ux + gy * tn.uy);
             }
             wave_acc<3>(sc, ac, cd.a_off);
           } break;
