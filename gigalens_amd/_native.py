@@ -60,6 +60,11 @@ SYMBOLS = {
                                        POINTER(c_float), POINTER(c_float)]),
     "gl_positions_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
+    "gl_model_num_linear": (c_int, [c_void_p]),
+    "gl_model_linear_column": (c_int, [c_void_p, c_int]),
+    "gl_lstsq_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "gl_lstsq_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_uint32, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_size_t, c_void_p]),
     "gl_model_set_catalogue": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int32), POINTER(c_float)]),
     "gl_scaled_eval": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
@@ -241,6 +246,25 @@ class Model:
             _check(lib().gl_model_set_catalogue(self._h, int(component), int(base_kind), int(t.shape[0]), col_arr,
                                                 t.ctypes.data_as(POINTER(c_float))))
         self._ws = {}  # the workspace grows with the catalogue
+
+    def num_linear(self):
+        return lib().gl_model_num_linear(self._h)
+
+    def lstsq(self, params, obs, err, parts, want):
+        """gl_lstsq_fwd: ``want`` in {"coeffs", "stacked", "image"} -> 1-tuple with that tensor."""
+        params = self._params(params)
+        B, D = params.shape[0], self.num_linear()
+        nbytes = lib().gl_lstsq_workspace_bytes(self._h, B)
+        ws = self._lstsq_ws if getattr(self, "_lstsq_ws", None) is not None and self._lstsq_ws.numel() >= nbytes else None
+        if ws is None:
+            ws = self._lstsq_ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        dev = params.device
+        coeffs = torch.empty((B, D), dtype=torch.float32, device=dev) if want == "coeffs" else None
+        stacked = torch.empty((B, D, self.out_h, self.out_w), dtype=torch.float32, device=dev) if want == "stacked" else None
+        image = torch.empty((B, self.out_h, self.out_w), dtype=torch.float32, device=dev) if want == "image" else None
+        _check(lib().gl_lstsq_fwd(self._h, _ptr(params), _ptr(obs), _ptr(err), B, int(parts), _ptr(coeffs),
+                                  _ptr(stacked), _ptr(image), _ptr(ws), ws.numel(), _stream()))
+        return ({"coeffs": coeffs, "stacked": stacked, "image": image}[want],)
 
     def set_prior(self, columns, const_row):
         """columns: list of (param_col, bijector, prior, a, b, lo, hi, log_norm); const_row: [P] floats."""

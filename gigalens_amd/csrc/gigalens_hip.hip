@@ -19,6 +19,7 @@
 #include "gl_pair.hip.h"
 #include "gl_post.hip.h"
 #include "gl_positions.hip.h"
+#include "gl_lstsq.hip.h"
 
 using namespace glk;
 
@@ -92,6 +93,9 @@ struct gl_model {
   CatDev* d_cats = nullptr;
   float* d_gal_table = nullptr;   // [G][7]
   float* d_gal_static = nullptr;  // [G][DP_NS]
+  // linear amplitudes (lstsq_simulate): channel k of the basis stack <-> packed parameter column
+  std::vector<int> lin_cols;
+  int* d_lin_cols = nullptr;
   int tile = 2;          // pixels per thread per tile (template T) for forward-only launches
   int tile_grad = 2;     // ... and for launches that also produce gradients
   int target_wgs = 2048;  // work decomposition target (>= 8 workgroups per CU)
@@ -245,7 +249,12 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
   dim3 grid(n_chunks, B), block(WG);
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
   if (m->timing) GL_HIP(hipEventRecord(m->ev0, stream));
-  if (m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
+  if constexpr (MODE == IMG_BASIS) {  // basis stack of lstsq_simulate: interpreter kernel, one tile shape
+    if (m->has_shapelets && m->has_dpie) hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true, true>), grid, block, shmem, stream, a);
+    else if (m->has_shapelets) hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true, false>), grid, block, shmem, stream, a);
+    else if (m->has_dpie) hipLaunchKernelGGL((gl_main_kernel<MODE, 2, false, true>), grid, block, shmem, stream, a);
+    else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, false, false>), grid, block, shmem, stream, a);
+  } else if (m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
     // specialised kernel launched
   } else {
     const int Tg = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
@@ -396,8 +405,8 @@ PostArgs post_args(const gl_model* m, float scale) {
   return p;
 }
 // supersampled pre-PSF image S [B,Hs,Ws] -> final image [B,H,W] (x conversion factor)
-int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t stream) {
-  PostArgs p = post_args(m, m->conversion_factor);
+int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t stream, float scale = -1.f) {
+  PostArgs p = post_args(m, scale < 0.f ? m->conversion_factor : scale);
   const int TR = (PT - 1) * p.ss + p.KH, TC = ((PT - 1) * p.ss + p.KW) | 1;
   size_t shmem = (size_t)TR * TC * sizeof(float);
   if (shmem > 64 * 1024) return fail(GL_EUNSUPPORTED, "PSF too large for the LDS-tiled convolution (%zu B)", shmem);
@@ -454,6 +463,34 @@ int run_likelihood(const gl_model* m, int B, const Workspace& w, int chunk, int 
   return launch_main<IMG_BWD>(m, a, B, n_chunks, stream);
 }
 
+}  // namespace
+
+namespace {
+struct LstsqWs {
+  float *stack_ss, *stack, *partial, *coeffs;
+  int chunk, n_chunks, Dp;
+  size_t bytes;
+};
+LstsqWs carve_lstsq(const gl_model* m, int B, void* base, size_t off) {
+  LstsqWs w{};
+  const int D = (int)m->lin_cols.size();
+  const size_t HWs = (size_t)m->height * m->width, HW = HWs / ((size_t)m->supersample * m->supersample);
+  char* p = (char*)base;
+  auto take = [&](size_t n) { float* q = (float*)(p + off); off += align_up(n * sizeof(float), 256); return q; };
+  w.Dp = (D + 1 + 3) & ~3;
+  // pixel chunks per sample: ~2048 workgroups in flight, whole LDS tiles per chunk
+  long long want = std::max<long long>(1, (2048 + B - 1) / B);
+  long long per = ((long long)HW + want - 1) / want;
+  per = std::max<long long>(2 * LS_TPP, (per + 2 * LS_TPP - 1) / (2 * LS_TPP) * (2 * LS_TPP));
+  w.chunk = (int)per;
+  w.n_chunks = (int)(((long long)HW + per - 1) / per);
+  w.stack_ss = m->has_post ? take((size_t)B * D * HWs) : nullptr;
+  w.stack = take((size_t)B * D * HW);
+  w.partial = take((size_t)B * w.n_chunks * w.Dp * w.Dp);
+  w.coeffs = take((size_t)B * D);
+  w.bytes = off;
+  return w;
+}
 }  // namespace
 
 extern "C" {
@@ -533,6 +570,8 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     cd.n_par = kind_num_params(c.kind, iparam);
     cd.n_acc = kind_num_acc(c.kind, iparam);
     if (c.kind == GL_SCALED) cd.iparam = -1;  // catalogue slot, set by gl_model_set_catalogue
+    cd.lin_off = (int)m->lin_cols.size();
+    for (int k = 0; k < kind_num_linear(c.kind, iparam); ++k) m->lin_cols.push_back(p_off + kind_linear_col(c.kind, iparam) + k);
     p_off += cd.n_par;
     d_off += (kind_num_derived(c.kind, iparam) + 3) & ~3;
     a_off += cd.n_acc;
@@ -579,6 +618,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   else ok = ok && (hipMalloc((void**)&m->d_comps, sizeof(CompDesc)) == hipSuccess);
   ok = ok && up((void**)&m->d_gx, grid->grid_x, sizeof(float) * m->N);
   ok = ok && up((void**)&m->d_gy, grid->grid_y, sizeof(float) * m->N);
+  if (!m->lin_cols.empty()) ok = ok && up((void**)&m->d_lin_cols, m->lin_cols.data(), sizeof(int) * m->lin_cols.size());
   if (grid->pix_index) {
     for (int i = 0; i < m->N && ok; ++i)
       if (grid->pix_index[i] < 0 || grid->pix_index[i] >= m->height * m->width) {
@@ -653,6 +693,7 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_zcols) (void)hipFree(m->d_zcols);
   if (m->d_src) (void)hipFree(m->d_src);
   if (m->d_const) (void)hipFree(m->d_const);
+  if (m->d_lin_cols) (void)hipFree(m->d_lin_cols);
   if (m->d_cats) (void)hipFree(m->d_cats);
   if (m->d_gal_table) (void)hipFree(m->d_gal_table);
   if (m->d_gal_static) (void)hipFree(m->d_gal_static);
@@ -756,6 +797,86 @@ int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs,
     return rc;
   return run_finalize(m, params, B, n_chunks, w, loglike, chi2, grad_params_or_null, stream, nullptr, nullptr, nullptr,
                       1.f, extra, use_partial);
+}
+
+int gl_model_num_linear(const gl_model* m) { return m ? (int)m->lin_cols.size() : fail(GL_EINVAL, "model is null"); }
+int gl_model_linear_column(const gl_model* m, int k) {
+  if (!m) return fail(GL_EINVAL, "model is null");
+  if (k < 0 || k >= (int)m->lin_cols.size()) return fail(GL_EINVAL, "linear coefficient index out of range");
+  return m->lin_cols[k];
+}
+
+size_t gl_lstsq_workspace_bytes(const gl_model* m, int B) {
+  if (!m || B <= 0) return 0;
+  return carve_lstsq(m, B, nullptr, align_up(carve(m, B, nullptr).bytes, 256)).bytes;
+}
+
+int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const float* err, int B, unsigned parts,
+                 float* coeffs_or_null, float* stacked_or_null, float* image_or_null, void* workspace,
+                 size_t workspace_bytes, void* hip_stream) {
+  if (!m) return fail(GL_EINVAL, "model is null");
+  const int D = (int)m->lin_cols.size();
+  if (D == 0) return fail(GL_EINVAL, "the model has no linear (light amplitude) coefficients");
+  if (D + 1 > LS_MAXD) return fail(GL_EUNSUPPORTED, "%d linear coefficients exceed the %d the in-LDS solve serves", D, LS_MAXD - 1);
+  if (!params || !workspace) return fail(GL_EINVAL, "params / workspace is null");
+  if (B <= 0 || B > 65535) return fail(GL_EINVAL, "batch size %d outside [1, 65535]", B);
+  if ((int)m->cats.size() != m->n_scaled) return fail(GL_EINVAL, "GL_SCALED component without a catalogue");
+  const bool solve = coeffs_or_null || image_or_null;
+  if (solve && (!obs || !err)) return fail(GL_EINVAL, "obs / err_map are required to solve for the coefficients");
+  if (!solve && !stacked_or_null) return fail(GL_EINVAL, "nothing to compute");
+  if (!(parts & (GL_PART_LENS_LIGHT | GL_PART_SOURCE_LIGHT)) || parts > 7u) return fail(GL_EINVAL, "bad parts");
+  const size_t need = gl_lstsq_workspace_bytes(m, B);
+  if (workspace_bytes < need) return fail(GL_ENOMEM, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+  hipStream_t stream = (hipStream_t)hip_stream;
+  Workspace w = carve(m, B, workspace);
+  LstsqWs lw = carve_lstsq(m, B, workspace, align_up(w.bytes, 256));
+  int chunk, n_chunks, rc;
+  chunking(m, B, &chunk, &n_chunks);
+  const int HW = (m->height / m->supersample) * (m->width / m->supersample);
+  // unit amplitudes -> derived constants -> basis stack
+  hipLaunchKernelGGL(gl_unit_amplitudes_kernel, dim3((unsigned)(((long long)B * m->P + 255) / 256)), dim3(256), 0,
+                     stream, params, m->P, B, m->d_lin_cols, D, w.params);
+  GL_HIP(hipGetLastError());
+  if ((rc = run_prep(m, w.params, B, w, stream))) return rc;
+  MainArgs a = base_args(m, w, chunk);
+  a.parts = parts | GL_PART_LENS_LIGHT | GL_PART_SOURCE_LIGHT;
+  a.n_lin = D;
+  if ((rc = run_order(m, B, w, &a, stream))) return rc;
+  float* target = m->has_post ? lw.stack_ss : lw.stack;
+  if (m->d_pix) GL_HIP(hipMemsetAsync(target, 0, sizeof(float) * (size_t)B * D * m->height * m->width, stream));
+  a.img = target;
+  if ((rc = launch_main<IMG_BASIS>(m, a, B, n_chunks, stream))) return rc;
+  if (m->has_post && (rc = post_fwd(m, B * D, lw.stack_ss, lw.stack, stream, 1.f))) return rc;  // no det(T) here (:226-240)
+  if (stacked_or_null)
+    GL_HIP(hipMemcpyAsync(stacked_or_null, lw.stack, sizeof(float) * (size_t)B * D * HW, hipMemcpyDeviceToDevice, stream));
+  if (!solve) return GL_OK;
+  NormalArgs na{};
+  na.stack = lw.stack;
+  na.obs = obs;
+  na.err = err;
+  na.D = D;
+  na.Dp = lw.Dp;
+  na.HW = HW;
+  na.chunk = lw.chunk;
+  na.n_chunks = lw.n_chunks;
+  na.partial = lw.partial;
+  if (D + 1 <= LS_SMALL)
+    hipLaunchKernelGGL((gl_normal_small_kernel<LS_SMALL>), dim3(lw.n_chunks, B), dim3(256), 0, stream, na);
+  else
+    hipLaunchKernelGGL(gl_normal_tiled_kernel, dim3(lw.n_chunks, B), dim3(256), sizeof(float2) * LS_TPP * lw.Dp, stream, na);
+  GL_HIP(hipGetLastError());
+  const int n = (D + 1) & ~1;
+  const size_t sm = sizeof(float) * ((size_t)2 * n * n + 3 * n + 8);
+  float* coeffs = coeffs_or_null ? coeffs_or_null : lw.coeffs;
+  hipLaunchKernelGGL(gl_pinv_solve_kernel, dim3(B), dim3(256), sm, stream, lw.partial, lw.n_chunks, D, lw.Dp, 1e-6f,
+                     12, coeffs);
+  GL_HIP(hipGetLastError());
+  if (image_or_null) {
+    hipLaunchKernelGGL(gl_combine_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, stream, lw.stack, coeffs, D, HW,
+                       image_or_null);
+    GL_HIP(hipGetLastError());
+  }
+  return GL_OK;
 }
 
 int gl_model_set_catalogue(gl_model* m, int component, int base_kind, int n_galaxies, const int32_t scale_col[3],

@@ -27,6 +27,7 @@ struct CompDesc {
   int a_off;  // offset of the accumulators inside the per-sample accumulator row
   int n_acc;
   int n_par;
+  int lin_off;  // light profiles: channel of the first linear basis image in the lstsq stack
 };
 
 // one galaxy catalogue of a K_SCALED component (gl_model_set_catalogue)
@@ -38,7 +39,7 @@ struct CatDev {
   int pad;
 };
 
-enum Mode : int { IMG_FWD = 0, IMG_BWD = 1, LL_FWD = 2, LL_GRAD = 3 };
+enum Mode : int { IMG_FWD = 0, IMG_BWD = 1, LL_FWD = 2, LL_GRAD = 3, IMG_BASIS = 4 };
 constexpr int WG = 256;
 constexpr int NSTAT = 4;  // accumulator row starts with [chi2, norm, pad, pad]
 
@@ -70,6 +71,7 @@ struct MainArgs {
   const float* gal_dyn;
   int G;
   int scaled_first;  // the K_SCALED lens whose scale tangents ride along the ray-shooting pass (-1: none)
+  int n_lin;         // IMG_BASIS: channels of the stack  img[B][n_lin][img_stride]
 };
 
 // ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
@@ -431,7 +433,7 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
   {
     const float* src = a.derived + (size_t)b * a.D;
     for (int i = tid; i < a.D; i += WG) s_d[i] = src[i];
-    if (MODE != IMG_FWD)
+    if (MODE != IMG_FWD && MODE != IMG_BASIS)
       for (int i = tid; i < a.ncols * a.Apad; i += WG) s_acc[i] = 0.f;
   }
   __syncthreads();
@@ -520,6 +522,34 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
           }
         } break;
       }
+    }
+    if constexpr (MODE == IMG_BASIS) {
+      // lstsq_simulate (tf/simulator.py:183-201): every linear component as its own image, amplitude 1, NaN -> 0
+      for (int ci = 0; ci < n_light; ++ci) {
+        const CompDesc& cd = comps[n_lens + ci];
+        const float* d = s_d + cd.d_off;
+        const bool src = ci >= n_ll;
+        float* row = a.img + ((size_t)b * a.n_lin + cd.lin_off) * a.img_stride;
+        if (cd.kind == K_SHAPELETS) {
+          if constexpr (SHP) {
+#pragma unroll 1
+            for (int t = 0; t < T; ++t) {
+              if (!valid[t]) continue;
+              const int pi = pidx[t];
+              const long long st = a.img_stride;
+              shapelets_basis<float, SH_CAP>(d, a.shp_tab, a.shp_stride, cd.flags & 1u, src ? bx[t] : x[t],
+                                             src ? by[t] : y[t], [&](int k, float v) { row[(size_t)k * st + pi] = isnan_(v) ? 0.f : v; });
+            }
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const float v = sersic_fwd(d, src ? bx[t] : x[t], src ? by[t] : y[t]);
+            if (valid[t]) row[pidx[t]] = isnan_(v) ? 0.f : v;
+          }
+        }
+      }
+      continue;
     }
     // ---- phase 2: render lens light at the grid, sources at beta (tf/simulator.py:128-138) ----
     for (int ci = 0; ci < n_light; ++ci) {
@@ -731,7 +761,7 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
       }
     }
   }
-  if (MODE == IMG_FWD) return;
+  if (MODE == IMG_FWD || MODE == IMG_BASIS) return;
   if (MODE == LL_FWD || MODE == LL_GRAD) wave_acc<2>(st, ac, 0);
   __syncthreads();
   float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;

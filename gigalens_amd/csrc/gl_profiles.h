@@ -93,6 +93,24 @@ GL_HD int kind_num_derived(int kind, int iparam) {
   }
   return -1;
 }
+// linear (amplitude) coefficients of a light profile, the reference's `depth` (profile.py:39; shapelets.py:22-23)
+GL_HD int kind_num_linear(int kind, int iparam) {
+  switch (kind) {
+    case K_SERSIC:
+    case K_SERSIC_ELLIPSE: return 1;
+    case K_SHAPELETS: return sh_layers(iparam);
+  }
+  return 0;
+}
+GL_HD int kind_linear_col(int kind, int iparam) {  // first amplitude column inside the component's parameter row
+  switch (kind) {
+    case K_SERSIC: return 4;
+    case K_SERSIC_ELLIPSE: return 6;
+    case K_SHAPELETS: return 3;
+  }
+  (void)iparam;
+  return -1;
+}
 GL_HD int kind_num_acc(int kind, int iparam) {
   switch (kind) {
     case K_EPL: return EPL_NACC;
@@ -750,6 +768,31 @@ GL_HD void shapelets_sum(const R* amp, int n_max, const R* Xv, const R* dXv, con
           Sv += a * Xv[n1] * dYv[n2];
         }
       }
+    }
+  }
+}
+
+// the L basis images phi_n1(u) phi_n2(v) themselves (use_lstsq=True, shapelets.py:61-62,71-72), in amplitude order
+template <class R, int CAP, class F>
+GL_HD void shapelets_basis(const R* d, const float* tab, int stride, bool interp, R x, R y, F&& emit) {
+  const int n_max = (int)d[SHP_NMAX];
+  R ib = d[SHP_IB];
+  R u = (x - d[SHP_CX]) * ib, v = (y - d[SHP_CY]) * ib;
+  R Xv[CAP + 1], dXv[CAP + 1], Yv[CAP + 1], dYv[CAP + 1];
+  R fac = (R)1;
+  if (interp) {
+    table_basis<R, CAP>(tab, stride, u, n_max, Xv, dXv);
+    table_basis<R, CAP>(tab, stride, v, n_max, Yv, dYv);
+  } else {
+    hermite_basis<R, CAP>(u, n_max, Xv, dXv);
+    hermite_basis<R, CAP>(v, n_max, Yv, dYv);
+    fac = exp_(-(u * u + v * v) * (R)0.5);
+  }
+#pragma unroll
+  for (int n = 0; n <= CAP; ++n) {
+    if (n <= n_max) {
+#pragma unroll
+      for (int n2 = 0; n2 <= n; ++n2) emit(n * (n + 1) / 2 + n2, fac * Xv[n - n2] * Yv[n2]);
     }
   }
 }

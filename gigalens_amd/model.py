@@ -27,10 +27,15 @@ class _Packing:
         groups = ((phys_model.lenses, phys_model.lenses_constants),
                   (phys_model.lens_light, phys_model.lens_light_constants),
                   (phys_model.source_light, phys_model.source_light_constants))
+        self.linear = []  # packed columns of amplitudes solved by least squares (use_lstsq profiles)
         for gname, (profiles, consts) in zip(_GROUPS, groups):
             for i, (prof, c) in enumerate(zip(profiles, consts)):
-                for name in prof.params:
-                    self.slots.append((gname, i, name, c.get(name)))
+                for name in prof._native_params():
+                    if name not in prof.params:  # linear amplitude: unit placeholder until lstsq fills it
+                        self.linear.append(len(self.slots))
+                        self.slots.append((gname, i, name, np.float32(1.0)))
+                    else:
+                        self.slots.append((gname, i, name, c.get(name)))
         self.P = len(self.slots)
 
     def pack(self, params: Dict[str, List[Dict]], bs: int, device):
@@ -389,3 +394,39 @@ class ForwardProbModel(ProbabilisticModel):
     def init_centroids(self, bs):
         """tf/model.py:187-194 (no-op without the position branch)."""
         return None
+
+
+class BackwardProbModel(ProbabilisticModel):
+    """Drop-in for ``gigalens.tf.model.BackwardProbModel`` (tf/model.py:197-273): the noise map comes from the
+    OBSERVED image, and the linear light amplitudes are solved by least squares inside the likelihood.
+
+    The reference differentiates through ``tf.linalg.pinv``; here the gradient uses the envelope property of the
+    solve -- the coefficients minimise exactly the chi^2 that the (fixed-noise) log-likelihood is made of, so
+    ``d log_like / d theta`` equals the partial derivative at fixed coefficients, which the fused forward+gradient
+    kernels evaluate with the solved amplitudes written into their columns (equal to the reference's total derivative
+    wherever the normal matrix has full rank above the ``rcond`` cut)."""
+
+    def __init__(self, prior, observed_image, background_rms, exp_time):
+        super().__init__(prior)
+        self.device = _native.device() if torch.cuda.is_available() else torch.device("cpu")
+        obs = np.asarray(observed_image, dtype=np.float32)
+        err = np.sqrt(np.float32(background_rms) ** 2 + np.clip(obs, 0, np.inf) / np.float32(exp_time)).astype(np.float32)
+        self.observed_image = torch.as_tensor(obs, device=self.device).contiguous()
+        self.err_map = torch.as_tensor(err, device=self.device).contiguous()
+        self._flat = prior.flat(self.device)
+        example = prior.sample(seed=0)
+        self.pack_bij = _PackBijector(example)
+        self.unconstraining_bij = _prior.JointBijector(self._flat)
+        self.bij = _ChainBijector(self.unconstraining_bij, self.pack_bij)
+
+    def log_prob(self, simulator, z):
+        """tf/model.py:242-273: ``(log_like + log_prior, mean squared normalised residual)``."""
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        x = self._flat.forward(z)
+        log_prior = self._flat.log_prob(x) + self._flat.fldj_columns(z).sum(-1)
+        packed = simulator.pack(self.pack_bij.forward(x))
+        coeffs = simulator._model.lstsq(packed.detach(), self.observed_image, self.err_map, 7, want="coeffs")[0]
+        lin = torch.tensor(simulator._layout.linear, dtype=torch.int64, device=packed.device)
+        full = packed.index_copy(1, lin, coeffs / simulator.conversion_factor)  # amplitude = coeff / det(T)
+        ll, chi2 = _LogLikeFn.apply(full, simulator._model, self.observed_image, self.err_map, None, 0.0, 1.0)
+        return ll + log_prior, chi2 / float(self.observed_image.numel())

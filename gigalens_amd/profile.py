@@ -28,6 +28,10 @@ class Parameterized(ABC):
     def _component(self):
         return (self._kind, 0, 0)
 
+    def _native_params(self):
+        """Column names of this component's packed native row (== ``params`` unless amplitudes are solved linearly)."""
+        return list(self.params)
+
 
 class LightProfile(Parameterized, ABC):
     """src/gigalens/profile.py:24-60.  ``use_lstsq`` removes the amplitude from ``params``
@@ -46,10 +50,16 @@ class LightProfile(Parameterized, ABC):
     def use_lstsq(self):
         return self._use_lstsq
 
+    def _native_params(self):
+        """With ``use_lstsq`` the amplitude leaves ``params`` (profile.py:40-41) but keeps its native column: the basis
+        images are rendered with amplitude 1 and the solved coefficients are written there (LensSimulator.lstsq_simulate)."""
+        return list(self.params) + ([self._amp] if self.use_lstsq else [])
+
     def light(self, x, y, **kwargs):
         """Surface brightness at ``(x, y)``; parameters broadcast on the last axis like the reference."""
         if self.use_lstsq:
-            raise NotImplementedError("use_lstsq=True (linear amplitude solve) is not built yet")
+            raise NotImplementedError("plugin-level light() of a use_lstsq profile (the stacked basis images) is not "
+                                      "built; LensSimulator.lstsq_simulate(return_stacked=True) renders them")
         return _native.profile_eval(self, x, y, kwargs)[0]
 
 

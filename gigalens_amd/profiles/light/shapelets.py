@@ -38,3 +38,6 @@ class Shapelets(LightProfile):
 
     def _component(self):
         return (self._kind, self.n_max, 1 if self.interpolate else 0)
+
+    def _native_params(self):
+        return list(self._params) + list(self._amp_names)

@@ -199,5 +199,21 @@ class LensSimulator(LensSimulatorInterface):
         """tf/simulator.py:299-328: the lensed sources only."""
         return self._parts(self._pack_partial(params), 1 | 4)
 
-    def lstsq_simulate(self, params, observed_image, err_map, **kw):
-        raise NotImplementedError("lstsq_simulate (linear amplitude solve) is a later row (SURVEY 8f-4)")
+    def lstsq_simulate(self, params, observed_image, err_map, return_stacked=False, return_coeffs=False,
+                       no_deflection=False):
+        """tf/simulator.py:158-240: render every ``use_lstsq`` light component as unit-amplitude basis images, solve
+        ``coeffs = pinv(X^T X, rcond=1e-6) X^T Y`` per sample and return the best-fit image (default), the stack
+        ``(bs, H, W, depth)`` or the coefficients ``(bs, depth)``.  All light profiles of the model must have been
+        built with ``use_lstsq=True`` (the reference stacks every component, :183-201)."""
+        if len(self._layout.linear) != self._model.num_linear():
+            raise ValueError("lstsq_simulate needs every light profile built with use_lstsq=True")
+        packed = params if torch.is_tensor(params) else self.pack(params)
+        parts = (0 if no_deflection else 1) | 2 | 4
+        if return_stacked:
+            (stack,) = self._model.lstsq(packed, None, None, parts, want="stacked")
+            return stack.permute(0, 2, 3, 1)
+        obs = torch.as_tensor(observed_image, dtype=torch.float32, device=self.device).contiguous()
+        err = torch.as_tensor(err_map, dtype=torch.float32, device=self.device).contiguous()
+        if return_coeffs:
+            return self._model.lstsq(packed, obs, err, parts, want="coeffs")[0]
+        return torch.squeeze(self._model.lstsq(packed, obs, err, parts, want="image")[0])

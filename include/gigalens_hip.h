@@ -164,6 +164,22 @@ int gl_model_set_positions(gl_model* m, int n_families, const int* family_sizes,
 int gl_positions_fwd_bwd(const gl_model* m, const float* params, int B, float* loglike, float* chi2,
                          float* grad_params_or_null, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* Linear-amplitude solve, LensSimulator.lstsq_simulate (tf/simulator.py:158-240): every light component is rendered
+ * as `depth` basis images of unit amplitude (Sersic: 1; Shapelets: (n_max+1)(n_max+2)/2), NaN -> 0, PSF and
+ * pooling per channel, then  coeffs = pinv(X^T X, rcond=1e-6) X^T Y  with X = stack / err_map, Y = obs / err_map.
+ *   params   [B,P]; the amplitude columns (gl_model_linear_column) are ignored
+ *   parts    GL_PART_DEFLECT | GL_PART_LENS_LIGHT | GL_PART_SOURCE_LIGHT; drop GL_PART_DEFLECT for no_deflection=True
+ *   coeffs   [B,D] (return_coeffs) | stacked [B,D,H,W] (return_stacked; the reference's layout is (B,H,W,D)) |
+ *   image    [B,H,W] = sum_d coeffs_d stack_d (default return; no det(T) factor, it is absorbed by the coefficients);
+ *            any of the three may be NULL.  obs, err: [H,W], required unless only `stacked` is requested.
+ * Equivalent forward parameters: amplitude_k = coeffs_k / conversion_factor. */
+int gl_model_num_linear(const gl_model* m);            /* D = sum of the light profiles' depth */
+int gl_model_linear_column(const gl_model* m, int k);  /* packed-parameter column of linear coefficient k */
+size_t gl_lstsq_workspace_bytes(const gl_model* m, int B);
+int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const float* err, int B, unsigned parts,
+                 float* coeffs_or_null, float* stacked_or_null, float* image_or_null, void* workspace,
+                 size_t workspace_bytes, void* hip_stream);
+
 /* Galaxy catalogue of a GL_SCALED component (ScalingRelation.__init__, scaling_relation.py:27-55).  Must be attached
  * to every GL_SCALED component before gl_workspace_bytes / any compute call (the workspace holds one block of
  * constants per sample and galaxy).

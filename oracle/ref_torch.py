@@ -505,11 +505,14 @@ _TABLE_CACHE: Dict = {}
 
 def shapelets_light(x, y, center_x, center_y, beta, amps, n_max, interpolate=True):
     """tf/profiles/light/shapelets.py:53-85.  ``amps``: list of n_layers tensors (B,)
-    in amp-name order (== tf.nest.flatten of the **amp kwargs, keys sorted)."""
+    in amp-name order (== tf.nest.flatten of the **amp kwargs, keys sorted); ``amps=None`` is the
+    ``use_lstsq=True`` branch (:61-62,71-72): the (n_layers, N, B) basis images themselves."""
     center_x, center_y, beta = _t(center_x, x), _t(center_y, x), _t(beta, x)
     N1, N2 = shapelet_index_order(n_max)
-    A = torch.stack([_t(a, x) * torch.ones(x.shape[-1], dtype=x.dtype) if _t(a, x).dim() == 0 else _t(a, x)
-                     for a in amps])  # (n_layers, B)
+    basis_only = amps is None
+    A = None if basis_only else torch.stack(
+        [_t(a, x) * torch.ones(x.shape[-1], dtype=x.dtype) if _t(a, x).dim() == 0 else _t(a, x)
+         for a in amps])  # (n_layers, B)
     u = (x - center_x) / beta
     v = (y - center_y) / beta
     if interpolate:
@@ -521,6 +524,8 @@ def shapelets_light(x, y, center_x, center_y, beta, amps, n_max, interpolate=Tru
         X = interp_regular_1d_grid(u, -5.0, 5.0, tab)  # (n_max+1, N, B)
         Y = interp_regular_1d_grid(v, -5.0, 5.0, tab)
         ret = X[N1] * Y[N2]  # (n_layers, N, B) -- the reference interpolates 66 duplicated rows
+        if basis_only:
+            return ret
         return torch.einsum('inj,ij->nj', ret, A)
     # direct mode :66-85
     herm = [torch.ones_like(u), 2 * u]
@@ -533,6 +538,8 @@ def shapelets_light(x, y, center_x, center_y, beta, amps, n_max, interpolate=Tru
     XX = torch.stack(herm[: n_max + 1]) * pref[:, None, None]
     YY = torch.stack(hermv[: n_max + 1]) * pref[:, None, None]
     fac = torch.exp(-(u ** 2 + v ** 2) / 2)
+    if basis_only:
+        return fac * (XX[N1] * YY[N2])
     return fac * torch.einsum('ij,inj->nj', A, XX[N1] * YY[N2])
 
 
@@ -580,6 +587,19 @@ def mass_hessian(profile, x, y, **kw):
     a, b = torch.autograd.grad(fx.sum(), [x, y], create_graph=True)
     cc, d = torch.autograd.grad(fy.sum(), [x, y], create_graph=True)
     return a, b, cc, d
+
+
+def light_basis(profile, x, y, **kw):
+    """``light`` of a ``use_lstsq=True`` profile: (depth, N, B) basis images with unit amplitude
+    (sersic.py:30-34 ``Ie = ones``; ``ret[tf.newaxis]``; shapelets.py:61-62,71-72)."""
+    name = profile.name
+    if name in ("SERSIC", "SERSIC_ELLIPSE"):
+        kw = {k: v for k, v in kw.items() if k != "Ie"}
+        return sersic_light(x, y, Ie=1.0, **kw)[None]
+    if name == "SHAPELETS":
+        return shapelets_light(x, y, kw["center_x"], kw["center_y"], kw["beta"], None, profile.n_max,
+                               getattr(profile, "interpolate", True))
+    raise NotImplementedError(name)
 
 
 def light_eval(profile, x, y, **kw):
@@ -678,6 +698,66 @@ class RefSimulator:
         if self.supersample != 1:  # :149-155
             ret = torch.nn.functional.avg_pool2d(ret, kernel_size=self.supersample, stride=self.supersample)
         return torch.squeeze(ret) * self.conversion_factor  # :156
+
+
+def lstsq_simulate(simulator: RefSimulator, params, observed_image, err_map, return_stacked=False,
+                   return_coeffs=False, no_deflection=False):
+    """tf/simulator.py:158-240: basis stack (depth channels, NaN -> 0, depthwise PSF, pooling), then
+    ``coeffs = pinv(X^T X, rcond=1e-6) X^T Y`` with ``X = stack / err_map``, ``Y = obs / err_map``.
+    (The reference scatters into a zero-length first axis, :183-193 -- a shape slip; restated as the
+    (depth, H, W, bs) stack it evidently builds and :199-205 reshapes.)"""
+    sim, pm, dt = simulator, simulator.phys_model, simulator.dtype
+    lens_params = params.get('lens_mass', [{} for _ in pm.lenses])
+    lens_light_params = params.get('lens_light', [{} for _ in pm.lens_light])
+    source_light_params = params.get('source_light', [{} for _ in pm.source_light])
+    beta_x, beta_y = sim.beta(sim.img_X, sim.img_Y, lens_params)
+    if no_deflection:
+        beta_x, beta_y = sim.img_X, sim.img_Y
+    Hs, Ws = sim.wcs.n_x * sim.supersample, sim.wcs.n_y * sim.supersample
+    rr, cc = torch.from_numpy(sim.region[:, 0]), torch.from_numpy(sim.region[:, 1])
+    chans = []
+    for lm, p, c in zip(pm.lens_light, lens_light_params, sim._consts("lens_light_constants", len(pm.lens_light))):
+        chans.append(light_basis(lm, sim.img_X, sim.img_Y, **p, **c))
+    for lm, p, c in zip(pm.source_light, source_light_params, sim._consts("source_light_constants", len(pm.source_light))):
+        chans.append(light_basis(lm, beta_x, beta_y, **p, **c))
+    flat = torch.cat(chans, dim=0)  # (depth, N, bs)
+    depth = flat.shape[0]
+    img = torch.zeros((depth, Hs, Ws, sim.bs), dtype=dt)
+    img[:, rr, cc, :] = flat
+    img = torch.where(torch.isnan(img), torch.zeros_like(img), img)
+    ret = img.permute(3, 0, 1, 2)  # (bs, depth, Hs, Ws) -- channels-first for torch's conv
+    if sim.flat_kernel is not None:  # depthwise_conv2d SAME (:209-215)
+        kh, kw = sim.flat_kernel.shape
+        ret = torch.nn.functional.pad(ret, ((kw - 1) // 2, kw // 2, (kh - 1) // 2, kh // 2))
+        ret = torch.nn.functional.conv2d(ret, sim.flat_kernel[None, None].repeat(depth, 1, 1, 1), groups=depth)
+    if sim.supersample != 1:
+        ret = torch.nn.functional.avg_pool2d(ret, kernel_size=sim.supersample, stride=sim.supersample)
+    ret = torch.where(torch.isnan(ret), torch.zeros_like(ret), ret)
+    if return_stacked:
+        return ret.permute(0, 2, 3, 1)  # the reference's (bs, H, W, depth)
+    err = torch.as_tensor(np.asarray(err_map, dtype=np.float32)).to(dt)
+    obs = torch.as_tensor(np.asarray(observed_image, dtype=np.float32)).to(dt)
+    W = 1 / err
+    Y = (obs * W).reshape(1, -1, 1)
+    X = (ret * W).reshape(sim.bs, depth, -1).permute(0, 2, 1)  # (bs, HW, depth)
+    Xt = X.permute(0, 2, 1)
+    coeffs = (torch.linalg.pinv(Xt @ X, rcond=1e-6) @ Xt @ Y)[..., 0]
+    if return_coeffs:
+        return coeffs
+    return torch.squeeze((ret * coeffs[:, :, None, None]).sum(dim=1))
+
+
+def backward_log_prob_terms(simulator: RefSimulator, params, observed_image, background_rms, exp_time):
+    """BackwardProbModel (tf/model.py:215-222,264-273) without the prior: err_map from the OBSERVED image,
+    Normal log-likelihood of the least-squares image, mean squared normalised residual."""
+    dt = simulator.dtype
+    obs = torch.as_tensor(np.asarray(observed_image, dtype=np.float32)).to(dt)
+    err_map = torch.sqrt(torch.as_tensor(np.float32(background_rms)).to(dt) ** 2
+                         + torch.clamp(obs, min=0) / torch.as_tensor(np.float32(exp_time)).to(dt))
+    im_sim = lstsq_simulate(simulator, params, observed_image, err_map.to(torch.float32).numpy())
+    err32 = err_map.to(torch.float32).to(dt)
+    log_like = (-0.5 * ((im_sim - obs) / err32) ** 2 - torch.log(err32) - 0.5 * math.log(2 * math.pi)).sum(dim=(-2, -1))
+    return log_like, (((im_sim - obs) / err32) ** 2).mean(dim=(-2, -1))
 
 
 def stats_pixels(simulator: RefSimulator, params, observed_image, background_rms=None, exp_time=None,

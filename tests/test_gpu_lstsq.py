@@ -1,0 +1,134 @@
+"""Linear-amplitude solve (LensSimulator.lstsq_simulate, tf/simulator.py:158-240) and BackwardProbModel
+(tf/model.py:197-273): HIP path vs the oracle (torch float64, torch.linalg.pinv, autograd through the solve)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.test_gpu_parity import gl  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _model(kind, num_pix, batch, psf=False, ss=1):
+    from gigalens_amd import prior as tfd
+    from gigalens_amd import workloads
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import Sersic, SersicEllipse
+    from gigalens_amd.profiles.light.shapelets import Shapelets
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.simulator import SimulatorConfig
+    J, S = tfd.JointDistributionNamed, tfd.JointDistributionSequential
+    epl = J(dict(theta_E=tfd.LogNormal(math.log(1.1), 0.1), gamma=tfd.TruncatedNormal(2, 0.1, 1.5, 2.5),
+                 e1=tfd.Normal(0.1, 0.05), e2=tfd.Normal(-0.05, 0.05), center_x=tfd.Normal(0, 0.03), center_y=tfd.Normal(0, 0.03)))
+    shear = J(dict(gamma1=tfd.Normal(0, 0.03), gamma2=tfd.Normal(0, 0.03)))
+    ser = lambda r: J(dict(R_sersic=tfd.LogNormal(math.log(r), 0.1), n_sersic=tfd.Uniform(1, 3),
+                           center_x=tfd.Normal(0, 0.1), center_y=tfd.Normal(0, 0.1)))
+    sere = J(dict(R_sersic=tfd.LogNormal(math.log(0.8), 0.1), n_sersic=tfd.Uniform(2, 4), e1=tfd.Normal(0, 0.1),
+                  e2=tfd.Normal(0, 0.1), center_x=tfd.Normal(0, 0.03), center_y=tfd.Normal(0, 0.03)))
+    if kind == "sersic":   # 3 linear coefficients: lens light + two sources
+        phys = PhysicalModel([EPL(), Shear()], [SersicEllipse(use_lstsq=True)], [Sersic(use_lstsq=True), Sersic(use_lstsq=True)])
+        prior = J(dict(lens_mass=S([epl, shear]), lens_light=S([sere]), source_light=S([ser(0.25), ser(0.12)])))
+    else:                  # shapelets n_max=3 (10) + lens light (1): the register-tiled normal-matrix kernel
+        shp = J(dict(beta=tfd.LogNormal(math.log(0.15), 0.1), center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05)))
+        n_max = 6 if kind == "shapelets6" else 3
+        phys = PhysicalModel([EPL(), Shear()], [SersicEllipse(use_lstsq=True)],
+                             [Shapelets(n_max, use_lstsq=True, interpolate=(kind != "shapelets_direct"))])
+        prior = J(dict(lens_mass=S([epl, shear]), lens_light=S([sere]), source_light=S([shp])))
+    cfg = SimulatorConfig(delta_pix=0.08, num_pix=num_pix, supersample=ss)
+    return workloads.Workload("LSQ", phys, prior, cfg, batch)
+
+
+def _observation(wl, seed=3):
+    """A noisy image of comparable scale (any image serves: the solve is a projection)."""
+    r = np.random.default_rng(seed)
+    n = wl.sim_config.num_pix
+    yy, xx = np.mgrid[:n, :n]
+    ring = 40 * np.exp(-0.5 * ((np.hypot(xx - n / 2, yy - n / 2) * 0.08 - 1.1) / 0.15) ** 2) \
+        + 80 * np.exp(-0.5 * (np.hypot(xx - n / 2, yy - n / 2) * 0.08 / 0.5) ** 2)
+    obs = (ring + r.normal(size=(n, n)) * 1.5).astype(np.float32)
+    err = np.sqrt(1.5 ** 2 + np.clip(obs, 0, None) / 100.0).astype(np.float32)
+    return obs, err
+
+
+@pytest.mark.parametrize("kind,num_pix,batch,psf,ss", [("sersic", 32, 5, False, 1), ("sersic", 30, 3, True, 2),
+                                                       ("shapelets", 36, 4, False, 1), ("shapelets_direct", 32, 3, True, 1),
+                                                       ("shapelets6", 40, 2, False, 1)])
+def test_lstsq_simulate_vs_oracle(gl, kind, num_pix, batch, psf, ss):
+    from oracle import ref_torch as ref
+    wl = _model(kind, num_pix, batch, psf, ss)
+    kern = None
+    if psf:
+        k = 5 * ss if ss > 1 else 5
+        g = np.exp(-0.5 * ((np.arange(k) - (k - 1) / 2) / (0.9 * ss)) ** 2)
+        kern = np.outer(g, g).astype(np.float32)
+        kern /= kern.sum()
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=batch, supersampled_kernel=kern)
+    x = wl.prior.sample(batch, seed=5)
+    obs, err = _observation(wl)
+    rs = ref.RefSimulator(wl.phys_model, wl.sim_config, batch, dtype=F64, supersampled_kernel=kern)
+    x64 = {g: [{k: v.double() for k, v in d.items()} for d in lst] for g, lst in x.items()}
+    st_o = ref.lstsq_simulate(rs, x64, obs, err, return_stacked=True)
+    st = sim.lstsq_simulate(x, obs, err, return_stacked=True)
+    assert st.shape == st_o.shape
+    sc = st_o.abs().amax(dim=(1, 2), keepdim=True)
+    assert torch.all((st.cpu().double() - st_o).abs() <= 5e-5 * sc + 1e-7)
+    img_o = ref.lstsq_simulate(rs, x64, obs, err)
+    img = sim.lstsq_simulate(x, obs, err)
+    # the fitted image is a projection of the data: well conditioned even when single coefficients are not
+    assert np.abs(img.cpu().numpy() - img_o.numpy()).max() <= 2e-4 * np.abs(img_o.numpy()).max()
+    c_o = ref.lstsq_simulate(rs, x64, obs, err, return_coeffs=True)
+    c = sim.lstsq_simulate(x, obs, err, return_coeffs=True)
+    assert c.shape == c_o.shape
+    if kind == "sersic":
+        assert np.allclose(c.cpu().numpy(), c_o.numpy(), rtol=2e-3, atol=2e-3 * np.abs(c_o.numpy()).max())
+    # no_deflection renders the sources on the image grid
+    nd_o = ref.lstsq_simulate(rs, x64, obs, err, no_deflection=True)
+    nd = sim.lstsq_simulate(x, obs, err, no_deflection=True)
+    assert np.abs(nd.cpu().numpy() - nd_o.numpy()).max() <= 2e-4 * np.abs(nd_o.numpy()).max()
+
+
+@pytest.mark.parametrize("kind", ["sersic", "shapelets"])
+def test_backward_prob_model_vs_oracle(gl, kind):
+    """log_prob value, and its gradient by the envelope property, against autograd THROUGH the float64 pinv solve."""
+    from gigalens_amd.model import BackwardProbModel
+    from oracle import ref_torch as ref
+    wl = _model(kind, 32, 4)
+    obs, _ = _observation(wl)
+    bg, t = 1.5, 100.0
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    pm = BackwardProbModel(wl.prior, obs, bg, t)
+    z = pm.bij.inverse(wl.prior.sample(wl.batch, seed=8)).to(sim.device).requires_grad_(True)
+    lp, red = pm.log_prob(sim, z)
+    lp.sum().backward()
+    # oracle: same z -> x through the torch prior (float64), lstsq inside autograd
+    rs = ref.RefSimulator(wl.phys_model, wl.sim_config, wl.batch, dtype=F64)
+    z64 = z.detach().cpu().double().requires_grad_(True)
+    flat = wl.prior.flat(torch.device("cpu"))
+    x64 = flat.forward(z64)
+    struct = pm.pack_bij.forward(x64)
+    ll_o, red_o = ref.backward_log_prob_terms(rs, struct, obs, bg, t)
+    lp_o = ll_o + flat.log_prob(x64) + flat.fldj_columns(z64).sum(-1)
+    (g_o,) = torch.autograd.grad(lp_o.sum(), z64)
+    assert np.allclose(lp.detach().cpu().numpy(), lp_o.detach().numpy(), rtol=2e-4)
+    assert np.allclose(red.detach().cpu().numpy(), red_o.detach().numpy(), rtol=2e-4)
+    g, go = z.grad.cpu().numpy(), g_o.numpy()
+    scale = np.abs(go).max(axis=1, keepdims=True)
+    assert np.all(np.abs(g - go) <= 5e-3 * scale + 1e-4), (np.abs(g - go) / scale).max()
+
+
+def test_lstsq_errors(gl):
+    from gigalens_amd import _native
+    wl = gl.workloads.make("C2", num_pix=16, batch=2)  # Sersic source WITHOUT use_lstsq
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=2)
+    with pytest.raises(ValueError):
+        sim.lstsq_simulate(wl.prior.sample(2, seed=0), np.zeros((16, 16), np.float32), np.ones((16, 16), np.float32))
+    wl2 = _model("sersic", 16, 2)
+    sim2 = gl.LensSimulator(wl2.phys_model, wl2.sim_config, bs=2)
+    packed = sim2.pack(wl2.prior.sample(2, seed=0))
+    with pytest.raises(_native.NativeLibraryError):  # coefficients need obs and err
+        sim2._model.lstsq(packed, None, None, 7, want="coeffs")
