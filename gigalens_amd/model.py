@@ -328,6 +328,20 @@ class ForwardProbModel(ProbabilisticModel):
     def _mask(self, simulator):
         return simulator.img_region if simulator.sim_config.pix_region is not None else None
 
+    def term_log_prob_and_grad(self, simulator, z, term):
+        """``(log_prior + log_like_term, log_like_term, gradient of the former w.r.t. z)`` for ONE likelihood term
+        (``"pixels"`` or ``"positions"``) -- the pieces the tempered SMC target is assembled from
+        (tf/inference.py:213-238,292-303)."""
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        model = self._bind_prior(simulator)
+        bit = {"pixels": 1, "positions": 2}[term]
+        if bit == 2:
+            self._bind_positions(simulator)
+        lp, ll, _, grad = model.logprob(z.detach(), self.observed_image, self.error_map, self._mask(simulator),
+                                        self.background_rms or 0.0, self.exp_time or 1.0, True,
+                                        self._n_eff(simulator) if bit == 1 else 1.0, bit)
+        return lp, ll, grad
+
     def log_prob_and_grad(self, simulator, z):
         """``(log_prob, red_chi2, d log_prob / d z)`` from ONE native launch sequence and no autograd graph --
         what one MAP / HMC-leapfrog step of the reference computes with ``tf.GradientTape`` (tf/inference.py:33-39)."""

@@ -53,3 +53,23 @@ def test_vi_and_hmc(setup):
     samples, stats = seq.HMC((mean, L), n_hmc=3, init_eps=0.3, init_l=3, max_leapfrog_steps=5, num_burnin_steps=3,
                              num_results=5)
     assert len(samples) == 5 and samples.shape == (5, 3, 13) and torch.isfinite(samples).all()
+
+
+def test_smc(setup):
+    """ModellingSequence.SMC (tf/inference.py:184-288): the temperature ladder reaches 1, the particles end at the
+    noise floor, the evidence is finite and two independent ensembles agree on it to Monte-Carlo accuracy."""
+    wl, pm, seq = setup
+    samples, info = seq.SMC(num_particles=96, num_ensembles=2, num_leapfrog_steps=4, post_sampling_steps=0,
+                            max_sampling_per_stage=3, target="pixels", auxiliar="none", seed=4, max_stage=200)
+    assert samples.shape == (96, 2, 13) and torch.isfinite(samples).all()
+    betas = np.array([s["beta"] for s in info["stages"]])
+    assert np.all(np.diff(betas, axis=0) >= 0) and np.allclose(betas[-1], 1.0)
+    from gigalens_amd.simulator import LensSimulator
+    sim = LensSimulator(wl.phys_model, wl.sim_config, bs=192)
+    _, red = pm.log_prob(sim, samples.permute(1, 0, 2).reshape(192, 13))
+    assert float(red.median()) < 1.6
+    lz = info["log_evidence"].numpy()
+    assert np.all(np.isfinite(lz)) and abs(lz[0] - lz[1]) < 0.05 * abs(lz).max() + 8.0
+    chain, _ = seq.SMC(num_particles=32, num_leapfrog_steps=3, post_sampling_steps=4, max_sampling_per_stage=2,
+                       target="pixels", auxiliar="none", seed=5, max_stage=200)
+    assert chain.shape == (4, 32, 13) and torch.isfinite(chain).all()
