@@ -866,10 +866,15 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
     hipLaunchKernelGGL(gl_normal_tiled_kernel, dim3(lw.n_chunks, B), dim3(256), sizeof(float2) * LS_TPP * lw.Dp, stream, na);
   GL_HIP(hipGetLastError());
   const int n = (D + 1) & ~1;
-  const size_t sm = sizeof(float) * ((size_t)2 * n * n + 3 * n + 8);
+  const size_t sm = sizeof(float) * ((size_t)2 * n * (n + 1) + 3 * n + 8);
   float* coeffs = coeffs_or_null ? coeffs_or_null : lw.coeffs;
-  hipLaunchKernelGGL(gl_pinv_solve_kernel, dim3(B), dim3(256), sm, stream, lw.partial, lw.n_chunks, D, lw.Dp, 1e-6f,
-                     12, coeffs);
+  // the Jacobi steps are barrier-latency bound: large systems get a full 1024-thread workgroup per sample
+  if (n > 24)
+    hipLaunchKernelGGL((gl_pinv_solve_kernel<1024>), dim3(B), dim3(1024), sm, stream, lw.partial, lw.n_chunks, D, lw.Dp,
+                       1e-6f, 12, coeffs);
+  else
+    hipLaunchKernelGGL((gl_pinv_solve_kernel<256>), dim3(B), dim3(256), sm, stream, lw.partial, lw.n_chunks, D, lw.Dp,
+                       1e-6f, 12, coeffs);
   GL_HIP(hipGetLastError());
   if (image_or_null) {
     hipLaunchKernelGGL(gl_combine_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, stream, lw.stack, coeffs, D, HW,

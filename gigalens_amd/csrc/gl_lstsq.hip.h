@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(256) gl_normal_small_kernel(NormalArgs a) {
 // ---- many channels: 4x4 register tiles of the lower triangle, pixel pairs packed --------------------------------
 __global__ void __launch_bounds__(256) gl_normal_tiled_kernel(NormalArgs a) {
   extern __shared__ float2 s_x[];  // [LS_TPP][Dp]
+  __shared__ float s_w[2 * LS_TPP];  // 1/err of the tile's pixels (0 beyond the chunk)
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int Dp = a.Dp, nt = Dp / 4, ntiles = nt * (nt + 1) / 2;
   int ti = 0, tj = 0;
@@ -85,16 +86,14 @@ __global__ void __launch_bounds__(256) gl_normal_tiled_kernel(NormalArgs a) {
   const int p0 = chunk * a.chunk, p1 = min(p0 + a.chunk, a.HW);
   for (int base = p0; base < p1; base += 2 * LS_TPP) {
     __syncthreads();
+    if (tid < 2 * LS_TPP) s_w[tid] = (base + tid < p1) ? 1.0f / a.err[base + tid] : 0.f;
+    __syncthreads();
     // stage [channel][64 pixels] -> LDS [pixel pair][channel] as (even pixel, odd pixel), weighted by 1/err
     for (int e = tid; e < Dp * 2 * LS_TPP; e += 256) {
       const int d = e / (2 * LS_TPP), q = e - d * (2 * LS_TPP);
-      const int p = base + q;
-      float v = 0.f;
-      if (p < p1) {
-        const float w = 1.0f / a.err[p];
-        v = d < a.D ? S[(size_t)d * a.HW + p] * w : (d == a.D ? a.obs[p] * w : 0.f);
-      }
-      reinterpret_cast<float*>(s_x)[((q >> 1) * Dp + d) * 2 + (q & 1)] = v;
+      const int p = min(base + q, p1 - 1);
+      const float v = d < a.D ? S[(size_t)d * a.HW + p] : (d == a.D ? a.obs[p] : 0.f);
+      reinterpret_cast<float*>(s_x)[((q >> 1) * Dp + d) * 2 + (q & 1)] = v * s_w[q];
     }
     __syncthreads();
     if (active) {
@@ -125,28 +124,30 @@ __global__ void __launch_bounds__(256) gl_normal_tiled_kernel(NormalArgs a) {
 // Parallel-ordered cyclic Jacobi (round-robin tournament: n-1 steps of n/2 disjoint rotations per sweep); all n/2
 // rotations of a step are applied together: columns (A J, V J), then rows (J^T A).  tf.linalg.pinv cuts singular
 // values <= rcond * max (here |eigenvalues| of the symmetric normal matrix).
-__global__ void __launch_bounds__(256) gl_pinv_solve_kernel(const float* __restrict__ partial, int n_chunks, int D,
+template <int NT>
+__global__ void __launch_bounds__(NT) gl_pinv_solve_kernel(const float* __restrict__ partial, int n_chunks, int D,
                                                             int Dp, float rcond, int sweeps, float* __restrict__ coeffs) {
   extern __shared__ float sm[];
   const int n = (D + 1) & ~1;  // even size for the tournament (a padded row/column of zeros is inert)
-  float* A = sm;               // [n][n]
-  float* V = A + n * n;        // [n][n]
-  float* cs = V + n * n;       // [n/2][2] rotations, then scratch
+  const int ld = n + 1;        // odd row stride: column sweeps hit distinct LDS banks
+  float* A = sm;               // [n][ld]
+  float* V = A + n * ld;       // [n][ld]
+  float* cs = V + n * ld;      // [n/2][2] rotations, then scratch
   float* rhs = cs + n;         // [n]
   int* pr = reinterpret_cast<int*>(rhs + n);  // [n/2][2] pairs
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* src = partial + (size_t)b * n_chunks * Dp * Dp;
-  for (int e = tid; e < n * n; e += 256) {
+  for (int e = tid; e < n * n; e += NT) {
     const int i = e / n, j = e - i * n;
     float v = 0.f;
     if (i < D && j < D) {
       const int hi = max(i, j), lo = min(i, j);
       for (int ch = 0; ch < n_chunks; ++ch) v += src[(size_t)ch * Dp * Dp + hi * Dp + lo];
     }
-    A[e] = v;
-    V[e] = (i == j) ? 1.f : 0.f;
+    A[i * ld + j] = v;
+    V[i * ld + j] = (i == j) ? 1.f : 0.f;
   }
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += NT) {
     float v = 0.f;
     if (i < D)
       for (int ch = 0; ch < n_chunks; ++ch) v += src[(size_t)ch * Dp * Dp + D * Dp + i];  // row D = X^T Y
@@ -154,16 +155,22 @@ __global__ void __launch_bounds__(256) gl_pinv_solve_kernel(const float* __restr
   }
   __syncthreads();
   const int half = n / 2;
+  __shared__ int s_rot;
   for (int sw = 0; sw < sweeps; ++sw) {
+    if (tid == 0) s_rot = 0;
+    __syncthreads();
     for (int r = 0; r < n - 1; ++r) {
       if (tid < half) {
         int p, q;
         if (tid == 0) { p = n - 1; q = r; }
         else { p = (r + tid) % (n - 1); q = (r - tid + (n - 1)) % (n - 1); }
         if (p > q) { int t = p; p = q; q = t; }
-        const float app = A[p * n + p], aqq = A[q * n + q], apq = A[p * n + q];
+        const float app = A[p * ld + p], aqq = A[q * ld + q], apq = A[p * ld + q];
         float c = 1.f, s = 0.f;
-        if (fabsf(apq) > 1e-30f) {
+        // rotations below fp32 resolution of the two diagonal entries change nothing: skip, and stop sweeping once a
+        // whole sweep consisted of such rotations
+        if (fabsf(apq) > 3e-8f * sqrtf(fabsf(app * aqq)) && fabsf(apq) > 1e-30f) {
+          s_rot = 1;
           const float tau = (aqq - app) / (2.f * apq);
           const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
           c = 1.f / sqrtf(1.f + t * t);
@@ -174,55 +181,56 @@ __global__ void __launch_bounds__(256) gl_pinv_solve_kernel(const float* __restr
       }
       __syncthreads();
       // columns: (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q) for every row of A and V
-      for (int e = tid; e < half * n; e += 256) {
+      for (int e = tid; e < half * n; e += NT) {
         const int k = e / n, i = e - k * n;
         const float c = cs[2 * k], s = cs[2 * k + 1];
         const int p = pr[2 * k], q = pr[2 * k + 1];
-        const float ap = A[i * n + p], aq = A[i * n + q];
-        A[i * n + p] = c * ap - s * aq;
-        A[i * n + q] = s * ap + c * aq;
-        const float vp = V[i * n + p], vq = V[i * n + q];
-        V[i * n + p] = c * vp - s * vq;
-        V[i * n + q] = s * vp + c * vq;
+        const float ap = A[i * ld + p], aq = A[i * ld + q];
+        A[i * ld + p] = c * ap - s * aq;
+        A[i * ld + q] = s * ap + c * aq;
+        const float vp = V[i * ld + p], vq = V[i * ld + q];
+        V[i * ld + p] = c * vp - s * vq;
+        V[i * ld + q] = s * vp + c * vq;
       }
       __syncthreads();
       // rows of A
-      for (int e = tid; e < half * n; e += 256) {
+      for (int e = tid; e < half * n; e += NT) {
         const int k = e / n, j = e - k * n;
         const float c = cs[2 * k], s = cs[2 * k + 1];
         const int p = pr[2 * k], q = pr[2 * k + 1];
-        const float ap = A[p * n + j], aq = A[q * n + j];
-        A[p * n + j] = c * ap - s * aq;
-        A[q * n + j] = s * ap + c * aq;
+        const float ap = A[p * ld + j], aq = A[q * ld + j];
+        A[p * ld + j] = c * ap - s * aq;
+        A[q * ld + j] = s * ap + c * aq;
       }
       __syncthreads();
     }
+    if (!s_rot) break;  // uniform: read after the step's last barrier
   }
   // eigenvalues on the diagonal, eigenvectors in the columns of V
   float* g = cs;  // reuse: g_k = (V^T rhs)_k / lambda_k  or 0
   __shared__ float s_max;
   if (tid == 0) {
     float m = 0.f;
-    for (int k = 0; k < D; ++k) m = fmaxf(m, fabsf(A[k * n + k]));
+    for (int k = 0; k < D; ++k) m = fmaxf(m, fabsf(A[k * ld + k]));
     s_max = m;
   }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += NT) {
     float v = 0.f;
     if (k < D) {
-      const float lam = A[k * n + k];
+      const float lam = A[k * ld + k];
       if (fabsf(lam) > rcond * s_max) {
         float dot = 0.f;
-        for (int i = 0; i < D; ++i) dot += V[i * n + k] * rhs[i];
+        for (int i = 0; i < D; ++i) dot += V[i * ld + k] * rhs[i];
         v = dot / lam;
       }
     }
     g[k] = v;
   }
   __syncthreads();
-  for (int i = tid; i < D; i += 256) {
+  for (int i = tid; i < D; i += NT) {
     float v = 0.f;
-    for (int k = 0; k < D; ++k) v += V[i * n + k] * g[k];
+    for (int k = 0; k < D; ++k) v += V[i * ld + k] * g[k];
     coeffs[(size_t)b * D + i] = v;
   }
 }

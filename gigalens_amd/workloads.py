@@ -98,6 +98,15 @@ def make(name: str, num_pix: Optional[int] = None, batch: Optional[int] = None, 
             source_light=tfd.JointDistributionSequential([_sersic_src_prior(uniform_center=4.0) for _ in range(n_sources)])))
         return Workload("C4", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 256), batch or 512,
                         description=f"cluster: {n_halos} NFW halos + {n_sources} Sersic sources")
+    if name == "C3L":  # C3 with the shapelet amplitudes solved by least squares (shapelets-demo cell 7)
+        phys = PhysicalModel([EPL(), Shear()], [], [Shapelets(n_max, use_lstsq=True, interpolate=interpolate)])
+        src = tfd.JointDistributionNamed(dict(beta=tfd.LogNormal(math.log(0.1), 0.15), center_x=tfd.Normal(0, 0.01),
+                                              center_y=tfd.Normal(0, 0.01)))
+        prior = tfd.JointDistributionNamed(dict(
+            lens_mass=tfd.JointDistributionSequential([_epl_prior(), _shear_prior()]),
+            source_light=tfd.JointDistributionSequential([src])))
+        return Workload("C3L", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 128), batch or 1024,
+                        description=f"EPL+shear lens, Shapelets n_max={n_max} source with least-squares amplitudes")
     if name == "C6":  # cluster with member galaxies: dPIE halo + DPIESubhalo catalogue + Sersic sources
         cat = galaxy_catalogue(n_galaxies, half_width=0.5 * 0.065 * (num_pix or 256))
         phys = PhysicalModel([DPIE(), DPIESubhalo(lum_star=1.0, galaxy_catalogue=cat)], [],

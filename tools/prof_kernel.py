@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--num-pix", type=int, default=None)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--mode", default="grad", choices=["grad", "fwd", "img"])
+    ap.add_argument("--mode", default="grad", choices=["grad", "fwd", "img", "lstsq"])
     ap.add_argument("--direct", action="store_true", help="C3: direct (non-table) shapelets")
     args = ap.parse_args()
     from gigalens_amd import workloads
@@ -29,6 +29,25 @@ def main():
     if args.workload.upper() == "C3":
         kw["interpolate"] = not args.direct
     wl = workloads.make(args.workload, **kw)
+    if args.mode == "lstsq":  # linear-amplitude solve: end-to-end time of gl_lstsq_fwd (coefficients)
+        c2 = workloads.make("C2", num_pix=wl.sim_config.num_pix, batch=1)
+        obs, _, _ = workloads.synthetic_observation(c2, LensSimulator)
+        err = torch.sqrt(wl.background_rms ** 2 + obs.clamp_min(0) / wl.exp_time).contiguous()
+        sim = LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+        packed = sim.pack(wl.prior.sample(wl.batch, seed=0)).contiguous()
+        for _ in range(2):
+            sim._model.lstsq(packed, obs, err, 7, want="coeffs")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.iters):
+            sim._model.lstsq(packed, obs, err, 7, want="coeffs")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        print(f"{wl.name} B={wl.batch} N={sim._model.N} D={sim._model.num_linear()} lstsq: {ms:.3f} ms per solve "
+              f"-> {wl.batch / (ms * 1e-3):.0f} solves/s")
+        return
     obs, err, _ = workloads.synthetic_observation(wl, LensSimulator)
     sim = LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
     packed = sim.pack(wl.prior.sample(wl.batch, seed=0)).contiguous()
