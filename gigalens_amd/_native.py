@@ -60,6 +60,7 @@ SYMBOLS = {
                                        POINTER(c_float), POINTER(c_float)]),
     "gl_positions_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
+    "gl_lens_maps": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "gl_model_num_linear": (c_int, [c_void_p]),
     "gl_model_linear_column": (c_int, [c_void_p, c_int]),
     "gl_lstsq_workspace_bytes": (c_size_t, [c_void_p, c_int]),
@@ -246,6 +247,19 @@ class Model:
             _check(lib().gl_model_set_catalogue(self._h, int(component), int(base_kind), int(t.shape[0]), col_arr,
                                                 t.ctypes.data_as(POINTER(c_float))))
         self._ws = {}  # the workspace grows with the catalogue
+
+    def lens_maps(self, params, x, y):
+        """gl_lens_maps: ``x, y`` broadcastable to ``(..., B)``; returns ``(6, ...)`` = beta_x, beta_y, f_xx, f_xy, f_yx, f_yy."""
+        params = self._params(params)
+        B = params.shape[0]
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device)
+        y = torch.as_tensor(y, dtype=torch.float32, device=self.device)
+        shape = torch.broadcast_shapes(x.shape, y.shape, (B,))
+        xb = x.expand(shape).reshape(-1, B).contiguous()
+        yb = y.expand(shape).reshape(-1, B).contiguous()
+        out = torch.empty((6,) + tuple(xb.shape), dtype=torch.float32, device=self.device)
+        _check(lib().gl_lens_maps(self._h, _ptr(params), B, _ptr(xb), _ptr(yb), xb.shape[0], 1, _ptr(out), _stream()))
+        return out.reshape((6,) + tuple(shape))
 
     def num_linear(self):
         return lib().gl_model_num_linear(self._h)

@@ -996,6 +996,27 @@ int gl_positions_fwd_bwd(const gl_model* m, const float* params, int B, float* l
   return GL_OK;
 }
 
+int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, const float* y, int64_t n_pts,
+                 int xy_batched, float* out, void* hip_stream) {
+  if (!m || !params || !x || !y || !out) return fail(GL_EINVAL, "null argument");
+  if (B <= 0 || n_pts <= 0) return fail(GL_EINVAL, "B and n_pts must be positive");
+  if ((int)m->cats.size() != m->n_scaled) return fail(GL_EINVAL, "GL_SCALED component without a catalogue");
+  PosArgs a{};
+  a.comps = m->d_comps;
+  a.n_lens = m->n_lens;
+  a.P = m->P;
+  a.B = B;
+  a.params = params;
+  a.cats = m->d_cats;
+  a.gal_table = m->d_gal_table;
+  a.gal_static = m->d_gal_static;
+  const long long total = (long long)n_pts * B;
+  hipLaunchKernelGGL(gl_lens_maps_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, a,
+                     x, y, (long long)n_pts, xy_batched, out);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
 int gl_model_set_prior(gl_model* m, const gl_zcolumn* cols, int d, const float* const_row) {
   if (!m) return fail(GL_EINVAL, "model is null");
   if (d < 0 || (d > 0 && !cols)) return fail(GL_EINVAL, "bad prior column table");

@@ -120,6 +120,37 @@ __global__ void __launch_bounds__(64) gl_pos_p1_kernel(PosArgs a) {
   o[0] = bx; o[1] = by; o[2] = fxx; o[3] = fxy; o[4] = fyx; o[5] = fyy;
 }
 
+// LensSimulator.beta / .magnification / .convergence / .shear on arbitrary points (tf/simulator.py:72-107):
+// out[6][n_pts][B] = beta_x, beta_y, f_xx, f_xy, f_yx, f_yy summed over the lenses (Hessians as `lens.hessian`
+// resolves them in the reference: derivative of the deflection, plus the dPIS override's convergence excess)
+__global__ void __launch_bounds__(64) gl_lens_maps_kernel(PosArgs a, const float* __restrict__ x,
+                                                         const float* __restrict__ y, long long n_pts, int xy_batched,
+                                                         float* __restrict__ out) {
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_pts * a.B) return;
+  const long long pt = i / a.B;
+  const int b = (int)(i - pt * a.B);
+  const float px = xy_batched ? x[i] : x[pt], py = xy_batched ? y[i] : y[pt];
+  using R = gld::Dual<float, 2>;
+  R xd(px), yd(py);
+  xd.d[0] = 1.f;
+  yd.d[1] = 1.f;
+  float bx = px, by = py, fxx = 0.f, fxy = 0.f, fyx = 0.f, fyy = 0.f;
+  for (int l = 0; l < a.n_lens; ++l) {
+    CompDesc cd = a.comps[l];
+    R p[7];
+    float pf[7];
+    for (int k = 0; k < cd.n_par; ++k) { pf[k] = a.params[(size_t)b * a.P + cd.p_off + k]; p[k] = R(pf[k]); }
+    R ax, ay;
+    lens_point<R>(a, cd, p, xd, yd, ax, ay);
+    const float ex = lens_kappa_excess<float>(a, cd, pf, px, py);
+    bx -= ax.v; by -= ay.v;
+    fxx += ax.d[0] + ex; fxy += ax.d[1]; fyx += ay.d[0]; fyy += ay.d[1] + ex;
+  }
+  const long long st = n_pts * a.B;
+  out[i] = bx; out[st + i] = by; out[2 * st + i] = fxx; out[3 * st + i] = fxy; out[4 * st + i] = fyx; out[5 * st + i] = fyy;
+}
+
 __global__ void __launch_bounds__(64) gl_pos_p2_kernel(PosArgs a) {
   int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= a.B * a.F) return;

@@ -161,6 +161,25 @@ class LensSimulator(LensSimulatorInterface):
             beta_x, beta_y = beta_x - f_xi, beta_y - f_yi
         return beta_x, beta_y
 
+    def _lens_maps(self, x, y, lens_params):
+        packed = self._pack_partial({"lens_mass": lens_params}) if not torch.is_tensor(lens_params) else lens_params
+        return self._model.lens_maps(packed, x, y)
+
+    def magnification(self, x, y, lens_params: List[Dict]):
+        """tf/simulator.py:80-91: ``1 / det(1 - Hessian)`` at ``(x, y)`` (trailing axis = batch)."""
+        _, _, fxx, fxy, fyx, fyy = self._lens_maps(x, y, lens_params)
+        return 1.0 / ((1 - fxx) * (1 - fyy) - fxy * fyx)
+
+    def convergence(self, x, y, lens_params: List[Dict]):
+        """tf/simulator.py:93-98 (sum of the lenses' ``(f_xx + f_yy) / 2``, tf/profile.py:30-34)."""
+        _, _, fxx, _, _, fyy = self._lens_maps(x, y, lens_params)
+        return 0.5 * (fxx + fyy)
+
+    def shear(self, x, y, lens_params: List[Dict]):
+        """tf/simulator.py:100-107: ``(gamma1, gamma2) = ((f_xx - f_yy)/2, f_xy)`` (tf/profile.py:36-42)."""
+        _, _, fxx, fxy, _, fyy = self._lens_maps(x, y, lens_params)
+        return 0.5 * (fxx - fyy), fxy
+
     def simulate(self, params, no_deflection=False):
         """tf/simulator.py:109-156.  Returns ``(bs, H, W)`` squeezed like ``tf.squeeze``."""
         packed = params if torch.is_tensor(params) else self.pack(params)

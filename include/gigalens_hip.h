@@ -198,6 +198,13 @@ int gl_scaled_eval(int base_kind, int n_galaxies, const int32_t scale_col[3], co
                    const float* y, int64_t n_pts, int B, int xy_batched, const float* scales, int n_scales,
                    float* out0, float* out1, void* hip_stream);
 
+/* LensSimulator.beta / .magnification / .convergence / .shear on arbitrary points (tf/simulator.py:72-107):
+ * out [6][n_pts][B] = beta_x, beta_y, f_xx, f_xy, f_yx, f_yy, the Hessian summed over the lenses as `lens.hessian`
+ * resolves it in the reference (tf/profile.py:9-43 autodiff; analytic overrides incl. piemd.py:62-83).
+ * x, y as in gl_profile_eval ([n_pts,B] when xy_batched, else [n_pts]); params [B,P] (only lens columns are read). */
+int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, const float* y, int64_t n_pts,
+                 int xy_batched, float* out, void* hip_stream);
+
 /* Plugin-level point evaluation, the reference's MassProfile.deriv / LightProfile.light called on
  * arbitrary coordinates (tests/test_profiles.py calls exactly these):
  *   x, y [n_pts, B] when xy_batched, else [n_pts] shared by every sample (pixel-major, batch-minor

@@ -114,3 +114,32 @@ def test_log_prob_pixels_plus_positions():
     assert torch.allclose(lp, lp_pix + lp_pos - prior_term, rtol=2e-5, atol=1e-2)
     assert torch.allclose(red, 0.5 * (red_pix + red_pos), rtol=2e-5)
     assert torch.allclose(pm.log_like(sim, z0), lp - prior_term, rtol=2e-5, atol=1e-2)
+
+
+def test_magnification_convergence_shear_maps():
+    """LensSimulator.magnification / convergence / shear (tf/simulator.py:80-107) on a grid of points."""
+    from gigalens_amd import workloads
+    from gigalens_amd.simulator import LensSimulator
+    from oracle import ref_torch as ref
+    phys, prior, cfg, B = _setup("mixed")
+    sim = LensSimulator(phys, cfg, bs=B)
+    wl = workloads.Workload("POS", phys, prior, cfg, B)
+    packed = H.sample_packed(wl, sim, seed=3)
+    r = np.random.default_rng(0)
+    x = (r.uniform(-2, 2, 300)).astype(np.float32)[:, None].repeat(B, 1)
+    y = (r.uniform(-2, 2, 300)).astype(np.float32)[:, None].repeat(B, 1)
+    lens_params = H.struct_from_packed(phys, packed)["lens_mass"]
+    mu = sim.magnification(x, y, lens_params).cpu().numpy()
+    kap = sim.convergence(x, y, lens_params).cpu().numpy()
+    g1, g2 = (t.cpu().numpy() for t in sim.shear(x, y, lens_params))
+    rs = ref.RefSimulator(phys, cfg, B, dtype=torch.float64)
+    p64 = H.struct_from_packed(phys, packed.cpu().double())["lens_mass"]
+    fxx, fxy, fyx, fyy = (t.detach().numpy() for t in ref.lens_hessian_autodiff(rs, torch.as_tensor(x).double(),
+                                                                               torch.as_tensor(y).double(), p64))
+    mu_o = 1.0 / ((1 - fxx) * (1 - fyy) - fxy * fyx)
+    ok = np.abs(mu_o) < 50  # away from the critical curves (1/det amplifies fp32 rounding there)
+    assert ok.mean() > 0.8
+    assert np.allclose(mu[ok], mu_o[ok], rtol=2e-3)
+    assert np.allclose(kap, 0.5 * (fxx + fyy), rtol=1e-4, atol=1e-5)
+    assert np.allclose(g1, 0.5 * (fxx - fyy), rtol=1e-4, atol=1e-5)
+    assert np.allclose(g2, fxy, rtol=1e-4, atol=1e-5)
