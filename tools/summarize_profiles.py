@@ -49,10 +49,11 @@ def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_ker
 
 summary = {}
 rows = stats_table("bench_stats", f"{tag}_bench_kernel_stats.md")
-for w in ("C2", "C3", "C4"):
+for w in ("C2", "C3", "C4", "C6", "C3L"):
     stats_table(f"kernel_stats_{w}", f"{tag}_{w}_kernel_stats.md", top=6)
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mix", "pmc_clk"):
     summary[d] = pmc(d)
+summary["pmc_C6"] = pmc("pmc_C6", kernel_filter=("gl_main_kernel<3",))
 fetch_kb = summary.get("pmc_fetch", {}).get("FETCH_SIZE")
 write_kb = summary.get("pmc_write", {}).get("WRITE_SIZE")
 if fetch_kb is not None and write_kb is not None:
