@@ -60,6 +60,11 @@ SYMBOLS = {
                                        POINTER(c_float), POINTER(c_float)]),
     "gl_positions_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
+    "gl_series_precompute": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, POINTER(c_float), c_int, c_int, c_void_p,
+                                     c_void_p, c_int64, c_void_p, c_void_p]),
+    "gl_model_set_series": (c_int, [c_void_p, c_int, c_float, c_void_p]),
+    "gl_series_eval": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                               c_void_p]),
     "gl_lens_maps": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "gl_model_num_linear": (c_int, [c_void_p]),
     "gl_model_linear_column": (c_int, [c_void_p, c_int]),
@@ -166,6 +171,39 @@ def scaled_eval(profile, x, y, scales):
     _check(lib().gl_scaled_eval(base_kind, table.shape[0], col_arr, _ptr(profile._dev_table), _ptr(xb), _ptr(yb),
                                 xb.shape[0], B, 1, _ptr(P), P.shape[1], _ptr(out0), _ptr(out1), _stream()))
     return out0.reshape(out_shape), out1.reshape(out_shape)
+
+
+def series_precompute(series):
+    """MassSeries.set_deriv (series_profile.py:61-62) through gl_series_precompute: device [2, order+1, n_points]."""
+    dev = device()
+    base_kind, cols, table, scales = series._series_inputs()
+    x = torch.as_tensor(series.x, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    y = torch.as_tensor(series.y, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    tab = torch.from_numpy(np.ascontiguousarray(table, dtype=np.float32)).to(dev)
+    sc = (c_float * len(scales))(*[float(v) for v in scales])
+    out = torch.empty((2, series.order + 1, x.numel()), dtype=torch.float32, device=dev)
+    _check(lib().gl_series_precompute(int(base_kind), tab.shape[0], (c_int32 * 3)(*cols), _ptr(tab), sc, len(scales),
+                                      series.order, _ptr(x), _ptr(y), x.numel(), _ptr(out), _stream()))
+    return out
+
+
+def series_eval(series, amplitude, var):
+    """MassSeries.deriv (series_profile.py:76-81): field shape + trailing batch axis."""
+    dev = device()
+    a = torch.as_tensor(amplitude, dtype=torch.float32, device=dev).reshape(-1)
+    v = torch.as_tensor(var, dtype=torch.float32, device=dev).reshape(-1)
+    B = max(a.numel(), v.numel())
+    a, v = a.expand(B).contiguous(), v.expand(B).contiguous()
+    n = series._coefs.shape[-1]
+    o0 = torch.empty((n, B), dtype=torch.float32, device=dev)
+    o1 = torch.empty_like(o0)
+    _check(lib().gl_series_eval(_ptr(series._coefs), series.order, n, B, _ptr(a), _ptr(v), float(series.series_var_0),
+                                _ptr(o0), _ptr(o1), _stream()))
+    shape = tuple(torch.as_tensor(series.x).shape)
+    if shape and shape[-1] == B and len(shape) > 1:  # grid given per batch element, as the reference's (N, bs) grids
+        shape = shape[:-1]
+        o0, o1 = o0.reshape(-1, B, B).diagonal(dim1=1, dim2=2), o1.reshape(-1, B, B).diagonal(dim1=1, dim2=2)
+    return o0.reshape(shape + (B,)), o1.reshape(shape + (B,))
 
 
 def profile_eval(profile, x, y, kwargs):
@@ -279,6 +317,14 @@ class Model:
         _check(lib().gl_lstsq_fwd(self._h, _ptr(params), _ptr(obs), _ptr(err), B, int(parts), _ptr(coeffs),
                                   _ptr(stacked), _ptr(image), _ptr(ws), ws.numel(), _stream()))
         return ({"coeffs": coeffs, "stacked": stacked, "image": image}[want],)
+
+    def set_series(self, component, r0, coeffs):
+        """Attach the coefficient field of a GL_SERIES lens (gl_model_set_series)."""
+        _require_cuda(coeffs, "series coefficients")
+        if coeffs.shape[-1] != self.N:
+            raise NativeLibraryError(f"series field has {coeffs.shape[-1]} points, the model grid {self.N}")
+        with torch.cuda.device(self.device):
+            _check(lib().gl_model_set_series(self._h, int(component), float(r0), _ptr(coeffs.contiguous())))
 
     def set_prior(self, columns, const_row):
         """columns: list of (param_col, bijector, prior, a, b, lo, hi, log_norm); const_row: [P] floats."""

@@ -93,6 +93,11 @@ struct gl_model {
   CatDev* d_cats = nullptr;
   float* d_gal_table = nullptr;   // [G][7]
   float* d_gal_static = nullptr;  // [G][DP_NS]
+  // series-expansion lenses (gl_model_set_series): one coefficient field per GL_SERIES component
+  std::vector<SeriesDev> series;      // device pointers owned by the model
+  std::vector<int> series_comp;       // component of each slot
+  int n_series = 0, n_series_set = 0;
+  SeriesDev* d_series = nullptr;
   // linear amplitudes (lstsq_simulate): channel k of the basis stack <-> packed parameter column
   std::vector<int> lin_cols;
   int* d_lin_cols = nullptr;
@@ -297,6 +302,7 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.gal_dyn = w.gal_dyn;
   a.G = m->G;
   a.scaled_first = m->cats.empty() ? -1 : m->cats[0].dev.comp;
+  a.series = m->d_series;
   return a;
 }
 
@@ -307,6 +313,9 @@ int check_call(const gl_model* m, const void* params, int B, void* ws, size_t ws
   if ((int)m->cats.size() != m->n_scaled)
     return fail(GL_EINVAL, "%d GL_SCALED component(s) without a catalogue (gl_model_set_catalogue)",
                 m->n_scaled - (int)m->cats.size());
+  if (m->n_series_set != m->n_series)
+    return fail(GL_EINVAL, "%d GL_SERIES component(s) without a coefficient field (gl_model_set_series)",
+                m->n_series - m->n_series_set);
   if (!ws) return fail(GL_EINVAL, "workspace is null");
   size_t need = gl_workspace_bytes(m, B);
   if (ws_bytes < need) return fail(GL_ENOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, need);
@@ -360,6 +369,7 @@ int run_order(const gl_model* m, int B, const Workspace& w, MainArgs* a, hipStre
 
 // image-position likelihood on the packed parameter rows `params` [B,P] (already on the device)
 int run_positions(const gl_model* m, const float* params, int B, const Workspace& w, bool want_grad, hipStream_t stream) {
+  if (m->n_series) return fail(GL_EUNSUPPORTED, "a series-expansion lens lives on the pixel grid only (series_profile.py:76-81): no image-position likelihood");
   PosArgs a{};
   a.comps = m->d_comps;
   a.n_lens = m->n_lens;
@@ -535,7 +545,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   for (int i = 0; i < n_comp; ++i) {
     const gl_component& c = comps[i];
     const bool mass = i < n_lens;
-    const bool is_mass_kind = c.kind >= GL_EPL && c.kind <= GL_SCALED;
+    const bool is_mass_kind = c.kind >= GL_EPL && c.kind <= GL_SERIES;
     const bool is_light_kind = c.kind >= GL_SERSIC && c.kind <= GL_SHAPELETS;
     if ((mass && !is_mass_kind) || (!mass && !is_light_kind)) {
       delete m;
@@ -547,7 +557,11 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
       if (iparam > 1000) { delete m; return fail(GL_EINVAL, "EPL niter %d too large", iparam); }
     }
     if (c.kind == GL_EPL) m->has_epl = true;
-    if (c.kind >= GL_DPIS && c.kind <= GL_SCALED) m->has_dpie = true;
+    if (c.kind >= GL_DPIS && c.kind <= GL_SERIES) m->has_dpie = true;
+    if (c.kind == GL_SERIES && (iparam < 0 || iparam > SERIES_MAX_ORDER)) {
+      delete m;
+      return fail(GL_EINVAL, "component %d: series order %d outside [0, %d]", i, iparam, SERIES_MAX_ORDER);
+    }
     if (c.kind == GL_SCALED) {
       if (iparam < 1 || iparam > 3) { delete m; return fail(GL_EINVAL, "component %d: GL_SCALED takes 1..3 scales, got %d", i, iparam); }
       ++m->n_scaled;
@@ -570,6 +584,11 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     cd.n_par = kind_num_params(c.kind, iparam);
     cd.n_acc = kind_num_acc(c.kind, iparam);
     if (c.kind == GL_SCALED) cd.iparam = -1;  // catalogue slot, set by gl_model_set_catalogue
+    if (c.kind == GL_SERIES) {
+      cd.flags = (unsigned)m->n_series++;
+      m->series.push_back(SeriesDev{nullptr, 0.f, iparam});
+      m->series_comp.push_back(i);
+    }
     cd.lin_off = (int)m->lin_cols.size();
     for (int k = 0; k < kind_num_linear(c.kind, iparam); ++k) m->lin_cols.push_back(p_off + kind_linear_col(c.kind, iparam) + k);
     p_off += cd.n_par;
@@ -694,6 +713,9 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_src) (void)hipFree(m->d_src);
   if (m->d_const) (void)hipFree(m->d_const);
   if (m->d_lin_cols) (void)hipFree(m->d_lin_cols);
+  for (auto& sv : m->series)
+    if (sv.coef) (void)hipFree((void*)sv.coef);
+  if (m->d_series) (void)hipFree(m->d_series);
   if (m->d_cats) (void)hipFree(m->d_cats);
   if (m->d_gal_table) (void)hipFree(m->d_gal_table);
   if (m->d_gal_static) (void)hipFree(m->d_gal_static);
@@ -821,6 +843,7 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   if (!params || !workspace) return fail(GL_EINVAL, "params / workspace is null");
   if (B <= 0 || B > 65535) return fail(GL_EINVAL, "batch size %d outside [1, 65535]", B);
   if ((int)m->cats.size() != m->n_scaled) return fail(GL_EINVAL, "GL_SCALED component without a catalogue");
+  if (m->n_series_set != m->n_series) return fail(GL_EINVAL, "GL_SERIES component without a coefficient field");
   const bool solve = coeffs_or_null || image_or_null;
   if (solve && (!obs || !err)) return fail(GL_EINVAL, "obs / err_map are required to solve for the coefficients");
   if (!solve && !stacked_or_null) return fail(GL_EINVAL, "nothing to compute");
@@ -881,6 +904,63 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
                        image_or_null);
     GL_HIP(hipGetLastError());
   }
+  return GL_OK;
+}
+
+int gl_series_precompute(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev,
+                         const float* scales, int n_scales, int order, const float* x_dev, const float* y_dev,
+                         int64_t n_pts, float* coeffs_dev, void* hip_stream) {
+  if (!scale_col || !table_dev || !scales || !x_dev || !y_dev || !coeffs_dev) return fail(GL_EINVAL, "null argument");
+  if (base_kind != GL_DPIS && base_kind != GL_DPIE && base_kind != GL_DPIEP)
+    return fail(GL_EUNSUPPORTED, "series expansion over profile kind %d is not built (dPIS, dPIE, dPIEP are)", base_kind);
+  if (n_galaxies <= 0 || n_pts <= 0 || n_scales < 1 || n_scales > 3) return fail(GL_EINVAL, "bad sizes");
+  if (order < 0 || order > SERIES_MAX_ORDER) return fail(GL_EINVAL, "order %d outside [0, %d]", order, SERIES_MAX_ORDER);
+  for (int k = 0; k < 3; ++k)
+    if (scale_col[k] >= n_scales) return fail(GL_EINVAL, "scale_col[%d]=%d outside the %d scales", k, scale_col[k], n_scales);
+  if (scale_col[2] < 0) return fail(GL_EINVAL, "the series variable r_cut must be a scaled parameter");
+  ScaledDesc sd{base_kind, n_galaxies, {scale_col[0], scale_col[1], scale_col[2]}};
+  float s[3] = {1.f, 1.f, 1.f};
+  for (int k = 0; k < n_scales; ++k) s[k] = scales[k];
+  dim3 grid((unsigned)((n_pts + 63) / 64)), block(64);
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (order <= 3)
+    hipLaunchKernelGGL((gl_series_precompute_kernel<3>), grid, block, 0, stream, sd, table_dev, s[0], s[1], s[2], order,
+                       x_dev, y_dev, (long long)n_pts, coeffs_dev);
+  else
+    hipLaunchKernelGGL((gl_series_precompute_kernel<5>), grid, block, 0, stream, sd, table_dev, s[0], s[1], s[2], order,
+                       x_dev, y_dev, (long long)n_pts, coeffs_dev);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+int gl_model_set_series(gl_model* m, int component, float r0, const float* coeffs_dev) {
+  if (!m || !coeffs_dev) return fail(GL_EINVAL, "null argument");
+  if (component < 0 || component >= m->n_lens || m->comps[component].kind != K_SERIES)
+    return fail(GL_EINVAL, "component %d is not a GL_SERIES lens", component);
+  const int slot = (int)m->comps[component].flags;
+  SeriesDev& sv = m->series[slot];
+  const size_t bytes = sizeof(float) * 2 * (size_t)(sv.order + 1) * m->N;
+  if (!sv.coef) {
+    float* p = nullptr;
+    GL_HIP(hipMalloc((void**)&p, bytes));
+    sv.coef = p;
+    ++m->n_series_set;
+  }
+  GL_HIP(hipMemcpy((void*)sv.coef, coeffs_dev, bytes, hipMemcpyDeviceToDevice));
+  sv.r0 = r0;
+  if (!m->d_series) GL_HIP(hipMalloc((void**)&m->d_series, sizeof(SeriesDev) * m->series.size()));
+  GL_HIP(hipMemcpy(m->d_series, m->series.data(), sizeof(SeriesDev) * m->series.size(), hipMemcpyHostToDevice));
+  return GL_OK;
+}
+
+int gl_series_eval(const float* coeffs_dev, int order, int64_t n_pts, int B, const float* theta_E, const float* r_cut,
+                   float r0, float* out0, float* out1, void* hip_stream) {
+  if (!coeffs_dev || !theta_E || !r_cut || !out0 || !out1) return fail(GL_EINVAL, "null argument");
+  if (order < 0 || order > SERIES_MAX_ORDER || n_pts <= 0 || B <= 0) return fail(GL_EINVAL, "bad sizes");
+  const long long total = (long long)n_pts * B;
+  hipLaunchKernelGGL(gl_series_eval_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                     coeffs_dev, order, (long long)n_pts, B, theta_E, r_cut, r0, out0, out1);
+  GL_HIP(hipGetLastError());
   return GL_OK;
 }
 
@@ -1001,6 +1081,7 @@ int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, 
   if (!m || !params || !x || !y || !out) return fail(GL_EINVAL, "null argument");
   if (B <= 0 || n_pts <= 0) return fail(GL_EINVAL, "B and n_pts must be positive");
   if ((int)m->cats.size() != m->n_scaled) return fail(GL_EINVAL, "GL_SCALED component without a catalogue");
+  if (m->n_series) return fail(GL_EUNSUPPORTED, "a series-expansion lens lives on the pixel grid only (series_profile.py:76-81)");
   PosArgs a{};
   a.comps = m->d_comps;
   a.n_lens = m->n_lens;
@@ -1091,6 +1172,7 @@ int gl_profile_eval(const gl_component* comp, const float* x, const float* y, in
   int npar = kind_num_params(comp->kind, comp->iparam);
   if (npar < 0) return fail(GL_EINVAL, "unknown profile kind %d", comp->kind);
   if (comp->kind == GL_SCALED) return fail(GL_EINVAL, "GL_SCALED needs its catalogue: use gl_scaled_eval");
+  if (comp->kind == GL_SERIES) return fail(GL_EINVAL, "GL_SERIES needs its coefficient field: use gl_series_eval");
   const bool mass = comp->kind <= GL_DPIEP;
   if (mass && !out1) return fail(GL_EINVAL, "out1 is required for mass profiles");
   CompDesc cd{};

@@ -15,6 +15,7 @@
 #include "gl_dpie.h"
 #include "gl_vec.hip.h"
 #include "gl_members.hip.h"
+#include "gl_series.h"
 
 namespace glk {
 using namespace glp;
@@ -37,6 +38,13 @@ struct CatDev {
   int comp;    // component index
   int col[3];  // theta_E, r_core, r_cut: column of the scale inside the component's parameter row, or -1
   int pad;
+};
+
+// coefficient field of one K_SERIES lens (gl_model_set_series): coef[2][order+1][N]
+struct SeriesDev {
+  const float* coef;
+  float r0;
+  int order;
 };
 
 enum Mode : int { IMG_FWD = 0, IMG_BWD = 1, LL_FWD = 2, LL_GRAD = 3, IMG_BASIS = 4 };
@@ -72,6 +80,7 @@ struct MainArgs {
   int G;
   int scaled_first;  // the K_SCALED lens whose scale tangents ride along the ray-shooting pass (-1: none)
   int n_lin;         // IMG_BASIS: channels of the stack  img[B][n_lin][img_stride]
+  const SeriesDev* series;
 };
 
 // ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
@@ -167,6 +176,7 @@ __global__ void __launch_bounds__(128) gl_prep_kernel(const CompDesc* __restrict
     case K_SIS: sis_prep<float>(p, d); break;
     case K_DPIS: case K_DPIE: case K_DPIEP: dpie_prep<float>(cd.kind, p, d); break;
     case K_SCALED: d[0] = d[1] = d[2] = d[3] = 0.f; break;
+    case K_SERIES: d[0] = p[0]; d[1] = p[1]; d[2] = d[3] = 0.f; break;
     case K_SERSIC: sersic_prep<float>(p, false, d); break;
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, d); break;
@@ -250,6 +260,7 @@ __global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restric
     case K_SIS: sis_prep<float>(p, dd); break;
     case K_DPIS: case K_DPIE: case K_DPIEP: dpie_prep<float>(cd.kind, p, dd); break;
     case K_SCALED: dd[0] = dd[1] = dd[2] = dd[3] = 0.f; break;
+    case K_SERIES: dd[0] = p[0]; dd[1] = p[1]; dd[2] = dd[3] = 0.f; break;
     case K_SERSIC: sersic_prep<float>(p, false, dd); break;
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, dd); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, dd); break;
@@ -507,6 +518,23 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             for (int t = 0; t < T; ++t) { float ax, ay; piep_fwd<float>(d, d + DP_NS, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
           }
           break;
+        case K_SERIES: if constexpr (DP) {  // alpha = theta_E sum_n C_n(pixel) (r_cut - r0)^n   (series_profile.py:76-95)
+          const SeriesDev sv = a.series[comps[l].flags];
+          const float te = d[0], dl = d[1] - sv.r0;
+          const size_t stn = (size_t)a.N;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const int j = base + t * WG + tid;
+            const float* c = sv.coef + (j < p1 ? j : p1 - 1);
+            float ax = c[(size_t)sv.order * stn], ay = c[(size_t)(2 * sv.order + 1) * stn];
+            for (int n = sv.order - 1; n >= 0; --n) {
+              ax = ax * dl + c[(size_t)n * stn];
+              ay = ay * dl + c[(size_t)(sv.order + 1 + n) * stn];
+            }
+            bx[t] -= te * ax;
+            by[t] -= te * ay;
+          }
+        } break;
         case K_SCALED: if constexpr (DP) {  // sum over the catalogue (scaling_relation.py:61-70), gl_members.hip.h
           const CatDev cat = a.cats[comps[l].iparam];
           const float* __restrict__ gs = a.gal_static + (size_t)cat.g_off * DP_NS;
@@ -735,6 +763,27 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             }
             wave_acc<DP_NACC>(acc, ac, cd.a_off);
           } break;
+          case K_SERIES: if constexpr (DP) {
+            const SeriesDev sv = a.series[cd.flags];
+            const float te = d[0], dl = d[1] - sv.r0;
+            const size_t stn = (size_t)a.N;
+            float acc[2] = {0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const int j = base + t * WG + tid;
+              const float* c = sv.coef + (j < p1 ? j : p1 - 1);
+              float ax = c[(size_t)sv.order * stn], ay = c[(size_t)(2 * sv.order + 1) * stn], dx = 0.f, dy = 0.f;
+              for (int n = sv.order - 1; n >= 0; --n) {  // Horner with derivative
+                dx = dx * dl + ax;
+                dy = dy * dl + ay;
+                ax = ax * dl + c[(size_t)n * stn];
+                ay = ay * dl + c[(size_t)(sv.order + 1 + n) * stn];
+              }
+              acc[0] += gbx[t] * ax + gby[t] * ay;
+              acc[1] += te * (gbx[t] * dx + gby[t] * dy);
+            }
+            wave_acc<2>(acc, ac, cd.a_off);
+          } break;
           case K_SCALED: if constexpr (DP) {
             // gradient of the scales = cotangent . (tangents carried by the ray-shooting pass); a second catalogue in
             // the same model re-evaluates its members here
@@ -819,6 +868,7 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
           for (int k = 0; k < 3; ++k)
             if (cat.col[k] >= 0) g[cat.col[k]] = acc[k];
         } break;
+        case K_SERIES: g[0] = acc[0]; g[1] = acc[1]; break;
         case K_SERSIC: sersic_finalize<float>(p, false, acc, g); break;
         case K_SERSIC_ELLIPSE: sersic_finalize<float>(p, true, acc, g); break;
         case K_SHAPELETS: shapelets_finalize<float>(p, cd.iparam, acc, g); break;
@@ -914,6 +964,44 @@ __global__ void __launch_bounds__(256) gl_scaled_point_kernel(ScaledDesc sd, con
   }
   out0[i] = sx;
   out1[i] = sy;
+}
+
+// Taylor coefficients of the population deflection at arbitrary points: coeffs[2][order+1][n_pts]
+template <int N>
+__global__ void __launch_bounds__(64) gl_series_precompute_kernel(ScaledDesc sd, const float* __restrict__ table,
+                                                                 float s0, float s1, float s2, int order,
+                                                                 const float* __restrict__ x, const float* __restrict__ y,
+                                                                 long long n_pts, float* __restrict__ coeffs) {
+  const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_pts) return;
+  // float64 jets: near a member's foci (removable 0/0 of the Kassiola-Kovner form) the k-th coefficient loses
+  // ~(1/distance)^k digits -- in fp32 orders >= 2 are noise at ~1 % of the pixels; the one-off precompute can afford
+  // CDNA4's full-rate fp64, the stored field is fp32 like every other operand of the path
+  const double scales[3] = {(double)s0, (double)s1, (double)s2};
+  double cx[N + 1], cy[N + 1];
+  series_point<N, double>(sd, table, scales, (double)x[i], (double)y[i], cx, cy);
+  for (int n = 0; n <= order; ++n) {
+    coeffs[(size_t)n * n_pts + i] = (float)cx[n];
+    coeffs[(size_t)(order + 1 + n) * n_pts + i] = (float)cy[n];
+  }
+}
+
+__global__ void __launch_bounds__(256) gl_series_eval_kernel(const float* __restrict__ coeffs, int order, long long n_pts,
+                                                             int B, const float* __restrict__ theta_E,
+                                                             const float* __restrict__ r_cut, float r0,
+                                                             float* __restrict__ out0, float* __restrict__ out1) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pts * B) return;
+  const long long pt = i / B;
+  const int b = (int)(i - pt * B);
+  const float dl = r_cut[b] - r0;
+  float ax = coeffs[(size_t)order * n_pts + pt], ay = coeffs[(size_t)(2 * order + 1) * n_pts + pt];
+  for (int n = order - 1; n >= 0; --n) {
+    ax = ax * dl + coeffs[(size_t)n * n_pts + pt];
+    ay = ay * dl + coeffs[(size_t)(order + 1 + n) * n_pts + pt];
+  }
+  out0[i] = theta_E[b] * ax;
+  out1[i] = theta_E[b] * ay;
 }
 
 }  // namespace glk

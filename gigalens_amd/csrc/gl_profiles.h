@@ -25,6 +25,7 @@ enum Kind : int {
   K_EPL = 1, K_SIE = 2, K_NFW = 3, K_SHEAR = 4, K_SIS = 5,
   K_DPIS = 6, K_DPIE = 7, K_DPIEP = 8,  // gl_dpie.h
   K_SCALED = 9,                         // ScalingRelation over a galaxy catalogue (gl_dpie.h); iparam = catalogue slot
+  K_SERIES = 10,                        // series expansion of a (scaled) dPIE in r_cut (gl_series.h); iparam = order, flags = field slot
   K_SERSIC = 16, K_SERSIC_ELLIPSE = 17, K_SHAPELETS = 18
 };
 
@@ -70,6 +71,7 @@ GL_HD int kind_num_params(int kind, int iparam) {
     case K_DPIE:
     case K_DPIEP: return 7;
     case K_SCALED: return (iparam >= 1 && iparam <= 3) ? iparam : -1;  // the population scales
+    case K_SERIES: return (iparam >= 0 && iparam <= 5) ? 2 : -1;       // theta_E, r_cut
     case K_SERSIC: return 5;
     case K_SERSIC_ELLIPSE: return 7;
     case K_SHAPELETS: return 3 + sh_layers(iparam);
@@ -87,6 +89,7 @@ GL_HD int kind_num_derived(int kind, int iparam) {
     case K_DPIE:
     case K_DPIEP: return 32;  // DPX_ND
     case K_SCALED: return 4;  // the member blocks live in the catalogue workspace, not in the sample's LDS block
+    case K_SERIES: return 4;
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_ND + 2;
     case K_SHAPELETS: return SHP_AMP + ((sh_layers(iparam) + 3) & ~3);
@@ -122,6 +125,7 @@ GL_HD int kind_num_acc(int kind, int iparam) {
     case K_DPIE:
     case K_DPIEP: return 7;  // DP_NACC
     case K_SCALED: return 3;
+    case K_SERIES: return 2;
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_NACC;
     case K_SHAPELETS: return SHPA_AMP + sh_layers(iparam);

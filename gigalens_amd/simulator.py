@@ -143,8 +143,13 @@ class LensSimulator(LensSimulatorInterface):
         self._model = _native.Model(comps, len(phys_model.lenses), len(phys_model.lens_light),
                                     len(phys_model.source_light), Hs, Ws, ss, img_X, img_Y, pix_index,
                                     self.conversion_factor, psf)
-        for i, lens in enumerate(phys_model.lenses):  # galaxy catalogues of ScalingRelation lenses
-            if hasattr(lens, "_catalogue"):
+        for i, lens in enumerate(phys_model.lenses):
+            if getattr(lens, "_kind", 0) == 10:  # series expansion: the field must live on THIS pixel list
+                if lens.x is not self.img_X or lens._coefs is None:
+                    lens.set_grid(self.img_X, self.img_Y)
+                    lens.set_deriv()
+                self._model.set_series(i, lens.series_var_0, lens._coefs)
+            elif hasattr(lens, "_catalogue"):  # galaxy catalogues of ScalingRelation lenses
                 self._model.set_catalogue(i, *lens._catalogue())
         self._layout = phys_model._packing()
         assert self._layout.P == self._model.P

@@ -16,6 +16,7 @@ from gigalens_amd.model import PhysicalModel
 from gigalens_amd.profiles.light.sersic import Sersic, SersicEllipse
 from gigalens_amd.profiles.light.shapelets import Shapelets
 from gigalens_amd.profiles.mass.epl import EPL
+from gigalens_amd.profiles.mass.dpie_series import DPIESubhaloSeries
 from gigalens_amd.profiles.mass.dpie_subhalo import DPIESubhalo
 from gigalens_amd.profiles.mass.nfw import NFW
 from gigalens_amd.profiles.mass.piemd import DPIE
@@ -107,6 +108,23 @@ def make(name: str, num_pix: Optional[int] = None, batch: Optional[int] = None, 
             source_light=tfd.JointDistributionSequential([src])))
         return Workload("C3L", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 128), batch or 1024,
                         description=f"EPL+shear lens, Shapelets n_max={n_max} source with least-squares amplitudes")
+    if name == "C6S":  # C6 with the member population behind the series-expansion accelerator (order 3 in r_cut)
+        cat = galaxy_catalogue(n_galaxies, half_width=0.5 * 0.065 * (num_pix or 256))
+        members = DPIESubhaloSeries(lum_star=1.0, galaxy_catalogue=cat, order=3)
+        members.set_constants(dict(theta_E=0.3, r_core=0.02, r_cut=2.0))
+        phys = PhysicalModel([DPIE(), members], [], [Sersic() for _ in range(n_sources)])
+        halo = tfd.JointDistributionNamed(dict(
+            theta_E=tfd.LogNormal(math.log(12.0), 0.1), r_core=tfd.LogNormal(math.log(3.0), 0.2),
+            r_cut=tfd.LogNormal(math.log(150.0), 0.1), center_x=tfd.Normal(0, 0.3), center_y=tfd.Normal(0, 0.3),
+            e1=tfd.Normal(0.15, 0.05), e2=tfd.Normal(-0.1, 0.05)))
+        mem_prior = tfd.JointDistributionNamed(dict(theta_E=tfd.LogNormal(math.log(0.3), 0.2),
+                                                    r_cut=tfd.LogNormal(math.log(2.0), 0.1)))
+        prior = tfd.JointDistributionNamed(dict(
+            lens_mass=tfd.JointDistributionSequential([halo, mem_prior]),
+            source_light=tfd.JointDistributionSequential([_sersic_src_prior(uniform_center=3.0) for _ in range(n_sources)])))
+        return Workload("C6S", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 256), batch or 128,
+                        description=f"cluster: dPIE halo + series expansion of {n_galaxies} scaled dPIE galaxies + "
+                        f"{n_sources} Sersic sources")
     if name == "C6":  # cluster with member galaxies: dPIE halo + DPIESubhalo catalogue + Sersic sources
         cat = galaxy_catalogue(n_galaxies, half_width=0.5 * 0.065 * (num_pix or 256))
         phys = PhysicalModel([DPIE(), DPIESubhalo(lum_star=1.0, galaxy_catalogue=cat)], [],

@@ -51,6 +51,9 @@ typedef enum gl_kind {
                     galaxies of one dPIE-family profile whose theta_E / r_core / r_cut follow (L/L*)^power * scale;
                     the packed parameters are the scales, in the order of the reference's `scaling_params`;
                     iparam = their number (1..3); the catalogue is attached with gl_model_set_catalogue */
+  GL_SERIES = 10, /* tf/series/series_profile.py:9-95 with dpie_series.py / scaling_series.py / dpie_subhalo_series.py:
+                     the (scaled) dPIE deflection expanded in the cut radius around r0, precomputed on the model grid;
+                     parameters [theta_E, r_cut]; iparam = order (0..5); field attached with gl_model_set_series */
   /* light profiles: LightProfile.light (profile.py:24-60) */
   GL_SERSIC = 16,         /* tf/profiles/light/sersic.py:23-24 [R_sersic,n_sersic,center_x,center_y,Ie] */
   GL_SERSIC_ELLIPSE = 17, /* sersic.py:68-69 [R_sersic,n_sersic,e1,e2,center_x,center_y,Ie] */
@@ -163,6 +166,23 @@ int gl_model_set_positions(gl_model* m, int n_families, const int* family_sizes,
                            const float* err_x, const float* err_y);
 int gl_positions_fwd_bwd(const gl_model* m, const float* params, int B, float* loglike, float* chi2,
                          float* grad_params_or_null, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Series-expansion accelerator (MassSeries.set_grid / set_constants / set_deriv, tf/series/series_profile.py:54-62;
+ * ScalingRelationSeries.precompute_deriv, scaling_series.py:19-35; DPIESeries.precompute_deriv, dpie_series.py:19-33).
+ * gl_series_precompute: Taylor coefficients C_n, n = 0..order, of the population's deflection per unit amplitude in the
+ *   cut-radius scale, at arbitrary points: coeffs [2][order+1][n_pts] (x components then y components).  Catalogue
+ *   arguments as gl_model_set_catalogue / gl_scaled_eval (table_dev: DEVICE [n_galaxies][7]); scales: HOST [n_scales],
+ *   the entry of theta_E is ignored (amplitude 1), the entry of r_cut is the expansion point r0 and must be scaled.
+ *   The reference's f_n (n-th derivatives, summed with 1/n!) are n! C_n.
+ * gl_model_set_series: attach a field computed on the model's own pixel list ([2][order+1][N], DEVICE; copied) to a
+ *   GL_SERIES lens; at run time  alpha = theta_E * sum_n C_n (r_cut - r0)^n  (series_profile.py:76-95).
+ * gl_series_eval: that polynomial on a field, out0/out1 [n_pts][B]  (MassSeries.deriv at plugin level). */
+int gl_series_precompute(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev,
+                         const float* scales, int n_scales, int order, const float* x_dev, const float* y_dev,
+                         int64_t n_pts, float* coeffs_dev, void* hip_stream);
+int gl_model_set_series(gl_model* m, int component, float r0, const float* coeffs_dev);
+int gl_series_eval(const float* coeffs_dev, int order, int64_t n_pts, int B, const float* theta_E, const float* r_cut,
+                   float r0, float* out0, float* out1, void* hip_stream);
 
 /* Linear-amplitude solve, LensSimulator.lstsq_simulate (tf/simulator.py:158-240): every light component is rendered
  * as `depth` basis images of unit amplitude (Sersic: 1; Shapelets: (n_max+1)(n_max+2)/2), NaN -> 0, PSF and

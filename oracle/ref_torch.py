@@ -377,6 +377,61 @@ def dpiep_deriv(x, y, theta_E, Ra, Rs, e1, e2, center_x=0, center_y=0):
     return _rotate(fx, fy, -phi)
 
 
+# ---- series-expansion accelerator (tf/series/series_profile.py, dpie_series.py, scaling_series.py) ----------------
+def _derivative_tower(fn, r, order):
+    """[fn(r), d fn/dr, ..., d^order fn/dr^order], elementwise in the broadcast variable ``r`` (nested forward-mode
+    JVPs along the all-ones direction) -- what the sympy-generated deriv_0..deriv_5 of tf/series/profiles/dpie.py
+    evaluate (generator: series_codegen/sympy_codegen.py:21-29, ``diff`` of the deflection w.r.t. the series variable)."""
+    outs, f = [], fn
+    for _ in range(order + 1):
+        outs.append(f(r))
+        f = (lambda g: (lambda rr: torch.func.jvp(g, (rr,), (torch.ones_like(rr),))[1]))(f)
+    return outs
+
+
+def dpie_series_precompute(order, x, y, theta_E, r_core, r_cut, e1, e2, center_x, center_y):
+    """DPIESeries.precompute_deriv (dpie_series.py:19-33): derivatives w.r.t. r_cut of the dPIE deflection per unit
+    theta_E (series_codegen/profiles/dpie.py:18-58: ``scale = r_cut/(r_cut - r_core)``, no radius sort, ellipticity
+    NOT clamped, dpie_series.py:52-56), rotated back; stacked on a trailing axis of length order + 1."""
+    r_core, r_cut, e1, e2, center_x, center_y = (_t(v, x) for v in (r_core, r_cut, e1, e2, center_x, center_y))
+    phi = torch.atan2(e2, e1) / 2
+    e = torch.sqrt(e1 ** 2 + e2 ** 2)
+    q = (1 - e) / (1 + e)
+    xs, ys = x - center_x, y - center_y
+    xr, yr = _rotate(xs, ys, phi)
+
+    def unit(rc):
+        ax, ay = _dpie_complex_deriv_dual(xr, yr, r_core, rc, e, q)
+        sc = rc / (rc - r_core)
+        return torch.stack(_rotate(sc * ax, sc * ay, -phi))
+
+    tower = _derivative_tower(unit, r_cut * torch.ones_like(xr * r_cut), order)
+    f = torch.stack(tower, dim=-1)  # (2, ..., order+1)
+    return f[0], f[1]
+
+
+def scaled_series_precompute(profile, order, x, y, **scales):
+    """ScalingRelationSeries.precompute_deriv (scaling_series.py:19-35): amplitude scale set to 1, every galaxy's
+    derivative tower weighted by ``(L/L*)^p_amp * ((L/L*)^p_series)^n`` and summed over the catalogue."""
+    scales = dict(scales)
+    scales[profile.amplitude_param] = 1.0
+    kw = _scaled_galaxy_kwargs(profile, scales, x)
+    un = scaled_unscaled_factors(profile)
+    n = torch.arange(order + 1, dtype=x.dtype)
+    pre = un[profile.amplitude_param].to(x.dtype)[:, None] * un[profile.series_param].to(x.dtype)[:, None] ** n
+    fx, fy = dpie_series_precompute(order, x.unsqueeze(-1), y.unsqueeze(-1), **kw)  # (..., G, order+1)
+    return (pre * fx).sum(-2), (pre * fy).sum(-2)
+
+
+def series_deriv(coefs_x, coefs_y, order, var, var0, scale):
+    """MassSeries.deriv / _evaluate_series (series_profile.py:76-95): ``scale * sum_n f_n (var - var0)^n / n!``."""
+    n = torch.arange(order + 1, dtype=coefs_x.dtype)
+    fact = torch.exp(torch.lgamma(n + 1))
+    powers = (_t(var, coefs_x).unsqueeze(-1) - var0) ** n
+    scale = _t(scale, coefs_x)
+    return scale * (coefs_x * powers / fact).sum(-1), scale * (coefs_y * powers / fact).sum(-1)
+
+
 _SCALED_BASE = {"dPIS": (dpis_deriv, dpis_hessian), "dPIE": (dpie_deriv, dpie_hessian)}
 
 
@@ -564,6 +619,11 @@ def mass_deriv(profile, x, y, **kw):
         return dpiep_deriv(x, y, **kw)
     if name == "dPIE":
         return dpie_deriv(x, y, **kw)
+    if name.startswith("Scaled-SeriesExpansion") or name.startswith("SeriesExpansion"):
+        # MassSeries.deriv ignores (x, y) and reads the field precomputed on ITS grid (series_profile.py:76-81)
+        cx, cy = profile._oracle_coefs(x.dtype)
+        return series_deriv(cx, cy, profile.order, kw[profile.series_param], profile.series_var_0,
+                            kw[profile.amplitude_param])
     if name.startswith("Scaled-"):
         return scaled_deriv(profile, x, y, **kw)
     raise NotImplementedError(name)

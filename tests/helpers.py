@@ -13,8 +13,10 @@ def struct_from_packed(phys, packed):
         lst = []
         for p in profs:
             d = {}
-            for n in p.params:
-                d[n] = packed[:, k]
+            names = p._native_params() if hasattr(p, "_native_params") else p.params
+            for n in names:  # native column order; columns that are not sampled parameters (lstsq amplitudes) are skipped
+                if n in p.params:
+                    d[n] = packed[:, k]
                 k += 1
             lst.append(d)
         out[g] = lst

@@ -10,6 +10,7 @@
 #include "../../gigalens_amd/csrc/gl_host_tables.h"
 #include "../../gigalens_amd/csrc/gl_profiles.h"
 #include "../../gigalens_amd/csrc/gl_dpie.h"
+#include "../../gigalens_amd/csrc/gl_series.h"
 #include "../../gigalens_amd/csrc/gl_dual.h"
 
 using namespace glp;
@@ -199,6 +200,12 @@ void hm_scaled_f64(int base_kind, int n_gal, const float* table, const int* cols
                    const double* x, const double* y, const double* gx, const double* gy, double* ax, double* ay,
                    double* gscales) {
   run_scaled<double>(base_kind, n_gal, table, cols, scales, n, x, y, gx, gy, ax, ay, gscales);
+}
+// Taylor coefficients C_n (n <= 5) of the population deflection in the cut-radius scale: out [n][2][6]
+void hm_series_f64(int base_kind, int n_gal, const float* table, const int* cols, const double* scales, int n,
+                   const double* x, const double* y, double* out) {
+  ScaledDesc sd{base_kind, n_gal, {cols[0], cols[1], cols[2]}};
+  for (int i = 0; i < n; ++i) series_point<5, double>(sd, table, scales, x[i], y[i], out + 12 * i, out + 12 * i + 6);
 }
 void hm_scaled_f32(int base_kind, int n_gal, const float* table, const int* cols, const float* scales, int n,
                    const float* x, const float* y, const float* gx, const float* gy, float* ax, float* ay,

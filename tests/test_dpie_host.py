@@ -2,6 +2,7 @@
 kernels' templates (gigalens_amd/csrc/gl_dpie.h, instantiated on the host by tests/hostmath) against the oracle and
 torch.autograd of the oracle.  Pure CPU."""
 import ctypes
+import math
 from ctypes import POINTER, c_double, c_float, c_int
 from types import SimpleNamespace
 
@@ -211,3 +212,37 @@ def test_scaled_fwd_and_scale_gradient_f64(hostmath, base, scaling):
         if k in scaling:
             assert np.isclose(gs[i], float(og[scaling.index(k)]), rtol=1e-6), (k, gs, og)
     assert len(canon) == len(scaling)
+
+
+# ---- series-expansion accelerator ---------------------------------------------------------------------------------
+def test_jet_series_coefficients_vs_autodiff_tower(hostmath):
+    """Taylor-mode jets through the member templates (gl_series.h) against nested forward-mode derivatives of the
+    oracle's deflection -- the quantities the reference's generated deriv_0..deriv_5 evaluate."""
+    n_gal, n = 11, 400
+    cat = make_catalogue(n_gal, 5)
+    power = {'theta_E': 0.5, 'r_core': 0.5, 'r_cut': 0.4}
+    prof = oracle_scaled_profile("dPIE", cat, ['theta_E', 'r_core', 'r_cut'], power, lum_star=1.3)
+    prof.amplitude_param, prof.series_param = 'theta_E', 'r_cut'
+    t, cols = catalogue_table(prof, n_gal)
+    r = np.random.default_rng(2)
+    x, y = r.uniform(-7, 7, n), r.uniform(-7, 7, n)
+    scales = np.array([123.0, 0.04, 2.5])  # theta_E is ignored by the precompute (scaling_series.py:20)
+    out = np.zeros((n, 2, 6))
+    hostmath.hm_series_f64(c_int(7), c_int(n_gal), _fp(t), cols.ctypes.data_as(POINTER(c_int)), _dp(scales), c_int(n),
+                           _dp(x), _dp(y), _dp(out))
+    fx, fy = ref.scaled_series_precompute(prof, 5, torch.as_tensor(x)[:, None], torch.as_tensor(y)[:, None],
+                                          theta_E=torch.tensor([1.0], dtype=F64), r_core=torch.tensor([0.04], dtype=F64),
+                                          r_cut=torch.tensor([2.5], dtype=F64))
+    fact = np.array([math.factorial(k) for k in range(6)], dtype=np.float64)
+    ox, oy = fx[:, 0].numpy() / fact, fy[:, 0].numpy() / fact  # derivatives -> Taylor coefficients
+    for k in range(6):
+        sc = np.abs(ox[:, k]).max()
+        # rounding grows ~6x per order in either evaluation (orders 0..5: 1e-15 .. 3e-11 absolute)
+        assert np.allclose(out[:, 0, k], ox[:, k], rtol=1e-6, atol=1e-7 * sc), k
+        assert np.allclose(out[:, 1, k], oy[:, k], rtol=1e-6, atol=1e-7 * sc), k
+    # and the series reproduces the exact scaled deflection near r0 (order-5 remainder)
+    ex, ey = ref.mass_deriv(prof, torch.as_tensor(x)[:, None], torch.as_tensor(y)[:, None],
+                            theta_E=torch.tensor([0.3], dtype=F64), r_core=torch.tensor([0.04], dtype=F64),
+                            r_cut=torch.tensor([2.6], dtype=F64))
+    sx = 0.3 * (out[:, 0, :] * 0.1 ** np.arange(6)).sum(-1)
+    assert np.allclose(sx, ex[:, 0].numpy(), rtol=1e-5, atol=1e-7)

@@ -207,3 +207,117 @@ def test_cluster_stats_positions_vs_oracle(gl, name, kw):
     g, go = p.grad.cpu().numpy(), g_o.numpy()
     scale = np.abs(go).max(axis=1, keepdims=True)
     assert np.all(np.abs(g - go) <= 2e-3 * np.maximum(np.abs(go), 1e-2 * scale) + 1e-6), (np.abs(g - go) / scale).max()
+
+
+# ---- series-expansion accelerator (tf/series, dpie_series.py, scaling_series.py, dpie_subhalo_series.py) ---------------
+def _series_lens(n_gal, order, r0=2.0):
+    from gigalens_amd import workloads
+    from gigalens_amd.profiles.mass.dpie_series import DPIESubhaloSeries
+    cat = workloads.galaxy_catalogue(n_gal, half_width=1.2)
+    s = DPIESubhaloSeries(lum_star=1.3, galaxy_catalogue=cat, order=order,
+                          scaling_params_power={"theta_E": 0.5, "r_core": 0.5, "r_cut": 0.4})
+    s.set_constants(dict(theta_E=0.3, r_core=0.03, r_cut=r0))
+    return s
+
+
+def _oracle_field(series, x, y):
+    from oracle import ref_torch as ref
+    c = series.constants_dict
+    return ref.scaled_series_precompute(series, series.order, torch.as_tensor(x, dtype=F64)[:, None],
+                                        torch.as_tensor(y, dtype=F64)[:, None],
+                                        theta_E=torch.tensor([1.0], dtype=F64),
+                                        r_core=torch.tensor([c["r_core"]], dtype=F64),
+                                        r_cut=torch.tensor([c["r_cut"]], dtype=F64))
+
+
+@pytest.mark.parametrize("order", [3, 5])
+def test_series_precompute_and_deriv(gl, order):
+    """Jets through the member kernels vs the oracle's derivative tower; then MassSeries.deriv vs the exact
+    ScalingRelation near the expansion point."""
+    from oracle import ref_torch as ref
+    s = _series_lens(17, order)
+    x, y = _pts(3000, 4, scale=1.0)
+    s.set_grid(x, y)
+    s.set_deriv()
+    fx, fy = _oracle_field(s, x, y)
+    fact = np.array([math.factorial(k) for k in range(order + 1)], dtype=np.float64)
+    co = s._coefs.cpu().numpy()  # [2, order+1, n]
+    for k in range(order + 1):
+        ox, oy = fx[:, 0, k].numpy() / fact[k], fy[:, 0, k].numpy() / fact[k]
+        sc = np.abs(ox).max()
+        # the field is evaluated in float64 jets and stored as fp32: storage rounding everywhere; a point within ~1e-2
+        # of a member's focus (removable 0/0) loses (1/distance)^k digits in ANY evaluation, the oracle's included
+        for c, o in ((co[0, k], ox), (co[1, k], oy)):
+            err = np.abs(c - o)
+            assert np.quantile(err, 0.99) <= 2e-7 * sc, k
+            assert err.max() <= (1e-5 if k < 4 else 2e-2) * sc, k
+    te, rc = np.array([0.3, 0.5], np.float32), np.array([2.0, 2.15], np.float32)
+    ax, ay = s.deriv(x, y, theta_E=te, r_cut=rc)
+    assert ax.shape == (3000, 2)
+    sx, sy = ref.series_deriv(fx, fy, order, torch.as_tensor(rc, dtype=F64), 2.0, torch.as_tensor(te, dtype=F64))
+    scl = float(sx.abs().max())
+    assert np.abs(ax.cpu().numpy() - sx.numpy()).max() <= 5e-5 * scl
+    # against the exact (non-expanded) population: remainder O(delta^(order+1))
+    exact = ref.mass_deriv(_subhalo_like(s), torch.as_tensor(x, dtype=F64)[:, None], torch.as_tensor(y, dtype=F64)[:, None],
+                           theta_E=torch.as_tensor(te, dtype=F64), r_core=torch.tensor([0.03, 0.03], dtype=F64),
+                           r_cut=torch.as_tensor(rc, dtype=F64))
+    assert np.abs(ax.cpu().numpy() - exact[0].numpy()).max() <= 2e-4 * scl
+
+
+def _subhalo_like(series):
+    """The same catalogue as a plain ScalingRelation (for the oracle's exact evaluation)."""
+    from types import SimpleNamespace
+    return SimpleNamespace(name="Scaled-dPIE", profile=series.profile, params=series.scaling_params,
+                           scaling_params=series.scaling_params, lum_star=series.lum_star, power=series.power,
+                           galaxy_cat=series.galaxy_cat, not_scaling_params=series.not_scaling_params)
+
+
+def test_series_lens_in_the_pixel_likelihood(gl):
+    """A DPIESubhaloSeries lens inside simulate / log-like / gradient: the kernel's per-pixel polynomial and its
+    derivative against the oracle evaluating ITS OWN float64 field the same way (series_profile.py:76-95)."""
+    from gigalens_amd import prior as tfd
+    from gigalens_amd import workloads
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.profiles.mass.piemd import DPIE
+    from gigalens_amd.simulator import SimulatorConfig
+    J, S = tfd.JointDistributionNamed, tfd.JointDistributionSequential
+    series = _series_lens(25, 3)
+    phys = PhysicalModel([DPIE(), series], [], [Sersic()])
+    halo = J(dict(theta_E=tfd.LogNormal(math.log(1.0), 0.1), r_core=tfd.LogNormal(math.log(0.1), 0.2),
+                  r_cut=tfd.LogNormal(math.log(8.0), 0.1), center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05),
+                  e1=tfd.Normal(0.15, 0.05), e2=tfd.Normal(-0.1, 0.05)))
+    mem = J(dict(theta_E=tfd.LogNormal(math.log(0.3), 0.2), r_cut=tfd.LogNormal(math.log(2.0), 0.05)))
+    src = J(dict(R_sersic=tfd.LogNormal(math.log(0.2), 0.1), n_sersic=tfd.Uniform(1, 3), center_x=tfd.Normal(0, 0.1),
+                 center_y=tfd.Normal(0, 0.1), Ie=tfd.LogNormal(math.log(50.0), 0.3)))
+    prior = J(dict(lens_mass=S([halo, mem]), source_light=S([src])))
+    wl = workloads.Workload("SER", phys, prior, SimulatorConfig(delta_pix=0.08, num_pix=36), 4)
+    obs, _, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    gx, gy = sim.img_X.cpu().numpy(), sim.img_Y.cpu().numpy()
+    fx, fy = _oracle_field(series, gx, gy)
+    fact = torch.exp(torch.lgamma(torch.arange(4, dtype=F64) + 1))
+    series._oracle_coefs = lambda dt: (fx, fy)
+    packed = H.sample_packed(wl, sim, seed=11)
+    obs_np = obs.cpu().numpy()
+    ll_o, red_o, g_o, img_o = H.oracle_loglike_and_grad(wl, packed.cpu().double(), obs_np, None, wl.batch)
+    img = sim.simulate(packed).cpu().numpy().reshape(img_o.shape)
+    assert np.abs(img - img_o).max() <= 5 * IMG_RTOL * np.abs(img_o).max() + 1e-7
+    pm = gl.ForwardProbModel(wl.prior, obs_np, wl.background_rms, wl.exp_time, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, red = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    assert np.all(np.abs(ll.detach().cpu().numpy() - ll_o) <= 5 * LL_RTOL * np.maximum(np.abs(ll_o), red_o * 36 * 36))
+    g = p.grad.cpu().numpy()
+    scale = np.maximum(np.abs(g_o).max(axis=1, keepdims=True), 1e-3 * np.abs(g_o).max())
+    bad = np.abs(g - g_o) > GRAD_RTOL * np.maximum(np.abs(g_o), 1e-2 * scale) + 1e-6
+    assert not bad.any(), (np.argwhere(bad)[:5], g[bad][:5], g_o[bad][:5])
+    # fused unconstrained-space entry
+    z = pm.bij.inverse(wl.prior.sample(wl.batch, seed=4)).to(sim.device)
+    z1, z2 = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    lp1, _ = pm.log_prob(sim, z1)
+    lp2, _ = pm.log_prob_unfused(sim, z2)
+    lp1.sum().backward()
+    lp2.sum().backward()
+    assert torch.allclose(lp1, lp2, rtol=2e-5)
+    assert torch.all((z1.grad - z2.grad).abs() <= 2e-4 * z2.grad.abs().max(dim=1, keepdim=True).values + 1e-5)

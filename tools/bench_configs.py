@@ -52,7 +52,9 @@ def main():
            run("C3 shapelets n_max=10 (table) 128x128 B=1024", workloads.make("C3", interpolate=True)),
            run("C3 shapelets n_max=10 (direct) 128x128 B=1024", workloads.make("C3", interpolate=False)),
            run("C4 8 NFW + 20 Sersic 256x256 B=512", workloads.make("C4")),
-           run("C6 dPIE halo + 200 scaled dPIE galaxies + 20 Sersic 256x256 B=128", workloads.make("C6"))]
+           run("C6 dPIE halo + 200 scaled dPIE galaxies + 20 Sersic 256x256 B=128", workloads.make("C6")),
+           run("C6S same, galaxies through the order-3 series expansion, B=128", workloads.make("C6S")),
+           run("C6S same, B=512", workloads.make("C6S", batch=512))]
     # the reference's tf-demo MAP set-up: EPL+Shear | SersicEllipse | SersicEllipse,
     # 60x60 px, supersample 2, 13x13 PSF (here block-replicated to the supersampled grid), 500 samples per step
     from tests.test_prior_host import default_prior
