@@ -76,6 +76,8 @@ SYMBOLS = {
                                c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
+    "gl_profile_hessian": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                   c_void_p, c_void_p]),
     "gl_kind_num_params": (c_int, [POINTER(gl_component)]),
     "gl_model_set_timing": (c_int, [c_void_p, c_int]),
     "gl_model_last_main_ms": (c_int, [c_void_p, POINTER(c_float)]),
@@ -204,6 +206,17 @@ def series_eval(series, amplitude, var):
         shape = shape[:-1]
         o0, o1 = o0.reshape(-1, B, B).diagonal(dim1=1, dim2=2), o1.reshape(-1, B, B).diagonal(dim1=1, dim2=2)
     return o0.reshape(shape + (B,)), o1.reshape(shape + (B,))
+
+
+def profile_hessian(profile, x, y, kwargs):
+    """MassProfile.hessian (tf/profile.py:9-27): ``(f_xx, f_xy, f_yx, f_yy)``."""
+    dev = device()
+    comp = component_of(profile)
+    xb, yb, P, B, out_shape = _broadcast_points(profile, x, y, kwargs, list(profile.params), dev)
+    out = torch.empty((4,) + tuple(xb.shape), dtype=torch.float32, device=dev)
+    _check(lib().gl_profile_hessian(ctypes.byref(comp), _ptr(xb), _ptr(yb), xb.shape[0], B, 1, _ptr(P), _ptr(out),
+                                    _stream()))
+    return tuple(out[k].reshape(out_shape) for k in range(4))
 
 
 def profile_eval(profile, x, y, kwargs):

@@ -1076,6 +1076,24 @@ int gl_positions_fwd_bwd(const gl_model* m, const float* params, int B, float* l
   return GL_OK;
 }
 
+int gl_profile_hessian(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
+                       const float* params, float* out, void* hip_stream) {
+  if (!comp || !x || !y || !params || !out) return fail(GL_EINVAL, "null argument");
+  if (n_pts <= 0 || B <= 0) return fail(GL_EINVAL, "n_pts and B must be positive");
+  if (comp->kind < GL_EPL || comp->kind > GL_DPIEP) return fail(GL_EINVAL, "kind %d is not a free-standing mass profile", comp->kind);
+  CompDesc cd{};
+  cd.kind = comp->kind;
+  cd.iparam = comp->iparam;
+  cd.flags = comp->flags;
+  cd.n_par = kind_num_params(comp->kind, comp->iparam);
+  if (cd.kind == GL_EPL && cd.iparam <= 0) cd.iparam = 50;
+  const long long total = (long long)n_pts * B;
+  hipLaunchKernelGGL(gl_profile_hessian_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream,
+                     cd, x, y, (long long)n_pts, B, xy_batched, params, out);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
 int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, const float* y, int64_t n_pts,
                  int xy_batched, float* out, void* hip_stream) {
   if (!m || !params || !x || !y || !out) return fail(GL_EINVAL, "null argument");

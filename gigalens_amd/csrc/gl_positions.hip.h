@@ -151,6 +151,31 @@ __global__ void __launch_bounds__(64) gl_lens_maps_kernel(PosArgs a, const float
   out[i] = bx; out[st + i] = by; out[2 * st + i] = fxx; out[3 * st + i] = fxy; out[4 * st + i] = fyx; out[5 * st + i] = fyy;
 }
 
+// MassProfile.hessian at plugin level (tf/profile.py:9-27 and the analytic overrides): out[4][n_pts][B]
+__global__ void __launch_bounds__(64) gl_profile_hessian_kernel(CompDesc cd, const float* __restrict__ x,
+                                                               const float* __restrict__ y, long long n_pts, int B,
+                                                               int xy_batched, const float* __restrict__ params,
+                                                               float* __restrict__ out) {
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_pts * B) return;
+  const long long pt = i / B;
+  const int b = (int)(i - pt * B);
+  const float px = xy_batched ? x[i] : x[pt], py = xy_batched ? y[i] : y[pt];
+  using R = gld::Dual<float, 2>;
+  R xd(px), yd(py);
+  xd.d[0] = 1.f;
+  yd.d[1] = 1.f;
+  R p[7];
+  float pf[7];
+  for (int k = 0; k < cd.n_par; ++k) { pf[k] = params[(size_t)b * cd.n_par + k]; p[k] = R(pf[k]); }
+  PosArgs none{};
+  R ax, ay;
+  lens_point<R>(none, cd, p, xd, yd, ax, ay);
+  const float ex = lens_kappa_excess<float>(none, cd, pf, px, py);
+  const long long st = n_pts * B;
+  out[i] = ax.d[0] + ex; out[st + i] = ax.d[1]; out[2 * st + i] = ay.d[0]; out[3 * st + i] = ay.d[1] + ex;
+}
+
 __global__ void __launch_bounds__(64) gl_pos_p2_kernel(PosArgs a) {
   int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= a.B * a.F) return;

@@ -69,3 +69,19 @@ class MassProfile(Parameterized, ABC):
     def deriv(self, x, y, **kwargs):
         """Deflection ``(alpha_x, alpha_y)`` at ``(x, y)``."""
         return _native.profile_eval(self, x, y, kwargs)
+
+    def hessian(self, x, y, **kwargs):
+        """``(f_xx, f_xy, f_yx, f_yy)`` as the reference resolves ``hessian``: derivative of ``deriv``
+        (src/gigalens/tf/profile.py:9-27; the NFW / Shear / SIS / dPIE overrides equal it), the dPIS override as
+        written (piemd.py:62-83).  Evaluated natively with forward-mode duals -- exact, no finite differences."""
+        return _native.profile_hessian(self, x, y, kwargs)
+
+    def convergence(self, x, y, **kwargs):
+        """tf/profile.py:29-34."""
+        f_xx, _, _, f_yy = self.hessian(x, y, **kwargs)
+        return (f_xx + f_yy) / 2
+
+    def shear(self, x, y, **kwargs):
+        """tf/profile.py:36-42."""
+        f_xx, f_xy, _, f_yy = self.hessian(x, y, **kwargs)
+        return (f_xx - f_yy) / 2, f_xy

@@ -233,6 +233,12 @@ int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, 
 int gl_profile_eval(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B,
                     int xy_batched, const float* params, float* out0, float* out1, void* hip_stream);
 
+/* MassProfile.hessian / convergence / shear at plugin level (tf/profile.py:9-43 and the analytic overrides of
+ * nfw.py:77-94, shear.py:18-26, sis.py:19-29, piemd.py:62-83,121-138): out [4][n_pts][B] = f_xx, f_xy, f_yx, f_yy.
+ * Free-standing mass kinds only (catalogues and series: gl_lens_maps on a model). */
+int gl_profile_hessian(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
+                       const float* params, float* out, void* hip_stream);
+
 int gl_kind_num_params(const gl_component* comp); /* length of the reference's params list for this profile */
 
 /* Measurement hooks (bench.py / rocprof cross-check): when enabled, every subsequent call records a pair of
