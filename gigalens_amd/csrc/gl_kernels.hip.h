@@ -356,7 +356,7 @@ template <int T> __device__ __forceinline__ void epl_fwd_T(const float* d, const
 
 template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const float (&x)[T], const float (&y)[T],
                                                             const float (&gx)[T], const float (&gy)[T], float* acc) {
-  float Cs[T], Ss[T], E2x[T], E2y[T], Ex[T], Ey[T], Ox[T], Oy[T], Sx[T], Sy[T], Fx[T], Fy[T], Tx[T], Ty[T];
+  float Cs[T], Ss[T], E2x[T], E2y[T], Ex[T], Ey[T], Ox[T], Oy[T], Fx[T], Fy[T], Tx[T], Ty[T];
   float xr[T], yr[T], inv[T], R0[T];
   const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
 #pragma unroll
@@ -374,7 +374,6 @@ template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const
     E2y[t] = 2.f * Cs[t] * Ss[t];
     Ex[t] = Cs[t]; Ey[t] = Ss[t];
     Ox[t] = Cs[t]; Oy[t] = Ss[t];
-    Sx[t] = Cs[t]; Sy[t] = Ss[t];
     Fx[t] = 0.f; Fy[t] = 0.f; Tx[t] = 0.f; Ty[t] = 0.f;
   }
   const int K = (int)d[EPL_K];
@@ -387,7 +386,6 @@ template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const
       Ey[t] = E2y[t] * Ex[t] + E2x[t] * Ey[t];
       Ex[t] = tx;
       Ox[t] += cc.x * Ex[t]; Oy[t] += cc.x * Ey[t];
-      Sx[t] += cc.y * Ex[t]; Sy[t] += cc.y * Ey[t];
       Fx[t] += cc.z * Ex[t]; Fy[t] += cc.z * Ey[t];
       Tx[t] += cc.w * Ex[t]; Ty[t] += cc.w * Ey[t];
     }
@@ -406,7 +404,8 @@ template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const
     float g_phi = gy[t] * ax - gx[t] * ay;
     float gP = grx * Ox[t] + gry * Oy[t];
     float gOx = P * grx, gOy = P * gry;
-    float g_ang = gOy * Sx[t] - gOx * Sy[t];
+    // S = sum (2n+1) c_n E_n = Omega + 2 f dOmega/df
+    float g_ang = (gOy * Ox[t] - gOx * Oy[t]) + d[EPL_F2] * (gOy * Fx[t] - gOx * Fy[t]);
     float g_t = gOx * Tx[t] + gOy * Ty[t];
     float g_f = gOx * Fx[t] + gOy * Fy[t];
     float gW_W = gP * P;

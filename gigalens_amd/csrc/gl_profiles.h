@@ -37,7 +37,7 @@ constexpr int SH_NODES = 6000;                          // shapelets.py:39-40
 // layout of the derived-constant blocks and accumulator arrays
 // ---------------------------------------------------------------------------------------------
 // EPL
-enum { EPL_CX = 0, EPL_CY, EPL_C, EPL_S, EPL_Q, EPL_B, EPL_TM1, EPL_P0, EPL_K, EPL_INVB, EPL_KI /* K as int bits */, EPL_TAB = 12 };
+enum { EPL_CX = 0, EPL_CY, EPL_C, EPL_S, EPL_Q, EPL_B, EPL_TM1, EPL_P0, EPL_K, EPL_INVB, EPL_KI /* K as int bits */, EPL_F2 /* 2 f */, EPL_TAB = 12 };
 enum { EPLA_CX = 0, EPLA_CY, EPLA_PHI, EPLA_Q, EPLA_B, EPLA_T, EPLA_F, EPLA_P0, EPL_NACC };
 // SIE
 enum { SIE_CX = 0, SIE_CY, SIE_C, SIE_S, SIE_Q, SIE_SQ, SIE_A, SIE_ND };
@@ -219,7 +219,7 @@ template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
   d[EPL_P0] = ((R)2 * b) / ((R)1 + q);
   d[EPL_INVB] = (R)1 / b;
   d[10] = (R)0;
-  d[11] = (R)0;
+  d[EPL_F2] = (R)2 * f;
   R niter = p_log((R)1e-12) / p_log(f) + (R)2;
   int K = 0;
   R* tab = d + EPL_TAB;

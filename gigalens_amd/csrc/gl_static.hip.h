@@ -35,7 +35,7 @@ template <class F, int... Is> __device__ __forceinline__ void static_for(F&& f, 
 // ---- EPL with state -----------------------------------------------------------------------------
 template <int T> struct EplState {
   float xr[T], yr[T], inv[T], Cs[T], Ss[T], iRc[T], L2[T], P[T];
-  float Ox[T], Oy[T], Sx[T], Sy[T], Fx[T], Fy[T], Tx[T], Ty[T];
+  float Ox[T], Oy[T], Fx[T], Fy[T], Tx[T], Ty[T];
   bool inclamp[T];
 };
 
@@ -49,8 +49,9 @@ __device__ __forceinline__ void epl_fwd_state(const float* d, const float* __res
   // packed fp32 op (v_pk_mul_f32 / v_pk_fma_f32: two lanes-worth of FMA per issue slot, which is what the
   // 157 TFLOP/s vector peak of the chip assumes), with the coefficients as SGPR operands:
   //   E <- E2 * E = E2x * (Ex, Ey) + (-E2y, E2y) * (Ey, Ex)          2 packed ops
-  //   O += c0 E ; S += c1 E ; F += c2 E ; Tt += c3 E                  4 packed ops (1 in forward-only mode)
-  v2f E[T], E2a[T], E2b[T], O[T], S[T], F[T], Tt[T];
+  //   O += c0 E ; F += c2 E ; Tt += c3 E                              3 packed ops (1 in forward-only mode)
+  // (dOmega/dtheta = i S, S = sum (2n+1) c_n E_n = O + 2 f F because c_n ~ f^n: no separate S sum)
+  v2f E[T], E2a[T], E2b[T], O[T], F[T], Tt[T];
   const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -71,7 +72,6 @@ __device__ __forceinline__ void epl_fwd_state(const float* d, const float* __res
     E2b[t] = v2f{-E2y, E2y};
     E[t] = v2f{st.Cs[t], st.Ss[t]};
     O[t] = E[t];
-    S[t] = E[t];
     F[t] = v2f{0.f, 0.f};
     Tt[t] = v2f{0.f, 0.f};
   }
@@ -86,7 +86,6 @@ __device__ __forceinline__ void epl_fwd_state(const float* d, const float* __res
       E[t] = E2a[t] * E[t] + E2b[t] * sw;
       O[t] += cc.x * E[t];
       if (GRAD) {
-        S[t] += cc.y * E[t];
         F[t] += cc.z * E[t];
         Tt[t] += cc.w * E[t];
       }
@@ -103,7 +102,6 @@ __device__ __forceinline__ void epl_fwd_state(const float* d, const float* __res
   for (int t = 0; t < T; ++t) {
     st.Ox[t] = O[t].x; st.Oy[t] = O[t].y;
     if (GRAD) {
-      st.Sx[t] = S[t].x; st.Sy[t] = S[t].y;
       st.Fx[t] = F[t].x; st.Fy[t] = F[t].y;
       st.Tx[t] = Tt[t].x; st.Ty[t] = Tt[t].y;
     }
@@ -128,7 +126,7 @@ __device__ __forceinline__ void epl_vjp_state(const float* d, const float (&gx)[
     float g_phi = gy[t] * ax - gx[t] * ay;
     float gP = grx * st.Ox[t] + gry * st.Oy[t];
     float gOx = P * grx, gOy = P * gry;
-    float g_ang = gOy * st.Sx[t] - gOx * st.Sy[t];
+    float g_ang = (gOy * st.Ox[t] - gOx * st.Oy[t]) + d[EPL_F2] * (gOy * st.Fx[t] - gOx * st.Fy[t]);
     float g_t = gOx * st.Tx[t] + gOy * st.Ty[t];
     float g_f = gOx * st.Fx[t] + gOy * st.Fy[t];
     float gW_W = gP * P;

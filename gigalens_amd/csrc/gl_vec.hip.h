@@ -50,7 +50,7 @@ __device__ __forceinline__ float hsum(v2f a) { return a.x + a.y; }
 
 // ---- EPL ------------------------------------------------------------------------------------------------
 template <class V> struct EplStateV {
-  V xr, yr, inv, invc, L2, P, Ox, Oy, Sx, Sy, Fx, Fy, Tx, Ty;
+  V xr, yr, inv, invc, L2, P, Ox, Oy, Fx, Fy, Tx, Ty;
 };
 
 template <class V, bool GRAD>
@@ -75,7 +75,6 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   V Ex = Cs, Ey = Ss;
   st.Ox = Cs; st.Oy = Ss;
   if (GRAD) {
-    st.Sx = Cs; st.Sy = Ss;
     st.Fx = V(0.f); st.Fy = V(0.f); st.Tx = V(0.f); st.Ty = V(0.f);
   }
   // scalar-loaded trip count and coefficients (wave-uniform address): SGPR operands, scalar loop control
@@ -87,7 +86,6 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
     Ex = tx;
     st.Ox += cc.x * Ex; st.Oy += cc.x * Ey;
     if (GRAD) {
-      st.Sx += cc.y * Ex; st.Sy += cc.y * Ey;
       st.Fx += cc.z * Ex; st.Fy += cc.z * Ey;
       st.Tx += cc.w * Ex; st.Ty += cc.w * Ey;
     }
@@ -122,7 +120,8 @@ __device__ __forceinline__ void epl_vjp_v(const float* d, V gx, V gy, const EplS
   V g_phi = gy * ax - gx * ay;
   V gP = grx * st.Ox + gry * st.Oy;
   V gOx = P * grx, gOy = P * gry;
-  V g_ang = gOy * st.Sx - gOx * st.Sy;
+  // d Omega/d theta = i S with S = sum (2n+1) c_n E_n = Omega + 2 f dOmega/df  (c_n ~ f^n): no separate S sum
+  V g_ang = (gOy * st.Ox - gOx * st.Oy) + (gOy * st.Fx - gOx * st.Fy) * d[EPL_F2];
   V g_t = gOx * st.Tx + gOy * st.Ty;
   V g_f = gOx * st.Fx + gOy * st.Fy;
   V gW_W = gP * P;
