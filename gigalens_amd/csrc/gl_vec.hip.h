@@ -71,8 +71,11 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   V Ss = st.yr * st.inv;
   V iRc = vmin(vmax(r, V(1e-10f)), V(1e10f));
   st.invc = (iRc == r) ? r : V(0.f);  // clip_by_value passes gradient only inside the clamp
-  V E2x = Cs * Cs - Ss * Ss, E2y = (Cs + Cs) * Ss;
-  V Ex = Cs, Ey = Ss;
+  // E_n = e^{i(2n+1)theta} by the three-term recurrence  E_{n+1} = 2 cos(2 theta) E_n - E_{n-1}  (one FMA per
+  // component and term, against four for the complex product of the reference's  rot(2 theta) * last, epl.py:43-44);
+  // E_{-1} = conj(E_0).  Two terms per trip so that the two registers simply swap roles.
+  V twoc = (Cs * Cs - Ss * Ss) * 2.f;
+  V Ex = Cs, Ey = Ss, Px = Cs, Py = -Ss;
   st.Ox = Cs; st.Oy = Ss;
   if (GRAD) {
     st.Fx = V(0.f); st.Fy = V(0.f); st.Tx = V(0.f); st.Ty = V(0.f);
@@ -80,29 +83,28 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   // scalar-loaded trip count and coefficients (wave-uniform address): SGPR operands, scalar loop control
   const int K = reinterpret_cast<const int*>(gd)[EPL_KI];
   const float4* __restrict__ gtab = reinterpret_cast<const float4*>(gd + EPL_TAB);
-  auto step = [&](const float4 cc) {
-    V tx = E2x * Ex - E2y * Ey;
-    Ey = E2y * Ex + E2x * Ey;
-    Ex = tx;
-    st.Ox += cc.x * Ex; st.Oy += cc.x * Ey;
+  auto add = [&](const float4 cc, const V& ex, const V& ey) {
+    st.Ox += cc.x * ex; st.Oy += cc.x * ey;
     if (GRAD) {
-      st.Fx += cc.z * Ex; st.Fy += cc.z * Ey;
-      st.Tx += cc.w * Ex; st.Ty += cc.w * Ey;
+      st.Fx += cc.z * ex; st.Fy += cc.z * ey;
+      st.Tx += cc.w * ex; st.Ty += cc.w * ey;
     }
   };
   int n = 1;
-#if defined(GL_EXP_NOTABLE)  // timing experiment only: coefficients hoisted out of the loop (wrong numbers)
-  const float4 c1 = gtab[1], c2 = gtab[2];
-  for (; n + 1 <= K; n += 2) { step(c1); step(c2); }
-  if (n <= K) step(c1);
-#else
   for (; n + 1 <= K; n += 2) {
     const float4 ca = gtab[n], cb = gtab[n + 1];
-    step(ca);
-    step(cb);
+    Px = twoc * Ex - Px;  // E_n      (P held E_{n-2})
+    Py = twoc * Ey - Py;
+    add(ca, Px, Py);
+    Ex = twoc * Px - Ex;  // E_{n+1}
+    Ey = twoc * Py - Ey;
+    add(cb, Ex, Ey);
   }
-  if (n <= K) step(gtab[n]);
-#endif
+  if (n <= K) {
+    Px = twoc * Ex - Px;
+    Py = twoc * Ey - Py;
+    add(gtab[n], Px, Py);
+  }
   st.L2 = log2_(iRc * d[EPL_B]);
   st.P = exp2_(st.L2 * d[EPL_TM1]) * d[EPL_P0];  // 2b/(1+q) (b/R)^(t-1), epl.py:55
   V arx = st.P * st.Ox, ary = st.P * st.Oy;
