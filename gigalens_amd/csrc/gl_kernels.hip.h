@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) gl_order_kernel(const CompDesc* __restric
 // ---- T-pixel EPL: series loop outermost so one LDS table read serves T pixels -------------------
 template <int T> __device__ __forceinline__ void epl_fwd_T(const float* d, const float (&x)[T], const float (&y)[T],
                                                             float (&bx)[T], float (&by)[T]) {
-  float Cs[T], Ss[T], E2x[T], E2y[T], Ex[T], Ey[T], Ox[T], Oy[T], Rc[T];
+  float Cs[T], Ss[T], twoc[T], Ex[T], Ey[T], Px[T], Py[T], Ox[T], Oy[T], Rc[T];
   const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -327,21 +327,32 @@ template <int T> __device__ __forceinline__ void epl_fwd_T(const float* d, const
     Cs[t] = pos ? X * inv : 1.f;
     Ss[t] = yr * inv;
     Rc[t] = clamp_(R0, 1e-10f, 1e10f);
-    E2x[t] = Cs[t] * Cs[t] - Ss[t] * Ss[t];
-    E2y[t] = 2.f * Cs[t] * Ss[t];
-    Ex[t] = Cs[t]; Ey[t] = Ss[t]; Ox[t] = Cs[t]; Oy[t] = Ss[t];
+    twoc[t] = 2.f * (Cs[t] * Cs[t] - Ss[t] * Ss[t]);  // E_{n+1} = 2 cos(2 theta) E_n - E_{n-1}, see epl_fwd_v
+    Ex[t] = Cs[t]; Ey[t] = Ss[t]; Px[t] = Cs[t]; Py[t] = -Ss[t]; Ox[t] = Cs[t]; Oy[t] = Ss[t];
   }
   const int K = (int)d[EPL_K];
   const float* tab = d + EPL_TAB;
-  for (int n = 1; n <= K; ++n) {
-    float cn = tab[4 * n];
+  int n = 1;
+  for (; n + 1 <= K; n += 2) {
+    const float ca = tab[4 * n], cb = tab[4 * n + 4];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      float tx = E2x[t] * Ex[t] - E2y[t] * Ey[t];
-      Ey[t] = E2y[t] * Ex[t] + E2x[t] * Ey[t];
-      Ex[t] = tx;
-      Ox[t] += cn * Ex[t];
-      Oy[t] += cn * Ey[t];
+      Px[t] = twoc[t] * Ex[t] - Px[t];
+      Py[t] = twoc[t] * Ey[t] - Py[t];
+      Ox[t] += ca * Px[t];
+      Oy[t] += ca * Py[t];
+      Ex[t] = twoc[t] * Px[t] - Ex[t];
+      Ey[t] = twoc[t] * Py[t] - Ey[t];
+      Ox[t] += cb * Ex[t];
+      Oy[t] += cb * Ey[t];
+    }
+  }
+  if (n <= K) {
+    const float ca = tab[4 * n];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      Ox[t] += ca * (twoc[t] * Ex[t] - Px[t]);
+      Oy[t] += ca * (twoc[t] * Ey[t] - Py[t]);
     }
   }
 #pragma unroll
@@ -356,7 +367,7 @@ template <int T> __device__ __forceinline__ void epl_fwd_T(const float* d, const
 
 template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const float (&x)[T], const float (&y)[T],
                                                             const float (&gx)[T], const float (&gy)[T], float* acc) {
-  float Cs[T], Ss[T], E2x[T], E2y[T], Ex[T], Ey[T], Ox[T], Oy[T], Fx[T], Fy[T], Tx[T], Ty[T];
+  float Cs[T], Ss[T], twoc[T], Ex[T], Ey[T], Px[T], Py[T], Ox[T], Oy[T], Fx[T], Fy[T], Tx[T], Ty[T];
   float xr[T], yr[T], inv[T], R0[T];
   const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
 #pragma unroll
@@ -370,25 +381,35 @@ template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const
     inv[t] = pos ? rcp(R0[t]) : 0.f;
     Cs[t] = pos ? X * inv[t] : 1.f;
     Ss[t] = yr[t] * inv[t];
-    E2x[t] = Cs[t] * Cs[t] - Ss[t] * Ss[t];
-    E2y[t] = 2.f * Cs[t] * Ss[t];
-    Ex[t] = Cs[t]; Ey[t] = Ss[t];
+    twoc[t] = 2.f * (Cs[t] * Cs[t] - Ss[t] * Ss[t]);
+    Ex[t] = Cs[t]; Ey[t] = Ss[t]; Px[t] = Cs[t]; Py[t] = -Ss[t];
     Ox[t] = Cs[t]; Oy[t] = Ss[t];
     Fx[t] = 0.f; Fy[t] = 0.f; Tx[t] = 0.f; Ty[t] = 0.f;
   }
   const int K = (int)d[EPL_K];
   const float4* tab = reinterpret_cast<const float4*>(d + EPL_TAB);
-  for (int n = 1; n <= K; ++n) {
-    float4 cc = tab[n];
+  auto add = [&](const float4 cc, int t, float ex, float ey) {
+    Ox[t] += cc.x * ex; Oy[t] += cc.x * ey;
+    Fx[t] += cc.z * ex; Fy[t] += cc.z * ey;
+    Tx[t] += cc.w * ex; Ty[t] += cc.w * ey;
+  };
+  int n = 1;
+  for (; n + 1 <= K; n += 2) {
+    const float4 ca = tab[n], cb = tab[n + 1];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      float tx = E2x[t] * Ex[t] - E2y[t] * Ey[t];
-      Ey[t] = E2y[t] * Ex[t] + E2x[t] * Ey[t];
-      Ex[t] = tx;
-      Ox[t] += cc.x * Ex[t]; Oy[t] += cc.x * Ey[t];
-      Fx[t] += cc.z * Ex[t]; Fy[t] += cc.z * Ey[t];
-      Tx[t] += cc.w * Ex[t]; Ty[t] += cc.w * Ey[t];
+      Px[t] = twoc[t] * Ex[t] - Px[t];
+      Py[t] = twoc[t] * Ey[t] - Py[t];
+      add(ca, t, Px[t], Py[t]);
+      Ex[t] = twoc[t] * Px[t] - Ex[t];
+      Ey[t] = twoc[t] * Py[t] - Ey[t];
+      add(cb, t, Ex[t], Ey[t]);
     }
+  }
+  if (n <= K) {
+    const float4 ca = tab[n];
+#pragma unroll
+    for (int t = 0; t < T; ++t) add(ca, t, twoc[t] * Ex[t] - Px[t], twoc[t] * Ey[t] - Py[t]);
   }
   const float tm1 = d[EPL_TM1], P0 = d[EPL_P0];
 #pragma unroll

@@ -48,10 +48,11 @@ __device__ __forceinline__ void epl_fwd_state(const float* d, const float* __res
   // Complex numbers are kept as (re, im) register pairs so that every instruction of the series loop is a
   // packed fp32 op (v_pk_mul_f32 / v_pk_fma_f32: two lanes-worth of FMA per issue slot, which is what the
   // 157 TFLOP/s vector peak of the chip assumes), with the coefficients as SGPR operands:
-  //   E <- E2 * E = E2x * (Ex, Ey) + (-E2y, E2y) * (Ey, Ex)          2 packed ops
+  //   E_{n+1} = 2 cos(2 theta) E_n - E_{n-1}                           1 packed op (three-term recurrence, see epl_fwd_v)
   //   O += c0 E ; F += c2 E ; Tt += c3 E                              3 packed ops (1 in forward-only mode)
   // (dOmega/dtheta = i S, S = sum (2n+1) c_n E_n = O + 2 f F because c_n ~ f^n: no separate S sum)
-  v2f E[T], E2a[T], E2b[T], O[T], F[T], Tt[T];
+  v2f E[T], Pv[T], O[T], F[T], Tt[T];
+  float twoc[T];
   const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -66,11 +67,9 @@ __device__ __forceinline__ void epl_fwd_state(const float* d, const float* __res
     st.Ss[t] = st.yr[t] * st.inv[t];
     st.inclamp[t] = (R0 >= 1e-10f) && (R0 <= 1e10f);
     st.iRc[t] = rcp(clamp_(R0, 1e-10f, 1e10f));
-    float E2x = st.Cs[t] * st.Cs[t] - st.Ss[t] * st.Ss[t];
-    float E2y = 2.f * st.Cs[t] * st.Ss[t];
-    E2a[t] = v2f{E2x, E2x};
-    E2b[t] = v2f{-E2y, E2y};
+    twoc[t] = 2.f * (st.Cs[t] * st.Cs[t] - st.Ss[t] * st.Ss[t]);
     E[t] = v2f{st.Cs[t], st.Ss[t]};
+    Pv[t] = v2f{st.Cs[t], -st.Ss[t]};
     O[t] = E[t];
     F[t] = v2f{0.f, 0.f};
     Tt[t] = v2f{0.f, 0.f};
@@ -79,25 +78,29 @@ __device__ __forceinline__ void epl_fwd_state(const float* d, const float* __res
   // loop control, SGPR operands -- the loop issues no vector-memory or LDS instruction.
   const int K = reinterpret_cast<const int*>(gd)[EPL_KI];
   const float4* __restrict__ gtab = reinterpret_cast<const float4*>(gd + EPL_TAB);
-  auto step = [&](const float4 cc) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      v2f sw = __builtin_shufflevector(E[t], E[t], 1, 0);
-      E[t] = E2a[t] * E[t] + E2b[t] * sw;
-      O[t] += cc.x * E[t];
-      if (GRAD) {
-        F[t] += cc.z * E[t];
-        Tt[t] += cc.w * E[t];
-      }
+  auto add = [&](const float4 cc, int t, const v2f& e) {
+    O[t] += cc.x * e;
+    if (GRAD) {
+      F[t] += cc.z * e;
+      Tt[t] += cc.w * e;
     }
   };
   int n = 1;
-  for (; n + 1 <= K; n += 2) {  // two terms per trip: one s_load_dwordx8, one wait
+  for (; n + 1 <= K; n += 2) {  // two terms per trip: one s_load_dwordx8, one wait; E and Pv swap roles
     const float4 ca = gtab[n], cb = gtab[n + 1];
-    step(ca);
-    step(cb);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      Pv[t] = twoc[t] * E[t] - Pv[t];
+      add(ca, t, Pv[t]);
+      E[t] = twoc[t] * Pv[t] - E[t];
+      add(cb, t, E[t]);
+    }
   }
-  if (n <= K) step(gtab[n]);
+  if (n <= K) {
+    const float4 ca = gtab[n];
+#pragma unroll
+    for (int t = 0; t < T; ++t) add(ca, t, twoc[t] * E[t] - Pv[t]);
+  }
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     st.Ox[t] = O[t].x; st.Oy[t] = O[t].y;
