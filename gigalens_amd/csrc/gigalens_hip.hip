@@ -81,6 +81,7 @@ struct gl_model {
   float* d_pos = nullptr;  // [4][J]: x, y, err_x, err_y
   int* d_fam = nullptr;    // [F+1]
   bool has_epl = false;
+  int epl_comp = -1;     // the model's only EPL component, or -1 (none / several)
   bool has_dpie = false;  // any dPIE-family lens or galaxy catalogue
   bool use_order = true;
   bool timing = false;
@@ -124,6 +125,7 @@ struct Workspace {
   float* partial;
   float* params;  // [B,P] constrained rows produced from z (gl_logprob_fwd_bwd)
   int* order;     // [B] cost-ordered dispatch
+  int* cost;      // [B] per-sample dispatch cost written by prep (single-EPL models)
   float* gal_dyn;  // [B][G][DP_ND] catalogue members' per-sample constants
   float *pos_w, *pos_adj, *pos_g, *pos_fam, *pos_ll, *pos_chi2, *pos_grad;  // image-position likelihood
   float* img_ss;   // supersampled / pre-PSF image or its cotangent (PSF path only)
@@ -145,6 +147,8 @@ Workspace carve(const gl_model* m, int B, void* base) {
   w.params = (float*)(p + off);
   off += align_up((size_t)B * std::max(m->P, 1) * sizeof(float), 256);
   w.order = (int*)(p + off);
+  off += align_up((size_t)B * sizeof(int), 256);
+  w.cost = (int*)(p + off);
   off += align_up((size_t)B * sizeof(int), 256);
   if (m->G) {
     w.gal_dyn = (float*)(p + off);
@@ -336,7 +340,7 @@ int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, 
   int n_comp = (int)m->comps.size();
   int total = B * n_comp;
   hipLaunchKernelGGL(gl_prep_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, params,
-                     m->P, B, w.derived, m->D);
+                     m->P, B, w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
   GL_HIP(hipGetLastError());
   return run_galprep(m, params, B, w, stream);
 }
@@ -360,7 +364,7 @@ int run_order(const gl_model* m, int B, const Workspace& w, MainArgs* a, hipStre
   a->order = nullptr;
   if (!m->has_epl || !m->use_order || B < 2) return GL_OK;
   hipLaunchKernelGGL(gl_order_kernel, dim3(1), dim3(256), 0, stream, m->d_comps, m->n_lens, w.derived, m->D, B,
-                     w.order);
+                     w.order, m->epl_comp >= 0 ? w.cost : nullptr);
   GL_HIP(hipGetLastError());
   a->order = w.order;
   return GL_OK;
@@ -556,7 +560,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
       if (iparam <= 0) iparam = 50;  // epl.py:15
       if (iparam > 1000) { delete m; return fail(GL_EINVAL, "EPL niter %d too large", iparam); }
     }
-    if (c.kind == GL_EPL) m->has_epl = true;
+    if (c.kind == GL_EPL) { m->epl_comp = m->has_epl ? -2 : i; m->has_epl = true; }
     if (c.kind >= GL_DPIS && c.kind <= GL_SERIES) m->has_dpie = true;
     if (c.kind == GL_SERIES && (iparam < 0 || iparam > SERIES_MAX_ORDER)) {
       delete m;
@@ -1167,7 +1171,8 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   chunking(m, B, &chunk, &n_chunks);
   int n_comp = (int)m->comps.size();
   hipLaunchKernelGGL(gl_zprep_kernel, dim3((B * n_comp + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, z,
-                     m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D);
+                     m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D,
+                     m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
   GL_HIP(hipGetLastError());
   if ((rc = run_galprep(m, w.params, B, w, stream))) return rc;
   const float* extra = nullptr;

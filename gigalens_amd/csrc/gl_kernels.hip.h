@@ -159,9 +159,12 @@ template <int G> __device__ __forceinline__ void wave_acc(float (&acc)[G], const
 }
 
 // ---- per-sample prep: raw parameter rows -> derived constants --------------------------------
+// `cost` (optional): per-sample dispatch cost = the EPL trip count, written by the thread of component `cost_comp`
+// (models with exactly one EPL), so that gl_order_kernel reads one coalesced int array
 __global__ void __launch_bounds__(128) gl_prep_kernel(const CompDesc* __restrict__ comps, int n_comp,
                                                       const float* __restrict__ params, int P, int B,
-                                                      float* __restrict__ derived, int D) {
+                                                      float* __restrict__ derived, int D, int* __restrict__ cost,
+                                                      int cost_comp) {
   int i = blockIdx.x * 128 + threadIdx.x;
   if (i >= B * n_comp) return;
   int b = i / n_comp, c = i - b * n_comp;
@@ -181,6 +184,7 @@ __global__ void __launch_bounds__(128) gl_prep_kernel(const CompDesc* __restrict
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, d); break;
   }
+  if (cost && c == cost_comp) cost[b] = reinterpret_cast<const int*>(d)[EPL_KI];
 }
 
 // ---- unconstrained-space front/back end: bijector + prior fused into prep / finalize -------------
@@ -240,7 +244,8 @@ __global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restric
                                                        const float* __restrict__ z, int d_z,
                                                        const ZCol* __restrict__ zcols, const int* __restrict__ src,
                                                        const float* __restrict__ const_row, int P, int B,
-                                                       float* __restrict__ params, float* __restrict__ derived, int D) {
+                                                       float* __restrict__ params, float* __restrict__ derived, int D,
+                                                       int* __restrict__ cost, int cost_comp) {
   int i = blockIdx.x * 128 + threadIdx.x;
   if (i >= B * n_comp) return;
   int b = i / n_comp, c = i - b * n_comp;
@@ -265,6 +270,7 @@ __global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restric
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, dd); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, dd); break;
   }
+  if (cost && c == cost_comp) cost[b] = reinterpret_cast<const int*>(dd)[EPL_KI];
 }
 
 // per (sample, galaxy) constants of the catalogue members: radii, amplitude and the map to the scale gradients
@@ -289,12 +295,13 @@ __global__ void __launch_bounds__(128) gl_galprep_kernel(const CompDesc* __restr
 // path), so the heaviest workgroups start first and the tail of the launch is filled with light ones.
 __global__ void __launch_bounds__(256) gl_order_kernel(const CompDesc* __restrict__ comps, int n_lens,
                                                        const float* __restrict__ derived, int D, int B,
-                                                       int* __restrict__ order) {
+                                                       int* __restrict__ order, const int* __restrict__ cost_in) {
   __shared__ int hist[256];
   __shared__ int offs[256];
   hist[threadIdx.x] = 0;
   __syncthreads();
   auto cost = [&](int b) {
+    if (cost_in) return min(cost_in[b], 255);
     int k = 0;
     for (int l = 0; l < n_lens; ++l)
       if (comps[l].kind == K_EPL) k += reinterpret_cast<const int*>(derived + (size_t)b * D + comps[l].d_off)[EPL_KI];
@@ -302,10 +309,19 @@ __global__ void __launch_bounds__(256) gl_order_kernel(const CompDesc* __restric
   };
   for (int b = threadIdx.x; b < B; b += 256) atomicAdd(&hist[cost(b)], 1);
   __syncthreads();
-  {  // exclusive prefix over DESCENDING cost: every thread sums the bins above its own (256 independent LDS reads)
-    int run = 0;
-    for (int k = 255; k > (int)threadIdx.x; --k) run += hist[k];
-    offs[threadIdx.x] = run;
+  {  // exclusive prefix over DESCENDING cost = inclusive suffix sum of the bins above: log-step scan in LDS
+    int v = hist[threadIdx.x];
+    offs[threadIdx.x] = v;
+    __syncthreads();
+    for (int step = 1; step < 256; step <<= 1) {
+      const int add = (threadIdx.x + step < 256) ? offs[threadIdx.x + step] : 0;
+      __syncthreads();
+      offs[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const int incl = offs[threadIdx.x];  // sum of bins >= own
+    __syncthreads();
+    offs[threadIdx.x] = incl - v;        // bins strictly above
   }
   __syncthreads();
   for (int b = threadIdx.x; b < B; b += 256) order[atomicAdd(&offs[cost(b)], 1)] = b;

@@ -221,16 +221,19 @@ template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
   d[10] = (R)0;
   d[EPL_F2] = (R)2 * f;
   R niter = p_log((R)1e-12) / p_log(f) + (R)2;
+  // terms n = 1..K with n < niter (epl.py:47-54), K <= cap:  K = ceil(niter) - 1, evaluated without a data-dependent
+  // exit so that the divisions of different n overlap (they are independent; only the products chain)
   int K = 0;
+  if (niter > (R)1) K = (int)fmin_(-floor_(-niter) - (R)1, (R)cap);
   R* tab = d + EPL_TAB;
   R c = (R)1, cf = (R)0, ct = (R)0;
   tab[0] = (R)1; tab[1] = (R)1; tab[2] = (R)0; tab[3] = (R)0;
-  for (int n = 1; n <= cap; ++n) {
-    if (!((R)n < niter)) break;
-    R den = (R)(2 * n) + ((R)2 - t);
-    R r = -((R)(2 * n) - ((R)2 - t)) / den;
+  const R two_mt = (R)2 - t;
+  for (int n = 1; n <= K; ++n) {
+    R iden = (R)1 / ((R)(2 * n) + two_mt);
+    R r = -((R)(2 * n) - two_mt) * iden;
     R pn = f * r;
-    R dpdt = -f * (R)(4 * n) / (den * den);
+    R dpdt = -f * (R)(4 * n) * (iden * iden);
     cf = cf * pn + c * r;
     ct = ct * pn + c * dpdt;
     c = c * pn;
@@ -238,7 +241,6 @@ template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
     tab[4 * n + 1] = (R)(2 * n + 1) * c;
     tab[4 * n + 2] = cf;
     tab[4 * n + 3] = ct;
-    K = n;
   }
   for (int j = 0; j < 4; ++j) tab[4 * (K + 1) + j] = (R)0;  // the prefetched-but-unused row
   d[EPL_K] = (R)K;
