@@ -345,16 +345,41 @@ int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, 
   return run_galprep(m, params, B, w, stream);
 }
 
+FinArgs fin_args(const gl_model* m, const float* params, const Workspace& w, float* loglike, float* chi2, float* grad,
+                 const float* z, float* logprob, float* grad_z, float chi2_scale, const float* extra_stats,
+                 int use_partial, bool with_positions, float pos_chi2_scale) {
+  FinArgs f{};
+  f.n_comp = (int)m->comps.size();
+  f.P = m->P;
+  f.A = m->A;
+  f.d_z = m->d_z;
+  f.params = params;
+  f.loglike = loglike;
+  f.chi2 = chi2;
+  f.grad = grad;
+  f.z = z;
+  f.zcols = z ? (const ZCol*)m->d_zcols : nullptr;
+  f.logprob = logprob;
+  f.grad_z = grad_z;
+  f.chi2_scale = chi2_scale;
+  f.extra_stats = extra_stats;
+  f.use_partial = use_partial;
+  f.pos_ll = with_positions ? w.pos_ll : nullptr;
+  f.pos_chi2 = with_positions ? w.pos_chi2 : nullptr;
+  f.pos_grad = with_positions && (grad || grad_z) ? w.pos_grad : nullptr;
+  f.pos_chi2_scale = pos_chi2_scale;
+  f.cats = m->d_cats;
+  return f;
+}
+
 int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, const Workspace& w, float* loglike,
                  float* chi2, float* grad, hipStream_t stream, const float* z = nullptr, float* logprob = nullptr,
                  float* grad_z = nullptr, float chi2_scale = 1.f, const float* extra_stats = nullptr,
                  int use_partial = 1, bool with_positions = false, float pos_chi2_scale = 0.f) {
   size_t shmem = (size_t)(((m->A + 3) & ~3) + ((m->P + 3) & ~3) + ((m->d_z + 3) & ~3) + 4) * sizeof(float);
-  hipLaunchKernelGGL(gl_finalize_kernel, dim3(B), dim3(128), shmem, stream, m->d_comps, (int)m->comps.size(), params,
-                     m->P, w.partial, n_chunks, m->A, loglike, chi2, grad, z, m->d_z, z ? m->d_zcols : nullptr, logprob,
-                     grad_z, chi2_scale, extra_stats, use_partial, with_positions ? w.pos_ll : nullptr,
-                     with_positions ? w.pos_chi2 : nullptr,
-                     with_positions && (grad || grad_z) ? w.pos_grad : nullptr, pos_chi2_scale, m->d_cats);
+  FinArgs f = fin_args(m, params, w, loglike, chi2, grad, z, logprob, grad_z, chi2_scale, extra_stats, use_partial,
+                       with_positions, pos_chi2_scale);
+  hipLaunchKernelGGL(gl_finalize_kernel, dim3(B), dim3(128), shmem, stream, m->d_comps, f, w.partial, n_chunks);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -1177,12 +1202,12 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   if ((rc = run_galprep(m, w.params, B, w, stream))) return rc;
   const float* extra = nullptr;
   int use_partial = 0;
+  // red_chi2 = (red_pix + red_pos) / n_chi  (tf/model.py:150-162)
+  const float n_chi = (pix ? 1.f : 0.f) + (pos ? 1.f : 0.f);
   if (pix && (rc = run_likelihood(m, B, w, chunk, n_chunks, obs, err_or_null, mask_or_null, bg_rms, exp_time,
                                   grad_z_or_null != nullptr, stream, &extra, &use_partial)))
     return rc;
   if (pos && (rc = run_positions(m, w.params, B, w, grad_z_or_null != nullptr, stream))) return rc;
-  // red_chi2 = (red_pix + red_pos) / n_chi  (tf/model.py:150-162)
-  const float n_chi = (pix ? 1.f : 0.f) + (pos ? 1.f : 0.f);
   return run_finalize(m, w.params, B, n_chunks, w, loglike, chi2, nullptr, stream, z, logprob, grad_z_or_null,
                       pix ? 1.0f / (chi2_divisor * n_chi) : 0.f, extra, use_partial, pos,
                       pos ? 1.0f / (2.0f * (float)m->pos_J * n_chi) : 0.f);

@@ -47,6 +47,22 @@ struct SeriesDev {
   int order;
 };
 
+struct ZCol;
+struct FinArgs {
+  int n_comp, P, A, d_z;
+  const float* params;
+  float *loglike, *chi2, *grad;
+  const float* z;
+  const ZCol* zcols;
+  float *logprob, *grad_z;
+  float chi2_scale;
+  const float* extra_stats;
+  int use_partial;
+  const float *pos_ll, *pos_chi2, *pos_grad;
+  float pos_chi2_scale;
+  const CatDev* cats;
+};
+
 enum Mode : int { IMG_FWD = 0, IMG_BWD = 1, LL_FWD = 2, LL_GRAD = 3, IMG_BASIS = 4 };
 constexpr int WG = 256;
 constexpr int NSTAT = 4;  // accumulator row starts with [chi2, norm, pad, pad]
@@ -860,36 +876,29 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
 // ---- finalize: sum chunk partials (fixed order), chain rule to raw parameters -------------------
 // With zcols != null the gradient is carried on to the unconstrained vector z and the log-prior
 // + log|J| is added:  log_prob = loglike + sum_k [log p_k(x_k) + fldj_k(z_k)]   (tf/model.py:164-167).
-__global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __restrict__ comps, int n_comp,
-                                                          const float* __restrict__ params, int P,
-                                                          const float* __restrict__ partial, int n_chunks, int A,
-                                                          float* __restrict__ loglike, float* __restrict__ chi2,
-                                                          float* __restrict__ grad, const float* __restrict__ z,
-                                                          int d_z, const ZCol* __restrict__ zcols,
-                                                          float* __restrict__ logprob, float* __restrict__ grad_z,
-                                                          float chi2_scale, const float* __restrict__ extra_stats,
-                                                          int use_partial, const float* __restrict__ pos_ll,
-                                                          const float* __restrict__ pos_chi2,
-                                                          const float* __restrict__ pos_grad, float pos_chi2_scale,
-                                                          const CatDev* __restrict__ cats) {
-  extern __shared__ float s[];  // [A] accumulators, then [P] parameter gradients, then [d_z] prior terms
+
+// one sample, executed by NT threads of one workgroup; `s`: LDS scratch of A + P + d_z (+12) floats
+template <int NT>
+__device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ comps, const FinArgs& f,
+                                                const float* __restrict__ partial, int n_chunks, int b, int tid,
+                                                float* s) {
+  const int A = f.A, P = f.P, d_z = f.d_z;
   float* s_g = s + ((A + 3) & ~3);
   float* s_t = s_g + ((P + 3) & ~3);
-  const int b = blockIdx.x;
   const float* src = partial + (size_t)b * n_chunks * A;
-  for (int k = threadIdx.x; k < A; k += 128) {
+  for (int k = tid; k < A; k += NT) {
     float v = 0.f;
-    if (use_partial)
+    if (f.use_partial)
       for (int ch = 0; ch < n_chunks; ++ch) v += src[(size_t)ch * A + k];
-    if (extra_stats && k < 2) v += extra_stats[2 * b + k];  // chi2 / normalisation of a materialised image (PSF path)
+    if (f.extra_stats && k < 2) v += f.extra_stats[2 * b + k];  // chi2 / normalisation of a materialised image (PSF path)
     s[k] = v;
   }
   __syncthreads();
-  const bool want_grad = grad != nullptr || grad_z != nullptr;
+  const bool want_grad = f.grad != nullptr || f.grad_z != nullptr;
   if (want_grad) {
-    for (int c = threadIdx.x; c < n_comp; c += 128) {
+    for (int c = tid; c < f.n_comp; c += NT) {
       CompDesc cd = comps[c];
-      const float* p = params + (size_t)b * P + cd.p_off;
+      const float* p = f.params + (size_t)b * P + cd.p_off;
       float* g = s_g + cd.p_off;
       const float* acc = s + cd.a_off;
       switch (cd.kind) {
@@ -900,7 +909,7 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
         case K_SIS: sis_finalize<float>(p, acc, g); break;
         case K_DPIS: case K_DPIE: case K_DPIEP: dpie_finalize<float>(cd.kind, p, acc, g); break;
         case K_SCALED: {
-          const CatDev cat = cats[cd.iparam];
+          const CatDev cat = f.cats[cd.iparam];
           for (int k = 0; k < 3; ++k)
             if (cat.col[k] >= 0) g[cat.col[k]] = acc[k];
         } break;
@@ -911,38 +920,50 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
       }
     }
     __syncthreads();
-    if (pos_grad) {  // image-position likelihood: its parameter gradient joins before the chain to z
-      for (int k = threadIdx.x; k < P; k += 128) s_g[k] += pos_grad[(size_t)b * P + k];
+    if (f.pos_grad) {  // image-position likelihood: its parameter gradient joins before the chain to z
+      for (int k = tid; k < P; k += NT) s_g[k] += f.pos_grad[(size_t)b * P + k];
       __syncthreads();
     }
-    if (grad)
-      for (int k = threadIdx.x; k < P; k += 128) grad[(size_t)b * P + k] = s_g[k];
+    if (f.grad)
+      for (int k = tid; k < P; k += NT) f.grad[(size_t)b * P + k] = s_g[k];
   }
-  if (zcols) {
-    for (int k = threadIdx.x; k < d_z; k += 128) {
-      ZCol c = zcols[k];
-      ZEval e = z_eval(c, z[(size_t)b * d_z + k]);
+  if (f.zcols) {
+    for (int k = tid; k < d_z; k += NT) {
+      ZCol c = f.zcols[k];
+      ZEval e = z_eval(c, f.z[(size_t)b * d_z + k]);
       s_t[k] = e.logp_plus_fldj;
-      if (grad_z) grad_z[(size_t)b * d_z + k] = (s_g[c.param_col] + e.dlogp_dx) * e.dxdz + e.dfldj_dz;
+      if (f.grad_z) f.grad_z[(size_t)b * d_z + k] = (s_g[c.param_col] + e.dlogp_dx) * e.dxdz + e.dfldj_dz;
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0 && loglike) {
+  if (tid == 0 && f.loglike) {
     float ll = -0.5f * (s[0] + s[1]);  // tf/model.py:99
-    float c2 = s[0] * chi2_scale;
-    if (pos_ll) {  // tf/model.py:157-162
-      ll += pos_ll[b];
-      c2 += pos_chi2[b] * pos_chi2_scale;
+    float c2 = s[0] * f.chi2_scale;
+    if (f.pos_ll) {  // tf/model.py:157-162
+      ll += f.pos_ll[b];
+      c2 += f.pos_chi2[b] * f.pos_chi2_scale;
     }
-    loglike[b] = ll;
-    chi2[b] = c2;
-    if (zcols && logprob) {
+    f.loglike[b] = ll;
+    f.chi2[b] = c2;
+    if (f.zcols && f.logprob) {
       float lp = 0.f;
       for (int k = 0; k < d_z; ++k) lp += s_t[k];
-      logprob[b] = ll + lp;
+      f.logprob[b] = ll + lp;
     }
   }
 }
+
+__global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __restrict__ comps, FinArgs f,
+                                                          const float* __restrict__ partial, int n_chunks) {
+  extern __shared__ float s[];  // [A] accumulators, then [P] parameter gradients, then [d_z] prior terms
+  finalize_sample<128>(comps, f, partial, n_chunks, blockIdx.x, threadIdx.x, s);
+}
+
+// Fused form (specialised kernels, likelihood modes): the LAST workgroup of a sample to publish its partial row runs
+// the sample's finalize in its own tail -- one kernel launch less on the critical path of every step.
+// (Fusing this into the tail of each sample's last main-kernel workgroup was measured and dropped: with one L2 per XCD
+// the hand-over of the partial rows needs agent-scope release / L2-bypassing traffic per workgroup, which cost more
+// (0.172 ms per step) than the separate 5 us launch (0.137 ms).)
 
 // ---- plugin-level point evaluation (MassProfile.deriv / LightProfile.light on arbitrary points) ----
 __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float* __restrict__ x,
