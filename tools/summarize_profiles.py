@@ -20,10 +20,10 @@ def short(name):
 
 
 def stats_table(d, out, top=12):
-    f = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv"))
+    f = sorted(glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if not f:
         return None
-    rows = list(csv.DictReader(open(f[0])))
+    rows = list(csv.DictReader(open(f[-1])))  # newest run
     with open(os.path.join(dst, out), "w") as fh:
         fh.write(f"# rocprofv3 --kernel-trace --stats ({d})\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
         for r in rows[:top]:
@@ -33,11 +33,11 @@ def stats_table(d, out, top=12):
 
 
 def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_kernel<3")):
-    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     if not f:
         return {}
     agg, dur = collections.defaultdict(list), []
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(f[-1])):  # newest run
         if any(k in r["Kernel_Name"] for k in kernel_filter):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
