@@ -240,7 +240,7 @@ def profile_eval(profile, x, y, kwargs):
     yb = y.expand(out_shape).reshape(-1, B).contiguous()
     n_pts = xb.shape[0]
     out0 = torch.empty_like(xb)
-    is_mass = comp.kind <= 8
+    is_mass = comp.kind <= 12
     out1 = torch.empty_like(xb) if is_mass else None
     _check(lib().gl_profile_eval(ctypes.byref(comp), _ptr(xb), _ptr(yb), n_pts, B, 1, _ptr(P), _ptr(out0),
                                  _ptr(out1), _stream()))

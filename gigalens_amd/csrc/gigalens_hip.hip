@@ -574,8 +574,8 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   for (int i = 0; i < n_comp; ++i) {
     const gl_component& c = comps[i];
     const bool mass = i < n_lens;
-    const bool is_mass_kind = c.kind >= GL_EPL && c.kind <= GL_SERIES;
-    const bool is_light_kind = c.kind >= GL_SERSIC && c.kind <= GL_SHAPELETS;
+    const bool is_mass_kind = c.kind >= GL_EPL && c.kind <= GL_TNFW;
+    const bool is_light_kind = c.kind >= GL_SERSIC && c.kind <= GL_CORE_SERSIC;
     if ((mass && !is_mass_kind) || (!mass && !is_light_kind)) {
       delete m;
       return fail(GL_EINVAL, "component %d: kind %d is not a %s profile", i, c.kind, mass ? "mass" : "light");
@@ -586,7 +586,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
       if (iparam > 1000) { delete m; return fail(GL_EINVAL, "EPL niter %d too large", iparam); }
     }
     if (c.kind == GL_EPL) { m->epl_comp = m->has_epl ? -2 : i; m->has_epl = true; }
-    if (c.kind >= GL_DPIS && c.kind <= GL_SERIES) m->has_dpie = true;
+    if ((c.kind >= GL_DPIS && c.kind <= GL_TNFW) || c.kind == GL_CORE_SERSIC) m->has_dpie = true;  // extended families
     if (c.kind == GL_SERIES && (iparam < 0 || iparam > SERIES_MAX_ORDER)) {
       delete m;
       return fail(GL_EINVAL, "component %d: series order %d outside [0, %d]", i, iparam, SERIES_MAX_ORDER);
@@ -1109,7 +1109,8 @@ int gl_profile_hessian(const gl_component* comp, const float* x, const float* y,
                        const float* params, float* out, void* hip_stream) {
   if (!comp || !x || !y || !params || !out) return fail(GL_EINVAL, "null argument");
   if (n_pts <= 0 || B <= 0) return fail(GL_EINVAL, "n_pts and B must be positive");
-  if (comp->kind < GL_EPL || comp->kind > GL_DPIEP) return fail(GL_EINVAL, "kind %d is not a free-standing mass profile", comp->kind);
+  if (!((comp->kind >= GL_EPL && comp->kind <= GL_DPIEP) || comp->kind == GL_NFW_ELLIPSE || comp->kind == GL_TNFW))
+    return fail(GL_EINVAL, "kind %d is not a free-standing mass profile", comp->kind);
   CompDesc cd{};
   cd.kind = comp->kind;
   cd.iparam = comp->iparam;
@@ -1221,7 +1222,7 @@ int gl_profile_eval(const gl_component* comp, const float* x, const float* y, in
   if (npar < 0) return fail(GL_EINVAL, "unknown profile kind %d", comp->kind);
   if (comp->kind == GL_SCALED) return fail(GL_EINVAL, "GL_SCALED needs its catalogue: use gl_scaled_eval");
   if (comp->kind == GL_SERIES) return fail(GL_EINVAL, "GL_SERIES needs its coefficient field: use gl_series_eval");
-  const bool mass = comp->kind <= GL_DPIEP;
+  const bool mass = comp->kind <= GL_DPIEP || comp->kind == GL_NFW_ELLIPSE || comp->kind == GL_TNFW;
   if (mass && !out1) return fail(GL_EINVAL, "out1 is required for mass profiles");
   CompDesc cd{};
   cd.kind = comp->kind;

@@ -115,3 +115,21 @@ GLD_T Dual<T, N> p_atan2(const Dual<T, N>& y, const Dual<T, N>& x) { return l_at
 GLD_T Dual<T, N> p_pow(const Dual<T, N>& x, const Dual<T, N>& y) { return l_pow(x, y); }
 #undef GLD_T
 }  // namespace gld
+
+namespace glm {
+template <class T, int N> struct Wide<gld::Dual<T, N>> {
+  using type = gld::Dual<typename Wide<T>::type, N>;
+  static GL_HD type up(const gld::Dual<T, N>& x) {
+    type r;
+    r.v = Wide<T>::up(x.v);
+    for (int i = 0; i < N; ++i) r.d[i] = Wide<T>::up(x.d[i]);
+    return r;
+  }
+  static GL_HD gld::Dual<T, N> down(const type& x) {
+    gld::Dual<T, N> r;
+    r.v = Wide<T>::down(x.v);
+    for (int i = 0; i < N; ++i) r.d[i] = Wide<T>::down(x.d[i]);
+    return r;
+  }
+};
+}  // namespace glm

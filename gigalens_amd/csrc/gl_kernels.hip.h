@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include "gl_profiles.h"
 #include "gl_dpie.h"
+#include "gl_extra.h"
 #include "gl_vec.hip.h"
 #include "gl_members.hip.h"
 #include "gl_series.h"
@@ -196,6 +197,9 @@ __global__ void __launch_bounds__(128) gl_prep_kernel(const CompDesc* __restrict
     case K_DPIS: case K_DPIE: case K_DPIEP: dpie_prep<float>(cd.kind, p, d); break;
     case K_SCALED: d[0] = d[1] = d[2] = d[3] = 0.f; break;
     case K_SERIES: d[0] = p[0]; d[1] = p[1]; d[2] = d[3] = 0.f; break;
+    case K_NFW_ELLIPSE: nfw_ell_prep<float>(p, d); break;
+    case K_TNFW: tnfw_prep<float>(p, d); break;
+    case K_CORE_SERSIC: core_sersic_prep<float>(p, d); break;
     case K_SERSIC: sersic_prep<float>(p, false, d); break;
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, d); break;
@@ -282,6 +286,9 @@ __global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restric
     case K_DPIS: case K_DPIE: case K_DPIEP: dpie_prep<float>(cd.kind, p, dd); break;
     case K_SCALED: dd[0] = dd[1] = dd[2] = dd[3] = 0.f; break;
     case K_SERIES: dd[0] = p[0]; dd[1] = p[1]; dd[2] = dd[3] = 0.f; break;
+    case K_NFW_ELLIPSE: nfw_ell_prep<float>(p, dd); break;
+    case K_TNFW: tnfw_prep<float>(p, dd); break;
+    case K_CORE_SERSIC: core_sersic_prep<float>(p, dd); break;
     case K_SERSIC: sersic_prep<float>(p, false, dd); break;
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, dd); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, dd); break;
@@ -570,6 +577,18 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             for (int t = 0; t < T; ++t) { float ax, ay; piep_fwd<float>(d, d + DP_NS, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
           }
           break;
+        case K_NFW_ELLIPSE:
+          if constexpr (DP) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) { float ax, ay; nfw_ell_fwd<float>(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          }
+          break;
+        case K_TNFW:
+          if constexpr (DP) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) { float ax, ay; tnfw_fwd<float>(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          }
+          break;
         case K_SERIES: if constexpr (DP) {  // alpha = theta_E sum_n C_n(pixel) (r_cut - r0)^n   (series_profile.py:76-95)
           const SeriesDev sv = a.series[comps[l].flags];
           const float te = d[0], dl = d[1] - sv.r0;
@@ -624,7 +643,10 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
         } else {
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            const float v = sersic_fwd(d, src ? bx[t] : x[t], src ? by[t] : y[t]);
+            const float px_ = src ? bx[t] : x[t], py_ = src ? by[t] : y[t];
+            float v;
+            if (DP && cd.kind == K_CORE_SERSIC) v = core_sersic_fwd<float>(d, px_, py_);
+            else v = sersic_fwd(d, px_, py_);
             if (valid[t]) row[pidx[t]] = isnan_(v) ? 0.f : v;
           }
         }
@@ -643,6 +665,11 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
 #pragma unroll 1
           for (int t = 0; t < T; ++t)
             m[t] += shapelets_fwd<float, SH_CAP>(d, a.shp_tab, a.shp_stride, interp, src ? bx[t] : x[t], src ? by[t] : y[t]);
+        }
+      } else if (cd.kind == K_CORE_SERSIC) {
+        if constexpr (DP) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) m[t] += core_sersic_fwd<float>(d, src ? bx[t] : x[t], src ? by[t] : y[t]);
         }
       } else if constexpr (T % 2 == 0) {
 #pragma unroll
@@ -713,6 +740,19 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
               if (src) { gbx[t] += dgx; gby[t] += dgy; }
             }
             wave_acc<SHPA_AMP + SH_MAXL>(acc, ac, cd.a_off, cd.n_acc);
+          }
+        } else if (cd.kind == K_CORE_SERSIC) {
+          if constexpr (DP) {
+            float acc[CSR_NACC];
+#pragma unroll
+            for (int k = 0; k < CSR_NACC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              float dgx = 0.f, dgy = 0.f;
+              core_sersic_vjp<float>(d, src ? bx[t] : x[t], src ? by[t] : y[t], gm[t], acc, dgx, dgy);
+              if (src) { gbx[t] += dgx; gby[t] += dgy; }
+            }
+            wave_acc<CSR_NACC>(acc, ac, cd.a_off);
           }
         } else {
           float acc[SER_NACC];
@@ -815,6 +855,22 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             }
             wave_acc<DP_NACC>(acc, ac, cd.a_off);
           } break;
+          case K_NFW_ELLIPSE: if constexpr (DP) {
+            float acc[NFE_NACC];
+#pragma unroll
+            for (int k = 0; k < NFE_NACC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) nfw_ell_vjp<float>(d, x[t], y[t], gbx[t], gby[t], acc);
+            wave_acc<NFE_NACC>(acc, ac, cd.a_off);
+          } break;
+          case K_TNFW: if constexpr (DP) {
+            float acc[TNF_NACC];
+#pragma unroll
+            for (int k = 0; k < TNF_NACC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) tnfw_vjp<float>(d, x[t], y[t], gbx[t], gby[t], acc);
+            wave_acc<TNF_NACC>(acc, ac, cd.a_off);
+          } break;
           case K_SERIES: if constexpr (DP) {
             const SeriesDev sv = a.series[cd.flags];
             const float te = d[0], dl = d[1] - sv.r0;
@@ -914,6 +970,9 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
             if (cat.col[k] >= 0) g[cat.col[k]] = acc[k];
         } break;
         case K_SERIES: g[0] = acc[0]; g[1] = acc[1]; break;
+        case K_NFW_ELLIPSE: nfw_ell_finalize<float>(p, acc, g); break;
+        case K_TNFW: tnfw_finalize<float>(p, acc, g); break;
+        case K_CORE_SERSIC: core_sersic_finalize<float>(p, acc, g); break;
         case K_SERSIC: sersic_finalize<float>(p, false, acc, g); break;
         case K_SERSIC_ELLIPSE: sersic_finalize<float>(p, true, acc, g); break;
         case K_SHAPELETS: shapelets_finalize<float>(p, cd.iparam, acc, g); break;
@@ -985,6 +1044,9 @@ __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float*
     case K_SHEAR: { float d[4]; shear_prep<float>(p, d); shear_fwd(d, px, py, o0, o1); } break;
     case K_SIS: { float d[4]; sis_prep<float>(p, d); sis_fwd(d, px, py, o0, o1); } break;
     case K_DPIS: case K_DPIE: case K_DPIEP: { float d[DPX_ND]; dpie_prep<float>(cd.kind, p, d); dpie_fwd<float>(cd.kind, d, px, py, o0, o1); } break;
+    case K_NFW_ELLIPSE: { float d[NFE_ND]; nfw_ell_prep<float>(p, d); nfw_ell_fwd<float>(d, px, py, o0, o1); } break;
+    case K_TNFW: { float d[TNF_ND]; tnfw_prep<float>(p, d); tnfw_fwd<float>(d, px, py, o0, o1); } break;
+    case K_CORE_SERSIC: { float d[CSR_ND]; core_sersic_prep<float>(p, d); o0 = core_sersic_fwd<float>(d, px, py); } break;
     case K_SERSIC: { float d[SER_ND + 2]; sersic_prep<float>(p, false, d); o0 = sersic_fwd(d, px, py); } break;
     case K_SERSIC_ELLIPSE: { float d[SER_ND + 2]; sersic_prep<float>(p, true, d); o0 = sersic_fwd(d, px, py); } break;
     case K_SHAPELETS: {

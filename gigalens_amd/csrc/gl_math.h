@@ -71,4 +71,17 @@ GL_HD bool isnan_(float x) { return x != x; }
 
 template <class R> GL_HD R clamp_(R x, R lo, R hi) { return fmin_(fmax_(x, lo), hi); }
 
+// the wider twin of a real type, for the few expressions whose cancellation exceeds fp32 (float -> double; a type that
+// is already wide maps to itself; gl_dual.h extends this to dual numbers component-wise)
+template <class R> struct Wide {
+  using type = R;
+  static GL_HD type up(const R& x) { return x; }
+  static GL_HD R down(const type& x) { return x; }
+};
+template <> struct Wide<float> {
+  using type = double;
+  static GL_HD double up(float x) { return (double)x; }
+  static GL_HD float down(double x) { return (float)x; }
+};
+
 }  // namespace glm

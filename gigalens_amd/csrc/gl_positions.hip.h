@@ -51,6 +51,8 @@ template <class R> __device__ void lens_point(const PosArgs& a, const CompDesc& 
     case K_DPIS:
     case K_DPIE:
     case K_DPIEP: { R d[DPX_ND]; dpie_prep<R>(cd.kind, p, d); dpie_fwd<R>(cd.kind, d, x, y, ax, ay); } break;
+    case K_NFW_ELLIPSE: { R d[NFE_ND]; nfw_ell_prep<R>(p, d); nfw_ell_fwd<R>(d, x, y, ax, ay); } break;
+    case K_TNFW: { R d[TNF_ND]; tnfw_prep<R>(p, d); tnfw_fwd<R>(d, x, y, ax, ay); } break;
     case K_SCALED: {
       const CatDev cat = a.cats[cd.iparam];
       const ScaledDesc sd{cat.base_kind, cat.n_gal, {cat.col[0], cat.col[1], cat.col[2]}};

@@ -26,7 +26,9 @@ enum Kind : int {
   K_DPIS = 6, K_DPIE = 7, K_DPIEP = 8,  // gl_dpie.h
   K_SCALED = 9,                         // ScalingRelation over a galaxy catalogue (gl_dpie.h); iparam = catalogue slot
   K_SERIES = 10,                        // series expansion of a (scaled) dPIE in r_cut (gl_series.h); iparam = order, flags = field slot
-  K_SERSIC = 16, K_SERSIC_ELLIPSE = 17, K_SHAPELETS = 18
+  K_NFW_ELLIPSE = 11, K_TNFW = 12,      // gl_extra.h
+  K_SERSIC = 16, K_SERSIC_ELLIPSE = 17, K_SHAPELETS = 18,
+  K_CORE_SERSIC = 19                    // gl_extra.h
 };
 
 constexpr int SH_CAP = 10;                              // GL_SHAPELETS_NMAX_CAP
@@ -72,6 +74,9 @@ GL_HD int kind_num_params(int kind, int iparam) {
     case K_DPIEP: return 7;
     case K_SCALED: return (iparam >= 1 && iparam <= 3) ? iparam : -1;  // the population scales
     case K_SERIES: return (iparam >= 0 && iparam <= 5) ? 2 : -1;       // theta_E, r_cut
+    case K_NFW_ELLIPSE: return 6;
+    case K_TNFW: return 5;
+    case K_CORE_SERSIC: return 10;
     case K_SERSIC: return 5;
     case K_SERSIC_ELLIPSE: return 7;
     case K_SHAPELETS: return 3 + sh_layers(iparam);
@@ -90,6 +95,9 @@ GL_HD int kind_num_derived(int kind, int iparam) {
     case K_DPIEP: return 32;  // DPX_ND
     case K_SCALED: return 4;  // the member blocks live in the catalogue workspace, not in the sample's LDS block
     case K_SERIES: return 4;
+    case K_NFW_ELLIPSE:
+    case K_TNFW: return 8;
+    case K_CORE_SERSIC: return 16;
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_ND + 2;
     case K_SHAPELETS: return SHP_AMP + ((sh_layers(iparam) + 3) & ~3);
@@ -100,7 +108,8 @@ GL_HD int kind_num_derived(int kind, int iparam) {
 GL_HD int kind_num_linear(int kind, int iparam) {
   switch (kind) {
     case K_SERSIC:
-    case K_SERSIC_ELLIPSE: return 1;
+    case K_SERSIC_ELLIPSE:
+    case K_CORE_SERSIC: return 1;
     case K_SHAPELETS: return sh_layers(iparam);
   }
   return 0;
@@ -110,6 +119,7 @@ GL_HD int kind_linear_col(int kind, int iparam) {  // first amplitude column ins
     case K_SERSIC: return 4;
     case K_SERSIC_ELLIPSE: return 6;
     case K_SHAPELETS: return 3;
+    case K_CORE_SERSIC: return 9;
   }
   (void)iparam;
   return -1;
@@ -126,6 +136,9 @@ GL_HD int kind_num_acc(int kind, int iparam) {
     case K_DPIEP: return 7;  // DP_NACC
     case K_SCALED: return 3;
     case K_SERIES: return 2;
+    case K_NFW_ELLIPSE: return 6;
+    case K_TNFW: return 5;
+    case K_CORE_SERSIC: return 10;
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_NACC;
     case K_SHAPELETS: return SHPA_AMP + sh_layers(iparam);

@@ -20,3 +20,12 @@ class SersicEllipse(Sersic):
     _params = ["R_sersic", "n_sersic", "e1", "e2", "center_x", "center_y"]
     _amp = "Ie"
     _kind = 17
+
+
+class CoreSersic(Sersic):
+    """Core-Sersic profile, with the reference's expression as written (sersic.py:83-131)."""
+
+    _name = "CORE_SERSIC"
+    _params = ["R_sersic", "n_sersic", "Rb", "alpha", "gamma", "e1", "e2", "center_x", "center_y"]
+    _amp = "Ie"
+    _kind = 19

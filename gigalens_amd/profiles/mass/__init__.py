@@ -1,2 +1,2 @@
 from gigalens_amd.profiles.mass import (dpie_series, dpie_subhalo, epl, nfw, piemd, piep, scaling_relation,  # noqa: F401
-                                        shear, sie, sis)
+                                        shear, sie, sis, tnfw)

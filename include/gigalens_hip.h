@@ -54,10 +54,13 @@ typedef enum gl_kind {
   GL_SERIES = 10, /* tf/series/series_profile.py:9-95 with dpie_series.py / scaling_series.py / dpie_subhalo_series.py:
                      the (scaled) dPIE deflection expanded in the cut radius around r0, precomputed on the model grid;
                      parameters [theta_E, r_cut]; iparam = order (0..5); field attached with gl_model_set_series */
+  GL_NFW_ELLIPSE = 11, /* tf/profiles/mass/nfw.py:100   [Rs,alpha_Rs,e1,e2,center_x,center_y] */
+  GL_TNFW = 12,        /* tf/profiles/mass/tnfw.py:12   [Rs,alpha_Rs,r_trunc,center_x,center_y] */
   /* light profiles: LightProfile.light (profile.py:24-60) */
   GL_SERSIC = 16,         /* tf/profiles/light/sersic.py:23-24 [R_sersic,n_sersic,center_x,center_y,Ie] */
   GL_SERSIC_ELLIPSE = 17, /* sersic.py:68-69 [R_sersic,n_sersic,e1,e2,center_x,center_y,Ie] */
-  GL_SHAPELETS = 18       /* tf/profiles/light/shapelets.py:18,34-36 [beta,center_x,center_y,amp0..amp{L-1}] */
+  GL_SHAPELETS = 18,      /* tf/profiles/light/shapelets.py:18,34-36 [beta,center_x,center_y,amp0..amp{L-1}] */
+  GL_CORE_SERSIC = 19     /* sersic.py:85-96 [R_sersic,n_sersic,Rb,alpha,gamma,e1,e2,center_x,center_y,Ie] */
 } gl_kind;
 
 #define GL_SHAPELETS_NMAX_CAP 10 /* largest n_max the register-resident shapelet path serves */

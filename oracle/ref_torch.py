@@ -178,6 +178,54 @@ def nfw_deriv(x, y, Rs, alpha_Rs, center_x, center_y):
     return a * x, a * y
 
 
+def nfw_ellipse_deriv(x, y, Rs, alpha_Rs, e1, e2, center_x, center_y):
+    """tf/profiles/mass/nfw.py:108-133: NFW on coordinates stretched by sqrt(1 -+ e), e = |1-q^2|/(1+q^2)."""
+    Rs, alpha_Rs, e1, e2, center_x, center_y = (_t(v, x) for v in (Rs, alpha_Rs, e1, e2, center_x, center_y))
+    rho0 = alpha_Rs / (4.0 * Rs ** 2 * (1.0 - math.log(2.0)))
+    phi = torch.atan2(e2, e1) / 2
+    c = torch.clamp(torch.sqrt(e1 ** 2 + e2 ** 2), max=0.9999)
+    q = (1 - c) / (1 + c)
+    e = torch.abs(1 - q ** 2) / (1 + q ** 2)
+    x, y = x - center_x, y - center_y
+    x, y = _rotate(x, y, phi)
+    x, y = x * torch.sqrt(1 - e), y * torch.sqrt(1 + e)
+    R = torch.sqrt(x ** 2 + y ** 2)
+    # nfwAlpha (nfw.py:23-31)
+    Rc = torch.clamp(R, min=1e-7)
+    Rsc = torch.clamp(Rs, min=1e-7)
+    X = Rc / Rsc
+    a = 4 * rho0 * Rsc * _nfw_g(X) / X ** 2
+    fx, fy = a * x * torch.sqrt(1 - e), a * y * torch.sqrt(1 + e)
+    return _rotate(fx, fy, -phi)
+
+
+def _tnfw_F(x):
+    """tnfw.py:43-62 (both branches evaluated on safe arguments, selected afterwards; F(1) = 1)."""
+    lo = torch.clamp(x, max=1 - 1e-15)
+    hi = torch.clamp(x, min=1 + 1e-15)
+    f1 = torch.atanh(torch.sqrt(1 - lo ** 2)) / torch.sqrt(1 - lo ** 2)
+    f2 = torch.atan(torch.sqrt(hi ** 2 - 1)) / torch.sqrt(hi ** 2 - 1)
+    return torch.where(x < 1, f1, torch.where(x > 1, f2, torch.ones_like(x)))
+
+
+def tnfw_deriv(x, y, Rs, alpha_Rs, r_trunc, center_x, center_y):
+    """tf/profiles/mass/tnfw.py:17-41."""
+    Rs, alpha_Rs, r_trunc, center_x, center_y = (_t(v, x) for v in (Rs, alpha_Rs, r_trunc, center_x, center_y))
+    rho0 = alpha_Rs / (4.0 * Rs ** 2 * (1.0 + math.log(0.5)))
+    x, y = x - center_x, y - center_y
+    R = torch.sqrt(x ** 2 + y ** 2)
+    R = torch.maximum(R, 0.001 * Rs)
+    X = R / Rs
+    tau = r_trunc / Rs
+    L = torch.log(X / (tau + torch.sqrt(tau ** 2 + X ** 2)))
+    F = _tnfw_F(X)
+    gx = (tau ** 2) / (tau ** 2 + 1) ** 2 * (
+        (tau ** 2 + 1 + 2 * (X ** 2 - 1)) * F + tau * math.pi + (tau ** 2 - 1) * torch.log(tau)
+        + torch.sqrt(tau ** 2 + X ** 2) * (-math.pi + L * (tau ** 2 - 1) / tau))
+    a = 4 * rho0 * Rs * gx / X ** 2
+    return a * x, a * y
+
+
 def shear_deriv(x, y, gamma1, gamma2):
     """tf/profiles/mass/shear.py:14-16."""
     gamma1, gamma2 = _t(gamma1, x), _t(gamma2, x)
@@ -494,6 +542,16 @@ def sersic_light(x, y, R_sersic, n_sersic, center_x, center_y, Ie, e1=None, e2=N
     return Ie * torch.exp(-bn * ((R / R_sersic) ** (1 / n_sersic) - 1.0))
 
 
+def core_sersic_light(x, y, R_sersic, n_sersic, Rb, alpha, gamma, e1, e2, center_x, center_y, Ie):
+    """tf/profiles/light/sersic.py:98-131, operator precedence as written: ``R_sersic ** alpha ** 1.0`` is
+    ``R_sersic ** alpha`` and the following ``/ (alpha * n_sersic)`` divides."""
+    R_sersic, n_sersic, Rb, alpha, gamma, Ie = (_t(v, x) for v in (R_sersic, n_sersic, Rb, alpha, gamma, Ie))
+    R = sersic_distance(x, y, center_x, center_y, e1, e2)
+    bn = 1.9992 * n_sersic - 0.3271
+    return (Ie * (1 + (Rb / R) ** alpha) ** (gamma / alpha)
+            * torch.exp(-bn * ((R ** alpha + Rb ** alpha) / R_sersic ** alpha ** 1.0 / (alpha * n_sersic)) - 1.0))
+
+
 def shapelet_index_order(n_max):
     """tf/profiles/light/shapelets.py:26-46: (n1,n2) = (0,0),(1,0),(0,1),(2,0),(1,1),(0,2),..."""
     n_layers = int((n_max + 1) * (n_max + 2) / 2)
@@ -613,6 +671,10 @@ def mass_deriv(profile, x, y, **kw):
         return shear_deriv(x, y, **kw)
     if name == "SIS":
         return sis_deriv(x, y, **kw)
+    if name == "NFW_ELLIPSE":
+        return nfw_ellipse_deriv(x, y, **kw)
+    if name == "TNFW":
+        return tnfw_deriv(x, y, **kw)
     if name == "dPIS":
         return dpis_deriv(x, y, **kw)
     if name == "dPIE" and "Ra" in profile.params:  # piep.py:22 reuses the name "dPIE"
@@ -656,6 +718,9 @@ def light_basis(profile, x, y, **kw):
     if name in ("SERSIC", "SERSIC_ELLIPSE"):
         kw = {k: v for k, v in kw.items() if k != "Ie"}
         return sersic_light(x, y, Ie=1.0, **kw)[None]
+    if name == "CORE_SERSIC":
+        kw = {k: v for k, v in kw.items() if k != "Ie"}
+        return core_sersic_light(x, y, Ie=1.0, **kw)[None]
     if name == "SHAPELETS":
         return shapelets_light(x, y, kw["center_x"], kw["center_y"], kw["beta"], None, profile.n_max,
                                getattr(profile, "interpolate", True))
@@ -666,6 +731,8 @@ def light_eval(profile, x, y, **kw):
     name = profile.name
     if name in ("SERSIC", "SERSIC_ELLIPSE"):
         return sersic_light(x, y, **kw)
+    if name == "CORE_SERSIC":
+        return core_sersic_light(x, y, **kw)
     if name == "SHAPELETS":
         names = shapelet_amp_names(profile.n_max)
         amps = [kw[k] for k in sorted(k for k in kw if k.startswith("amp"))]

@@ -11,6 +11,7 @@
 #include "../../gigalens_amd/csrc/gl_profiles.h"
 #include "../../gigalens_amd/csrc/gl_dpie.h"
 #include "../../gigalens_amd/csrc/gl_series.h"
+#include "../../gigalens_amd/csrc/gl_extra.h"
 #include "../../gigalens_amd/csrc/gl_dual.h"
 
 using namespace glp;
@@ -34,6 +35,8 @@ void run_mass(int kind, int iparam, const R* p, int n, const R* x, const R* y, c
     case K_SHEAR: shear_prep<R>(p, d.data()); break;
     case K_SIS: sis_prep<R>(p, d.data()); break;
     case K_DPIS: case K_DPIE: case K_DPIEP: dpie_prep<R>(kind, p, d.data()); break;
+    case K_NFW_ELLIPSE: nfw_ell_prep<R>(p, d.data()); break;
+    case K_TNFW: tnfw_prep<R>(p, d.data()); break;
   }
   for (int i = 0; i < n; ++i) {
     switch (kind) {
@@ -44,6 +47,8 @@ void run_mass(int kind, int iparam, const R* p, int n, const R* x, const R* y, c
       case K_SIS: sis_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); sis_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
       case K_DPIS: case K_DPIE: case K_DPIEP:
         dpie_fwd<R>(kind, d.data(), x[i], y[i], ax[i], ay[i]); dpie_vjp<R>(kind, d.data(), x[i], y[i], gx[i], gy[i], acc); break;
+      case K_NFW_ELLIPSE: nfw_ell_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); nfw_ell_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
+      case K_TNFW: tnfw_fwd<R>(d.data(), x[i], y[i], ax[i], ay[i]); tnfw_vjp<R>(d.data(), x[i], y[i], gx[i], gy[i], acc); break;
     }
   }
   switch (kind) {
@@ -53,6 +58,8 @@ void run_mass(int kind, int iparam, const R* p, int n, const R* x, const R* y, c
     case K_SHEAR: shear_finalize<R>(p, acc, grad); break;
     case K_SIS: sis_finalize<R>(p, acc, grad); break;
     case K_DPIS: case K_DPIE: case K_DPIEP: dpie_finalize<R>(kind, p, acc, grad); break;
+    case K_NFW_ELLIPSE: nfw_ell_finalize<R>(p, acc, grad); break;
+    case K_TNFW: tnfw_finalize<R>(p, acc, grad); break;
   }
 }
 
@@ -98,11 +105,15 @@ void run_light(int kind, int iparam, unsigned flags, const R* p, int n, const R*
     case K_SERSIC: sersic_prep<R>(p, false, d.data()); break;
     case K_SERSIC_ELLIPSE: sersic_prep<R>(p, true, d.data()); break;
     case K_SHAPELETS: shapelets_prep<R>(p, iparam, d.data()); break;
+    case K_CORE_SERSIC: core_sersic_prep<R>(p, d.data()); break;
   }
   for (int i = 0; i < n; ++i) {
     gpx[i] = 0;
     gpy[i] = 0;
-    if (kind == K_SHAPELETS) {
+    if (kind == K_CORE_SERSIC) {
+      I[i] = core_sersic_fwd<R>(d.data(), x[i], y[i]);
+      core_sersic_vjp<R>(d.data(), x[i], y[i], gI[i], acc.data(), gpx[i], gpy[i]);
+    } else if (kind == K_SHAPELETS) {
       I[i] = shapelets_fwd<R, SH_CAP>(d.data(), tab.data(), stride, interp, x[i], y[i]);
       shapelets_vjp<R, SH_CAP>(d.data(), tab.data(), stride, interp, x[i], y[i], gI[i], acc.data(), gpx[i], gpy[i]);
     } else {
@@ -114,6 +125,7 @@ void run_light(int kind, int iparam, unsigned flags, const R* p, int n, const R*
     case K_SERSIC: sersic_finalize<R>(p, false, acc.data(), grad); break;
     case K_SERSIC_ELLIPSE: sersic_finalize<R>(p, true, acc.data(), grad); break;
     case K_SHAPELETS: shapelets_finalize<R>(p, iparam, acc.data(), grad); break;
+    case K_CORE_SERSIC: core_sersic_finalize<R>(p, acc.data(), grad); break;
   }
 }
 
@@ -136,6 +148,8 @@ template <int PL> static void lens_jet(int kind, int iparam, const double* p0, d
     case K_NFW: { R d[NFW_ND]; nfw_prep<R>(p, d); nfw_fwd<R>(d, x, y, ax, ay); } break;
     case K_SHEAR: { R d[4]; shear_prep<R>(p, d); shear_fwd<R>(d, x, y, ax, ay); } break;
     case K_DPIS: case K_DPIE: case K_DPIEP: { R d[DPX_ND]; dpie_prep<R>(kind, p, d); dpie_fwd<R>(kind, d, x, y, ax, ay); } break;
+    case K_NFW_ELLIPSE: { R d[NFE_ND]; nfw_ell_prep<R>(p, d); nfw_ell_fwd<R>(d, x, y, ax, ay); } break;
+    case K_TNFW: { R d[TNF_ND]; tnfw_prep<R>(p, d); tnfw_fwd<R>(d, x, y, ax, ay); } break;
     default: { R d[4]; sis_prep<R>(p, d); sis_fwd<R>(d, x, y, ax, ay); } break;
   }
   if (kind == K_DPIS) {  // the reference's analytic override (piemd.py:62-83), see dpis_kappa_excess
@@ -193,6 +207,8 @@ void hm_lens_jet_f64(int kind, int iparam, const double* p, double x, double y, 
     case K_SHEAR: lens_jet<2>(kind, iparam, p, x, y, out); break;
     case K_DPIS: lens_jet<5>(kind, iparam, p, x, y, out); break;
     case K_DPIE: case K_DPIEP: lens_jet<7>(kind, iparam, p, x, y, out); break;
+    case K_NFW_ELLIPSE: lens_jet<6>(kind, iparam, p, x, y, out); break;
+    case K_TNFW: lens_jet<5>(kind, iparam, p, x, y, out); break;
     default: lens_jet<3>(kind, iparam, p, x, y, out); break;
   }
 }
