@@ -74,6 +74,8 @@ SYMBOLS = {
     "gl_model_set_catalogue": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int32), POINTER(c_float)]),
     "gl_scaled_eval": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gl_scaled_hessian": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                  c_void_p, c_int, c_void_p, c_void_p]),
     "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     "gl_profile_hessian": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
@@ -206,6 +208,19 @@ def series_eval(series, amplitude, var):
         shape = shape[:-1]
         o0, o1 = o0.reshape(-1, B, B).diagonal(dim1=1, dim2=2), o1.reshape(-1, B, B).diagonal(dim1=1, dim2=2)
     return o0.reshape(shape + (B,)), o1.reshape(shape + (B,))
+
+
+def scaled_hessian(profile, x, y, scales):
+    """ScalingRelation.hessian (scaling_relation.py:72-83) through gl_scaled_hessian."""
+    dev = device()
+    xb, yb, P, B, out_shape = _broadcast_points(profile, x, y, scales, list(profile.params), dev)
+    base_kind, cols, table = profile._catalogue()
+    if profile._dev_table is None or profile._dev_table.device != dev:
+        profile._dev_table = torch.from_numpy(table).to(dev)
+    out = torch.empty((4,) + tuple(xb.shape), dtype=torch.float32, device=dev)
+    _check(lib().gl_scaled_hessian(base_kind, table.shape[0], (c_int32 * 3)(*cols), _ptr(profile._dev_table), _ptr(xb),
+                                   _ptr(yb), xb.shape[0], B, 1, _ptr(P), P.shape[1], _ptr(out), _stream()))
+    return tuple(out[k].reshape(out_shape) for k in range(4))
 
 
 def profile_hessian(profile, x, y, kwargs):

@@ -1066,6 +1066,23 @@ int gl_scaled_eval(int base_kind, int n_galaxies, const int32_t scale_col[3], co
   return GL_OK;
 }
 
+int gl_scaled_hessian(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev, const float* x,
+                      const float* y, int64_t n_pts, int B, int xy_batched, const float* scales, int n_scales,
+                      float* out, void* hip_stream) {
+  if (!scale_col || !table_dev || !x || !y || !scales || !out) return fail(GL_EINVAL, "null argument");
+  if (base_kind != GL_DPIS && base_kind != GL_DPIE && base_kind != GL_DPIEP)
+    return fail(GL_EUNSUPPORTED, "ScalingRelation over profile kind %d is not built (dPIS, dPIE, dPIEP are)", base_kind);
+  if (n_galaxies <= 0 || n_pts <= 0 || B <= 0 || n_scales < 1 || n_scales > 3) return fail(GL_EINVAL, "bad sizes");
+  for (int k = 0; k < 3; ++k)
+    if (scale_col[k] >= n_scales) return fail(GL_EINVAL, "scale_col[%d]=%d outside the %d scales", k, scale_col[k], n_scales);
+  ScaledDesc sd{base_kind, n_galaxies, {scale_col[0], scale_col[1], scale_col[2]}};
+  long long total = (long long)n_pts * B;
+  hipLaunchKernelGGL(gl_scaled_hessian_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream,
+                     sd, table_dev, x, y, (long long)n_pts, B, xy_batched, scales, n_scales, out);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
 int gl_model_set_positions(gl_model* m, int n_families, const int* family_sizes, const float* x, const float* y,
                            const float* err_x, const float* err_y) {
   if (!m) return fail(GL_EINVAL, "model is null");

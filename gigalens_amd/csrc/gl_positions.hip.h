@@ -178,6 +178,46 @@ __global__ void __launch_bounds__(64) gl_profile_hessian_kernel(CompDesc cd, con
   out[i] = ax.d[0] + ex; out[st + i] = ax.d[1]; out[2 * st + i] = ay.d[0]; out[3 * st + i] = ay.d[1] + ex;
 }
 
+// ScalingRelation.hessian at plugin level (scaling_relation.py:72-83): sum of the member Hessians, out[4][n_pts][B]
+__global__ void __launch_bounds__(64) gl_scaled_hessian_kernel(ScaledDesc sd, const float* __restrict__ table,
+                                                              const float* __restrict__ x, const float* __restrict__ y,
+                                                              long long n_pts, int B, int xy_batched,
+                                                              const float* __restrict__ scales, int n_scales,
+                                                              float* __restrict__ out) {
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_pts * B) return;
+  const long long pt = i / B;
+  const int b = (int)(i - pt * B);
+  const float px = xy_batched ? x[i] : x[pt], py = xy_batched ? y[i] : y[pt];
+  using R = gld::Dual<float, 2>;
+  R xd(px), yd(py);
+  xd.d[0] = 1.f;
+  yd.d[1] = 1.f;
+  R sc[3];
+  float scf[3] = {1.f, 1.f, 1.f};
+  for (int k = 0; k < n_scales; ++k) scf[k] = scales[(size_t)b * n_scales + k];
+  for (int k = 0; k < 3; ++k) sc[k] = R(scf[k]);
+  float fxx = 0.f, fxy = 0.f, fyx = 0.f, fyy = 0.f;
+  for (int g = 0; g < sd.n_gal; ++g) {
+    const float* row = table + (size_t)7 * g;
+    float dsf[DP_NS], ddf[DP_ND];
+    scaled_static<float>(sd.base_kind, row, dsf);
+    R ds[DP_NS], dd[DP_ND], ax, ay;
+    for (int k = 0; k < DP_NS; ++k) ds[k] = R(dsf[k]);
+    scaled_dyn<R>(sd, row, sc, dd);
+    if (sd.base_kind == K_DPIE) piemd_fwd<R>(ds, dd, xd, yd, ax, ay);
+    else piep_fwd<R>(ds, dd, xd, yd, ax, ay);
+    float ex = 0.f;
+    if (sd.base_kind == K_DPIS) {  // the analytic dPIS override (piemd.py:62-83)
+      scaled_dyn<float>(sd, row, scf, ddf);
+      ex = dpis_kappa_excess<float>(dsf, ddf, px, py);
+    }
+    fxx += ax.d[0] + ex; fxy += ax.d[1]; fyx += ay.d[0]; fyy += ay.d[1] + ex;
+  }
+  const long long st = n_pts * B;
+  out[i] = fxx; out[st + i] = fxy; out[2 * st + i] = fyx; out[3 * st + i] = fyy;
+}
+
 __global__ void __launch_bounds__(64) gl_pos_p2_kernel(PosArgs a) {
   int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= a.B * a.F) return;

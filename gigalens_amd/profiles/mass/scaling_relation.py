@@ -86,7 +86,5 @@ class ScalingRelation(MassProfile):
         return _native.scaled_eval(self, x, y, scales)
 
     def hessian(self, x, y, **scales):
-        raise NotImplementedError("hessian / convergence / shear maps are not built; the image-position likelihood "
-                                  "evaluates the catalogue's Hessian natively (gl_positions.hip.h)")
-
-    convergence = shear = hessian
+        """scaling_relation.py:72-83: the sum of the members' Hessians as the base profile resolves ``hessian``."""
+        return _native.scaled_hessian(self, x, y, scales)

@@ -170,6 +170,12 @@ int gl_model_set_positions(gl_model* m, int n_families, const int* family_sizes,
 int gl_positions_fwd_bwd(const gl_model* m, const float* params, int B, float* loglike, float* chi2,
                          float* grad_params_or_null, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* ScalingRelation.hessian on arbitrary points (scaling_relation.py:72-83): out [4][n_pts][B] = f_xx, f_xy, f_yx, f_yy
+ * summed over the catalogue; other arguments as gl_scaled_eval. */
+int gl_scaled_hessian(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev, const float* x,
+                      const float* y, int64_t n_pts, int B, int xy_batched, const float* scales, int n_scales,
+                      float* out, void* hip_stream);
+
 /* Series-expansion accelerator (MassSeries.set_grid / set_constants / set_deriv, tf/series/series_profile.py:54-62;
  * ScalingRelationSeries.precompute_deriv, scaling_series.py:19-35; DPIESeries.precompute_deriv, dpie_series.py:19-33).
  * gl_series_precompute: Taylor coefficients C_n, n = 0..order, of the population's deflection per unit amplitude in the

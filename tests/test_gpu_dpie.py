@@ -77,6 +77,21 @@ def test_scaling_relation_deriv(gl, base, scaling):
     sc = float(ox.abs().max())
     assert np.allclose(fx.cpu().numpy(), ox.numpy(), rtol=1e-5, atol=2e-5 * sc)
     assert np.allclose(fy.cpu().numpy(), oy.numpy(), rtol=1e-5, atol=2e-5 * sc)
+    # hessian / convergence / shear of the population (scaling_relation.py:72-104)
+    h = [t.cpu().numpy() for t in prof.hessian(x[:, None], y[:, None], **scales)]
+    ho = [t.detach().numpy() for t in ref.mass_hessian(prof, torch.as_tensor(x, dtype=F64)[:, None],
+                                                       torch.as_tensor(y, dtype=F64)[:, None],
+                                                       **{k: torch.as_tensor(v, dtype=F64) for k, v in scales.items()})]
+    hs = np.quantile(np.abs(ho[0]), 0.9)
+    ok = np.abs(ho[0]) < 20 * hs  # away from the members' centres (1/r^2)
+    # near a dPIE member's foci (removable 0/0 of the Kassiola-Kovner form) fp32 second derivatives lose digits like
+    # 1/distance^2: demand the tolerance on 99 % of the points and a loose bound on the rest
+    for a, b in zip(h, ho):
+        err = np.abs(a - b)[ok] / (np.abs(b[ok]) + hs)
+        assert np.quantile(err, 0.99) <= 1e-3 and err.max() <= 0.2, (np.quantile(err, 0.99), err.max())
+    kap = prof.convergence(x[:, None], y[:, None], **scales).cpu().numpy()
+    err = np.abs(kap - 0.5 * (ho[0] + ho[3]))[ok] / (np.abs(0.5 * (ho[0] + ho[3]))[ok] + hs)
+    assert np.quantile(err, 0.99) <= 1e-3
 
 
 def _mixed_cluster(num_pix, batch):
