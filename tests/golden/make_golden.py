@@ -26,12 +26,15 @@ CASES = {
     "c3_shapelets_table_24": ("C3", dict(num_pix=24, batch=2, interpolate=True)),
     "c3_shapelets_direct_24": ("C3", dict(num_pix=24, batch=2, interpolate=False)),
     "c4_cluster_32": ("C4", dict(num_pix=32, batch=2, n_halos=3, n_sources=4)),
+    "c6_cluster_members_28": ("C6", dict(num_pix=28, batch=2, n_galaxies=15, n_sources=2)),  # dPIE halo + catalogue
 }
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     for name, (wname, kw) in CASES.items():
+        if os.path.exists(os.path.join(out_dir, name + ".npz")) and "--all" not in sys.argv:
+            continue  # committed fixtures are never silently regenerated
         wl = workloads.make(wname, **kw)
         B, n = wl.batch, wl.sim_config.num_pix
         pack = _Packing(wl.phys_model)
