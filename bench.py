@@ -173,10 +173,13 @@ def main():
         bytes_b2 = 4 * (2 * P + 2) + 4 * N * n_planes / B
         achieved = bytes_b1 * B / (main_ms * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), profiles/<tag>_summary.json
+        valu_busy = None  # the binding bound (BASELINE.md section 4 `valu_fraction`): measured VALU-pipe busy fraction
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
             if prof and args.workload.upper() == "C2" and B == 1024:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1]))).get("traffic_bytes_per_launch")
+                summ = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+                traffic = summ.get("traffic_bytes_per_launch")
+                valu_busy = summ.get("valu_busy_frac")
         except Exception:
             traffic = None
         out = {
@@ -197,6 +200,7 @@ def main():
                          "kernel_ms": round(main_ms, 4), "native_call_ms": round(native_ms, 4),
                          "algorithmic_bytes_per_sim_B1": bytes_b1, "algorithmic_bytes_per_sim_B2": round(bytes_b2, 1),
                          "kernel_sims_per_s": round(B / (main_ms * 1e-3), 1),
+                         "valu_busy_frac": None if valu_busy is None else round(valu_busy, 4),
                          "note": "path is VALU/transcendental-bound (SURVEY 8d): HBM fraction is reported as the "
                                  "metric asks, the binding bound is fp32 VALU issue"},
         }
