@@ -336,3 +336,47 @@ def test_series_lens_in_the_pixel_likelihood(gl):
     lp2.sum().backward()
     assert torch.allclose(lp1, lp2, rtol=2e-5)
     assert torch.all((z1.grad - z2.grad).abs() <= 2e-4 * z2.grad.abs().max(dim=1, keepdim=True).values + 1e-5)
+
+
+def test_full_size_cluster_properties(gl):
+    """BASELINE-size cluster grid (256x256 px, 200 member galaxies), size-independent properties:
+    (1) permuting the catalogue changes nothing but the summation order;
+    (2) at r_cut == r_cut0 the series-expansion lens (float64 jets, C6S) and the member loop (C6) are the same model:
+        two independent evaluations of the population must give the same likelihood and gradient."""
+    B = 8
+    wl = gl.workloads.make("C6", batch=B)
+    wls = gl.workloads.make("C6S", batch=B)
+    obs, _, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    obs_np = obs.cpu().numpy()
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=B)
+    packed = H.sample_packed(wl, sim, seed=3)
+    members = wl.phys_model.lenses[1]
+    cols = {n: sim._layout.slots.index(("lens_mass", 1, n, None)) for n in ("theta_E", "r_core", "r_cut")}
+    packed[:, cols["r_core"]] = 0.02   # the constants the series was expanded with (workloads.make("C6S"))
+    packed[:, cols["r_cut"]] = 2.0
+    pm = gl.ForwardProbModel(wl.prior, obs_np, wl.background_rms, wl.exp_time, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, _ = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    # (1) permuted catalogue
+    perm = np.random.default_rng(0).permutation(members.n_galaxy)
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.mass.dpie_subhalo import DPIESubhalo
+    cat2 = {k: np.asarray(v)[perm] for k, v in members.galaxy_cat.items()}
+    phys2 = PhysicalModel([wl.phys_model.lenses[0], DPIESubhalo(lum_star=members.lum_star, galaxy_catalogue=cat2)], [],
+                          wl.phys_model.source_light)
+    sim2 = gl.LensSimulator(phys2, wl.sim_config, bs=B)
+    ll2, _ = pm._pixel_stats_packed(sim2, packed)
+    assert torch.allclose(ll2, ll.detach(), rtol=2e-5)
+    # (2) the series lens at its expansion point: parameters [.., theta_E, r_cut, ..] without r_core
+    sims = gl.LensSimulator(wls.phys_model, wls.sim_config, bs=B)
+    keep = [k for k in range(packed.shape[1]) if k != cols["r_core"]]
+    packed_s = packed[:, keep].contiguous()
+    pms = gl.ForwardProbModel(wls.prior, obs_np, wls.background_rms, wls.exp_time, include_positions=False)
+    ps = packed_s.clone().requires_grad_(True)
+    lls, _ = pms._pixel_stats_packed(sims, ps)
+    lls.sum().backward()
+    assert torch.allclose(lls, ll.detach(), rtol=5e-5), (lls, ll)
+    g, gs = p.grad[:, keep], ps.grad
+    sc = g.abs().max(dim=1, keepdim=True).values
+    assert torch.all((g - gs).abs() <= 5e-3 * torch.maximum(g.abs(), 1e-2 * sc) + 1e-5), ((g - gs).abs() / sc).max()
