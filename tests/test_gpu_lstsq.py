@@ -132,3 +132,31 @@ def test_lstsq_errors(gl):
     packed = sim2.pack(wl2.prior.sample(2, seed=0))
     with pytest.raises(_native.NativeLibraryError):  # coefficients need obs and err
         sim2._model.lstsq(packed, None, None, 7, want="coeffs")
+
+
+def test_full_size_round_trip(gl):
+    """BASELINE-size shapelet grid (128x128 px, n_max = 10, 66 coefficients): simulate with known amplitudes, solve
+    for them again.  Size-independent property: lstsq_simulate inverts simulate on its own output (noise-free, unit
+    error map), coefficient = amplitude x det(T) (tf/simulator.py:156 vs :226-240)."""
+    B = 16
+    wl_fwd = gl.workloads.make("C3", batch=B, interpolate=False)    # amplitudes as parameters
+    wl_lsq = gl.workloads.make("C3L", batch=B, interpolate=False)   # the same model with use_lstsq=True
+    sim_f = gl.LensSimulator(wl_fwd.phys_model, wl_fwd.sim_config, bs=B)
+    sim_l = gl.LensSimulator(wl_lsq.phys_model, wl_lsq.sim_config, bs=B)
+    x = wl_fwd.prior.sample(B, seed=2)
+    # one observation = the image of sample 0; every sample shares its non-linear parameters so that all B solves agree
+    for grp in x.values():
+        for d in grp:
+            for k in d:
+                d[k] = d[k][:1].expand(B).clone()
+    img = sim_f.simulate(x)[0]
+    err = torch.ones_like(img)
+    x_l = {g: [{k: v for k, v in d.items() if not k.startswith("amp")} for d in lst] for g, lst in x.items()}
+    coeffs = sim_l.lstsq_simulate(x_l, img, err, return_coeffs=True)
+    amps = torch.stack([x["source_light"][0][n] for n in wl_fwd.phys_model.source_light[0]._amp_names], dim=1)
+    want = amps.to(coeffs.device) * sim_f.conversion_factor
+    scale = want.abs().max()
+    assert torch.all((coeffs - want).abs() <= 2e-3 * scale), ((coeffs - want).abs().max() / scale)
+    fit = sim_l.lstsq_simulate(x_l, img, err)
+    assert torch.all((fit - img).abs() <= 1e-4 * img.abs().max())
+    assert torch.allclose(coeffs[0], coeffs[-1], rtol=0, atol=1e-6 * float(scale))  # deterministic across the batch
