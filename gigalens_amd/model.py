@@ -444,3 +444,19 @@ class BackwardProbModel(ProbabilisticModel):
         full = packed.index_copy(1, lin, coeffs / simulator.conversion_factor)  # amplitude = coeff / det(T)
         ll, chi2 = _LogLikeFn.apply(full, simulator._model, self.observed_image, self.err_map, None, 0.0, 1.0)
         return ll + log_prior, chi2 / float(self.observed_image.numel())
+
+    # -- what ModellingSequence.MAP / SVI / HMC need from a probabilistic model (shapelets-demo.ipynb runs them on it) --
+    include_pixels, include_positions, n_position = True, False, 0.0
+
+    def log_prob_and_grad(self, simulator, z):
+        zz = torch.as_tensor(z, dtype=torch.float32, device=self.device).detach().requires_grad_(True)
+        lp, red = self.log_prob(simulator, zz)
+        (g,) = torch.autograd.grad(lp.sum(), zz)
+        return lp.detach(), red.detach(), g
+
+    def log_prior(self, z):
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        return self._flat.log_prob(self._flat.forward(z)) + self._flat.fldj_columns(z).sum(-1)
+
+    def init_centroids(self, bs):
+        return None
