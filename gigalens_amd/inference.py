@@ -66,11 +66,13 @@ def svi_step(mu: torch.Tensor, l_packed: torch.Tensor, log_prob_fn: Callable[[to
     """One ELBO evaluation on this rank's particle shard, all-reduced over ranks.
 
     Returns ``(loss, grad_mu, grad_l_packed)`` identical on every rank: the mean over ranks of the per-rank
-    means (== the mean over all particles, shards being equal-sized)."""
+    means (== the mean over all particles, shards being equal-sized).  ``l_packed`` of length ``d`` is the mean-field
+    surrogate (``MultivariateNormalDiag`` with ``Exp`` on the scales, tf/inference.py:75-83), of length
+    ``d (d + 1) / 2`` the full-rank one."""
     d = mu.numel()
     mu_ = mu.detach().clone().requires_grad_(True)
     lp_ = l_packed.detach().clone().requires_grad_(True)
-    L = tril_unpack(lp_, d)
+    L = torch.diag(torch.exp(lp_)) if l_packed.numel() == d and d > 1 else tril_unpack(lp_, d)
     eps = torch.randn((n_local, d), generator=generator, dtype=mu.dtype,
                       device=generator.device if generator is not None else mu.device).to(mu.device)
     z = mu_ + eps @ L.T
@@ -122,8 +124,9 @@ class ModellingSequence:
         self.last_red_chi2 = red
         return gdist.gather_rows(trial)
 
-    def SVI(self, optimizer: Adam, start_mean, n_vi=250, init_scales=1e-3, num_steps=500, seed=2, progress=None):
-        """tf/inference.py:47-93 (full-rank), sharded like jax/inference.py:91-144."""
+    def SVI(self, optimizer: Adam, start_mean, n_vi=250, init_scales=1e-3, num_steps=500, seed=2, full_rank=True,
+            progress=None):
+        """tf/inference.py:47-93 (full-rank or mean-field surrogate), sharded like jax/inference.py:91-144."""
         rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
         n_local = max(1, n_vi // world)
         pm = self.prob_model
@@ -133,7 +136,7 @@ class ModellingSequence:
         d = mu.numel()
         scale = (torch.eye(d, device=pm.device) * float(init_scales) if not torch.is_tensor(init_scales)
                  else init_scales.to(pm.device))
-        lp = tril_pack(scale)
+        lp = tril_pack(scale) if full_rank else torch.log(torch.diagonal(scale))
         gen = gdist.rank_generator(seed, rank, device="cpu")
         params = torch.cat([mu, lp])
         losses = []
@@ -143,14 +146,17 @@ class ModellingSequence:
             losses.append(float(loss))
             if progress is not None:
                 progress(step, loss)
-        self.q_mean, self.q_scale_tril = params[:d].clone(), tril_unpack(params[d:], d)
+        self.q_mean = params[:d].clone()
+        self.q_scale_tril = tril_unpack(params[d:], d) if full_rank else torch.diag(torch.exp(params[d:]))
         return (self.q_mean, self.q_scale_tril), losses
 
     def HMC(self, q_z, init_eps=0.3, init_l=3, n_hmc=50, num_burnin_steps=250, num_results=750,
-            max_leapfrog_steps=30, adapt_rate=0.05, seed=3, target_accept=0.75):
+            max_leapfrog_steps=30, adapt_rate=0.05, adapt_mode="dual", seed=3, target_accept=0.75):
         """tf/inference.py:95-182: preconditioned HMC (momentum precision = SVI covariance) with dual-averaging
         step-size adaptation during burn-in.  Chains are sharded over ranks with no collective
         (jax/inference.py:157-208); samples are gathered along the chain axis at the end."""
+        if adapt_mode not in ("dual", "simple"):
+            raise ValueError(f"Invalid adaptation mode {adapt_mode}, the options are 'simple' and 'dual'")  # :163-164
         rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
         n_local = max(1, n_hmc // world)
         pm = self.prob_model
@@ -192,7 +198,10 @@ class ModellingSequence:
             lp = torch.where(acc, lpn, lp)
             a = float(torch.exp(torch.clamp(log_acc, max=0.0)).mean())
             accept_hist.append(a)
-            if it < num_burnin_steps:  # Nesterov dual averaging (Hoffman & Gelman 2014, alg. 5)
+            if it < num_burnin_steps and adapt_mode == "simple":
+                # tfp.mcmc.SimpleStepSizeAdaptation (tf/inference.py:159-162): multiplicative nudge towards the target
+                log_eps += math.log1p(adapt_rate) if a > target_accept else -math.log1p(adapt_rate)
+            elif it < num_burnin_steps:  # Nesterov dual averaging (Hoffman & Gelman 2014, alg. 5)
                 m = it + 1
                 h_bar = (1 - 1 / (m + 10)) * h_bar + (target_accept - a) / (m + 10)
                 log_eps = mu_da - math.sqrt(m) / adapt_rate * h_bar

@@ -53,6 +53,13 @@ def test_vi_and_hmc(setup):
     samples, stats = seq.HMC((mean, L), n_hmc=3, init_eps=0.3, init_l=3, max_leapfrog_steps=5, num_burnin_steps=3,
                              num_results=5)
     assert len(samples) == 5 and samples.shape == (5, 3, 13) and torch.isfinite(samples).all()
+    # mean-field surrogate (full_rank=False) and the 'simple' step-size adaptation (tf/inference.py:47-48,159-164)
+    (mean_d, L_d), losses = seq.SVI(Adam(1e-3), start, n_vi=5, num_steps=4, full_rank=False)
+    assert torch.allclose(L_d, torch.diag(torch.diagonal(L_d))) and len(losses) == 4 and np.all(np.isfinite(losses))
+    samples, stats = seq.HMC((mean_d, L_d), n_hmc=2, num_burnin_steps=3, num_results=2, adapt_mode="simple")
+    assert samples.shape == (2, 2, 13)
+    with pytest.raises(ValueError):
+        seq.HMC((mean_d, L_d), adapt_mode="nope")
 
 
 def test_smc(setup):
