@@ -677,7 +677,8 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   }
   if (m->has_table) {
     std::vector<float> tab;
-    glh::build_shapelet_table(sh_nmax, tab, &m->shp_stride);
+    (void)sh_nmax;  // always the full n_max = 10 table: stride 12, two rows of a node pair = six aligned float4
+    glh::build_shapelet_table(GL_SHAPELETS_NMAX_CAP, tab, &m->shp_stride);
     ok = ok && up((void**)&m->d_shp_tab, tab.data(), tab.size() * sizeof(float));
   }
   m->has_post = grid->psf != nullptr || grid->supersample != 1;

@@ -100,7 +100,7 @@ GL_HD int kind_num_derived(int kind, int iparam) {
     case K_CORE_SERSIC: return 16;
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_ND + 2;
-    case K_SHAPELETS: return SHP_AMP + ((sh_layers(iparam) + 3) & ~3);
+    case K_SHAPELETS: return SHP_AMP + ((SH_MAXL + 3) & ~3);  // amplitude triangle zero-padded to n_max = 10
   }
   return -1;
 }
@@ -720,7 +720,7 @@ template <class R> GL_HD void shapelets_prep(const R* p, int n_max, R* d) {
   d[SHP_NMAX] = (R)n_max;
   int L = sh_layers(n_max);
   for (int i = 0; i < L; ++i) d[SHP_AMP + i] = p[3 + i];
-  for (int i = L; i < ((L + 3) & ~3); ++i) d[SHP_AMP + i] = (R)0;
+  for (int i = L; i < ((SH_MAXL + 3) & ~3); ++i) d[SHP_AMP + i] = (R)0;  // the separable kernels run the full triangle
 }
 
 // orthonormal Gauss-Hermite functions without the Gaussian: X_n = H_n / sqrt(2^n sqrt(pi) n!)

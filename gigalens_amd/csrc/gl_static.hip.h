@@ -13,7 +13,8 @@
 #pragma once
 #include <utility>
 
-#include "gl_kernels.hip.h"  // (brings gl_vec.hip.h: v2f and the V-generic profile maths)
+#include "gl_kernels.hip.h"
+#include "gl_shapelets.hip.h"
 
 namespace glk {
 
@@ -253,6 +254,12 @@ __global__ void __launch_bounds__(WG, WAVES) gl_static_kernel(MainArgs a) {
     }
     EplState<T> est[NL > 0 ? NL : 1];
     SerState sst[NLIGHT > 0 ? NLIGHT : 1][T];
+    constexpr bool HAS_SHP = [] {
+      for (int i = 0; i < NLL; ++i) if (LLK::kinds[i < NLL ? i : 0] == K_SHAPELETS) return true;
+      for (int i = 0; i < NS; ++i) if (SK::kinds[i < NS ? i : 0] == K_SHAPELETS) return true;
+      return false;
+    }();
+    ShpState<SH_CAP> hst[HAS_SHP ? NLIGHT : 1][HAS_SHP ? T : 1];
     // ---- ray-shoot ----
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
@@ -282,7 +289,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_static_kernel(MainArgs a) {
       for (int t = 0; t < T; ++t) {
         float px = src ? bx[t] : x[t], py = src ? by[t] : y[t];
         if constexpr (kind == K_SHAPELETS)
-          m[t] += shapelets_fwd<float, SH_CAP>(d, a.shp_tab, a.shp_stride, comps[NL + i].flags & 1u, px, py);
+          m[t] += shp_fwd_state<SH_CAP>(d, gder + comps[NL + i].d_off + SHP_AMP, a.shp_tab, comps[NL + i].flags & 1u, px, py,
+                                        hst[i][t]);
         else
           m[t] += sersic_fwd_state(d, px, py, sst[i][t]);
       }
@@ -337,8 +345,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_static_kernel(MainArgs a) {
         for (int t = 0; t < T; ++t) {
           float dgx = 0.f, dgy = 0.f;
           if constexpr (kind == K_SHAPELETS)
-            shapelets_vjp<float, SH_CAP>(d, a.shp_tab, a.shp_stride, comps[NL + i].flags & 1u, src ? bx[t] : x[t],
-                                         src ? by[t] : y[t], gm[t], accC + off, dgx, dgy);
+            shp_vjp_state<SH_CAP>(d, gder + comps[NL + i].d_off + SHP_AMP, comps[NL + i].flags & 1u, hst[i][t], gm[t],
+                                  accC + off, dgx, dgy);
           else
             sersic_vjp_state(d, sst[i][t], gm[t], accC + off, dgx, dgy);
           if (src) { gbx[t] += dgx; gby[t] += dgy; }
