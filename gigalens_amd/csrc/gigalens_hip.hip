@@ -188,7 +188,7 @@ using C_Sersic = KindList<K_SERSIC>;
 using C_Shapelets = KindList<K_SHAPELETS>;
 
 enum StaticId { ST_NONE = 0, ST_EPLSHEAR_SERSIC, ST_EPLSHEAR_SERSIC_SERSIC, ST_SIE_SERSIC, ST_EPLSHEAR_SHAPELETS,
-                ST_SIESHEAR_SERSIC_SERSIC };
+                ST_SIESHEAR_SERSIC_SERSIC, ST_EPLSHEAR_SERSIC_SHAPELETS /* shapelets-demo.ipynb: lens light + shapelet source */ };
 
 int match_static(const gl_model* m) {
   auto fold = [](int k) { return k == K_SERSIC_ELLIPSE ? (int)K_SERSIC : k; };
@@ -202,6 +202,7 @@ int match_static(const gl_model* m) {
   if (L == eplshear && C == sersic && S == sersic) return ST_EPLSHEAR_SERSIC_SERSIC;
   if (L == sie && C == none && S == sersic) return ST_SIE_SERSIC;
   if (L == eplshear && C == none && S == shp) return ST_EPLSHEAR_SHAPELETS;
+  if (L == eplshear && C == sersic && S == shp) return ST_EPLSHEAR_SERSIC_SHAPELETS;
   if (L == sieshear && C == sersic && S == sersic) return ST_SIESHEAR_SERSIC_SERSIC;
   return ST_NONE;
 }
@@ -246,6 +247,10 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
       return true;
     case ST_EPLSHEAR_SHAPELETS:
       if (T == 2) GL_LAUNCH(2, 2, L_EplShear, C_None, C_Shapelets); else if (T == 1) GL_LAUNCH(1, 2, L_EplShear, C_None, C_Shapelets);
+      else return false;
+      return true;
+    case ST_EPLSHEAR_SERSIC_SHAPELETS:
+      if (T == 2) GL_LAUNCH(2, 2, L_EplShear, C_Sersic, C_Shapelets); else if (T == 1) GL_LAUNCH(1, 2, L_EplShear, C_Sersic, C_Shapelets);
       else return false;
       return true;
   }

@@ -17,6 +17,7 @@
 #include "gl_vec.hip.h"
 #include "gl_members.hip.h"
 #include "gl_series.h"
+#include "gl_shapelets.hip.h"
 
 namespace glk {
 using namespace glp;
@@ -662,9 +663,12 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
       if (cd.kind == K_SHAPELETS) {
         if (SHP) {
           const bool interp = cd.flags & 1u;
+          const float* __restrict__ gamp = a.derived + (size_t)b * a.D + cd.d_off + SHP_AMP;
 #pragma unroll 1
-          for (int t = 0; t < T; ++t)
-            m[t] += shapelets_fwd<float, SH_CAP>(d, a.shp_tab, a.shp_stride, interp, src ? bx[t] : x[t], src ? by[t] : y[t]);
+          for (int t = 0; t < T; ++t) {
+            ShpState<SH_CAP> hs;
+            m[t] += shp_fwd_state<SH_CAP>(d, gamp, a.shp_tab, interp, src ? bx[t] : x[t], src ? by[t] : y[t], hs);
+          }
         }
       } else if (cd.kind == K_CORE_SERSIC) {
         if constexpr (DP) {
@@ -732,11 +736,13 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             float acc[SHPA_AMP + SH_MAXL];
 #pragma unroll
             for (int k = 0; k < SHPA_AMP + SH_MAXL; ++k) acc[k] = 0.f;
+            const float* __restrict__ gamp = a.derived + (size_t)b * a.D + cd.d_off + SHP_AMP;
 #pragma unroll 1
             for (int t = 0; t < T; ++t) {
               float dgx = 0.f, dgy = 0.f;
-              shapelets_vjp<float, SH_CAP>(d, a.shp_tab, a.shp_stride, interp, src ? bx[t] : x[t],
-                                           src ? by[t] : y[t], gm[t], acc, dgx, dgy);
+              ShpState<SH_CAP> hs;  // bases re-evaluated (the interpreter keeps no per-component state), contractions separable
+              (void)shp_fwd_state<SH_CAP>(d, gamp, a.shp_tab, interp, src ? bx[t] : x[t], src ? by[t] : y[t], hs);
+              shp_vjp_state<SH_CAP>(d, gamp, interp, hs, gm[t], acc, dgx, dgy);
               if (src) { gbx[t] += dgx; gby[t] += dgy; }
             }
             wave_acc<SHPA_AMP + SH_MAXL>(acc, ac, cd.a_off, cd.n_acc);

@@ -99,6 +99,24 @@ def make(name: str, num_pix: Optional[int] = None, batch: Optional[int] = None, 
             source_light=tfd.JointDistributionSequential([_sersic_src_prior(uniform_center=4.0) for _ in range(n_sources)])))
         return Workload("C4", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 256), batch or 512,
                         description=f"cluster: {n_halos} NFW halos + {n_sources} Sersic sources")
+    if name == "C3D":  # the reference's shapelets-demo.ipynb model: EPL+shear, SersicEllipse lens light, Shapelets source
+        phys = PhysicalModel([EPL(), Shear()], [SersicEllipse()], [Shapelets(n_max, interpolate=interpolate)])
+        L = (n_max + 1) * (n_max + 2) // 2
+        names = phys.source_light[0]._amp_names
+        src = dict(beta=tfd.LogNormal(math.log(0.1), 0.15), center_x=tfd.Normal(0, 0.01), center_y=tfd.Normal(0, 0.01))
+        src.update({nm: tfd.Normal(0, 500.0 / math.sqrt(i + 1)) for i, nm in enumerate(names)})
+        ll = tfd.JointDistributionNamed(dict(
+            R_sersic=tfd.LogNormal(math.log(1.0), 0.15), n_sersic=tfd.Uniform(2, 6), e1=tfd.TruncatedNormal(0, 0.1, -0.3, 0.3),
+            e2=tfd.TruncatedNormal(0, 0.1, -0.3, 0.3), center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05),
+            Ie=tfd.LogNormal(math.log(500.0), 0.3)))
+        prior = tfd.JointDistributionNamed(dict(
+            lens_mass=tfd.JointDistributionSequential([_epl_prior(), _shear_prior()]),
+            lens_light=tfd.JointDistributionSequential([ll]),
+            source_light=tfd.JointDistributionSequential([tfd.JointDistributionNamed(src)])))
+        assert L == len(names)
+        return Workload("C3D", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 128), batch or 1024,
+                        use_error_map=True, description=f"shapelets-demo model: EPL+shear, SersicEllipse lens light, "
+                        f"Shapelets n_max={n_max} source")
     if name == "C3L":  # C3 with the shapelet amplitudes solved by least squares (shapelets-demo cell 7)
         phys = PhysicalModel([EPL(), Shear()], [], [Shapelets(n_max, use_lstsq=True, interpolate=interpolate)])
         src = tfd.JointDistributionNamed(dict(beta=tfd.LogNormal(math.log(0.1), 0.15), center_x=tfd.Normal(0, 0.01),

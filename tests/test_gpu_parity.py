@@ -136,6 +136,8 @@ CASES = [
     ("C3", dict(num_pix=20, batch=3, interpolate=True, n_max=4)),
     ("C4", dict(num_pix=40, batch=4, n_halos=3, n_sources=4)),
     ("C4", dict(num_pix=32, batch=2)),
+    ("C3D", dict(num_pix=30, batch=3, interpolate=True, n_max=8)),   # shapelets-demo.ipynb model
+    ("C3D", dict(num_pix=30, batch=3, interpolate=False, n_max=5)),
 ]
 
 
@@ -248,7 +250,8 @@ def test_fused_log_prob_matches_unfused(gl, name, kw):
 
 @pytest.mark.parametrize("name,kw", [("C1", dict(num_pix=40, batch=9)), ("C2", dict(num_pix=50, batch=17)),
                                      ("C3", dict(num_pix=32, batch=5, interpolate=False)),
-                                     ("C3", dict(num_pix=32, batch=5, interpolate=True, n_max=7)), ("DEMO", dict())])
+                                     ("C3", dict(num_pix=32, batch=5, interpolate=True, n_max=7)),
+                                     ("C3D", dict(num_pix=28, batch=4, interpolate=True, n_max=8)), ("DEMO", dict())])
 @pytest.mark.parametrize("tile", ["1", "2", "4", "pair"])
 def test_specialised_kernels_match_interpreter(gl, name, kw, tile, monkeypatch):
     """The compile-time-specialised kernels (gl_static.hip.h) and the generic interpreter kernel evaluate the

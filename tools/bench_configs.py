@@ -51,6 +51,7 @@ def main():
            run("C2 EPL+Shear|Sersic 128x128 B=1024", workloads.make("C2")),
            run("C3 shapelets n_max=10 (table) 128x128 B=1024", workloads.make("C3", interpolate=True)),
            run("C3 shapelets n_max=10 (direct) 128x128 B=1024", workloads.make("C3", interpolate=False)),
+           run("C3D shapelets-demo model (lens light + shapelets n_max=8, table) 128x128 B=1024", workloads.make("C3D", n_max=8)),
            run("C4 8 NFW + 20 Sersic 256x256 B=512", workloads.make("C4")),
            run("C6 dPIE halo + 200 scaled dPIE galaxies + 20 Sersic 256x256 B=128", workloads.make("C6")),
            run("C6S same, galaxies through the order-3 series expansion, B=128", workloads.make("C6S")),
