@@ -82,7 +82,7 @@ struct gl_model {
   int* d_fam = nullptr;    // [F+1]
   bool has_epl = false;
   int epl_comp = -1;     // the model's only EPL component, or -1 (none / several)
-  bool has_dpie = false;  // any dPIE-family lens or galaxy catalogue
+  int fam = 0;  // family level of the interpreter variant (gl_main_kernel FAM): 1 dPIE family / catalogues / series, 2 gl_extra.h
   bool use_order = true;
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -263,22 +263,20 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
   dim3 grid(n_chunks, B), block(WG);
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
   if (m->timing) GL_HIP(hipEventRecord(m->ev0, stream));
+#define GL_MAIN(TT, S_, F_) hipLaunchKernelGGL((gl_main_kernel<MODE, TT, S_, F_>), grid, block, shmem, stream, a)
+#define GL_MAIN_FAM(TT, S_) \
+  do { if (m->fam == 2) GL_MAIN(TT, S_, 2); else if (m->fam == 1) GL_MAIN(TT, S_, 1); else GL_MAIN(TT, S_, 0); } while (0)
   if constexpr (MODE == IMG_BASIS) {  // basis stack of lstsq_simulate: interpreter kernel, one tile shape
-    if (m->has_shapelets && m->has_dpie) hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true, true>), grid, block, shmem, stream, a);
-    else if (m->has_shapelets) hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true, false>), grid, block, shmem, stream, a);
-    else if (m->has_dpie) hipLaunchKernelGGL((gl_main_kernel<MODE, 2, false, true>), grid, block, shmem, stream, a);
-    else hipLaunchKernelGGL((gl_main_kernel<MODE, 2, false, false>), grid, block, shmem, stream, a);
+    if (m->has_shapelets) GL_MAIN_FAM(2, true); else GL_MAIN_FAM(2, false);
   } else if (m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
     // specialised kernel launched
   } else {
     const int Tg = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
-#define GL_MAIN(TT, S_, D_) hipLaunchKernelGGL((gl_main_kernel<MODE, TT, S_, D_>), grid, block, shmem, stream, a)
-    if (m->has_shapelets && m->has_dpie) { if (Tg == 4) GL_MAIN(4, true, true); else GL_MAIN(2, true, true); }
-    else if (m->has_shapelets) { if (Tg == 4) GL_MAIN(4, true, false); else GL_MAIN(2, true, false); }
-    else if (m->has_dpie) { if (Tg == 4) GL_MAIN(4, false, true); else GL_MAIN(2, false, true); }
-    else { if (Tg == 4) GL_MAIN(4, false, false); else GL_MAIN(2, false, false); }
-#undef GL_MAIN
+    if (m->has_shapelets) { if (Tg == 4) GL_MAIN_FAM(4, true); else GL_MAIN_FAM(2, true); }
+    else { if (Tg == 4) GL_MAIN_FAM(4, false); else GL_MAIN_FAM(2, false); }
   }
+#undef GL_MAIN_FAM
+#undef GL_MAIN
   if (m->timing) GL_HIP(hipEventRecord(m->ev1, stream));
   GL_HIP(hipGetLastError());
   return GL_OK;
@@ -591,7 +589,8 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
       if (iparam > 1000) { delete m; return fail(GL_EINVAL, "EPL niter %d too large", iparam); }
     }
     if (c.kind == GL_EPL) { m->epl_comp = m->has_epl ? -2 : i; m->has_epl = true; }
-    if ((c.kind >= GL_DPIS && c.kind <= GL_TNFW) || c.kind == GL_CORE_SERSIC) m->has_dpie = true;  // extended families
+    if (c.kind >= GL_DPIS && c.kind <= GL_SERIES) m->fam = std::max(m->fam, 1);
+    if (c.kind == GL_NFW_ELLIPSE || c.kind == GL_TNFW || c.kind == GL_CORE_SERSIC) m->fam = 2;
     if (c.kind == GL_SERIES && (iparam < 0 || iparam > SERIES_MAX_ORDER)) {
       delete m;
       return fail(GL_EINVAL, "component %d: series order %d outside [0, %d]", i, iparam, SERIES_MAX_ORDER);
@@ -653,7 +652,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   if (!m->tile_grad) m->tile_grad = m->static_id ? 1 : 2;  // measured: T=1 wins once the VJP state lives in registers
   if (!m->static_id) {  // the interpreter kernel is built for T = 2 and 4
     const bool env_tile = env_int("GIGALENS_HIP_TILE", 0) != 0;
-    if (!env_tile && !m->has_epl && !m->has_shapelets && !m->has_dpie) m->tile = m->tile_grad = 4;  // cheap profiles: amortise the per-tile accumulation
+    if (!env_tile && !m->has_epl && !m->has_shapelets && !m->fam) m->tile = m->tile_grad = 4;  // cheap profiles: amortise the per-tile accumulation
     if (m->tile == 1) m->tile = 2;
     if (m->tile_grad == 1) m->tile_grad = 2;
   }

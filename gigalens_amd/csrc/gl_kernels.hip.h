@@ -491,10 +491,13 @@ template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const
 }
 
 // ---- the main kernel ----------------------------------------------------------------------------
-// SHP / DP: the model contains shapelets / dPIE-family lenses -- their code (and register budget) is compiled only
-// into the variants that need it, so the common compositions keep their occupancy.
-template <int MODE, int T, bool SHP, bool DP>
-__global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainArgs a) {
+// SHP / FAM: the model contains shapelets / lenses of the extended families -- their code (and register budget) is
+// compiled only into the variants that need it, so the common compositions keep their occupancy.
+//   FAM 0: EPL, SIE, NFW, Shear, SIS | Sersic[Ellipse]     FAM 1: + dPIS / dPIE / dPIEP, catalogues, series lenses
+//   FAM 2: + NFW_ELLIPSE, TNFW, CoreSersic (gl_extra.h; the fp64 core of TNFW alone costs ~80 VGPRs)
+template <int MODE, int T, bool SHP, int FAM>
+__global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainArgs a) {
+  constexpr bool DP = FAM >= 1, XF = FAM >= 2;
   extern __shared__ float smem[];
   float* s_d = smem;
   float* s_acc = smem + ((a.D + 3) & ~3);
@@ -579,13 +582,13 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
           }
           break;
         case K_NFW_ELLIPSE:
-          if constexpr (DP) {
+          if constexpr (XF) {
 #pragma unroll
             for (int t = 0; t < T; ++t) { float ax, ay; nfw_ell_fwd<float>(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
           }
           break;
         case K_TNFW:
-          if constexpr (DP) {
+          if constexpr (XF) {
 #pragma unroll
             for (int t = 0; t < T; ++t) { float ax, ay; tnfw_fwd<float>(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
           }
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
           for (int t = 0; t < T; ++t) {
             const float px_ = src ? bx[t] : x[t], py_ = src ? by[t] : y[t];
             float v;
-            if (DP && cd.kind == K_CORE_SERSIC) v = core_sersic_fwd<float>(d, px_, py_);
+            if (XF && cd.kind == K_CORE_SERSIC) v = core_sersic_fwd<float>(d, px_, py_);
             else v = sersic_fwd(d, px_, py_);
             if (valid[t]) row[pidx[t]] = isnan_(v) ? 0.f : v;
           }
@@ -671,7 +674,7 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
           }
         }
       } else if (cd.kind == K_CORE_SERSIC) {
-        if constexpr (DP) {
+        if constexpr (XF) {
 #pragma unroll
           for (int t = 0; t < T; ++t) m[t] += core_sersic_fwd<float>(d, src ? bx[t] : x[t], src ? by[t] : y[t]);
         }
@@ -748,7 +751,7 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             wave_acc<SHPA_AMP + SH_MAXL>(acc, ac, cd.a_off, cd.n_acc);
           }
         } else if (cd.kind == K_CORE_SERSIC) {
-          if constexpr (DP) {
+          if constexpr (XF) {
             float acc[CSR_NACC];
 #pragma unroll
             for (int k = 0; k < CSR_NACC; ++k) acc[k] = 0.f;
@@ -861,7 +864,7 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             }
             wave_acc<DP_NACC>(acc, ac, cd.a_off);
           } break;
-          case K_NFW_ELLIPSE: if constexpr (DP) {
+          case K_NFW_ELLIPSE: if constexpr (XF) {
             float acc[NFE_NACC];
 #pragma unroll
             for (int k = 0; k < NFE_NACC; ++k) acc[k] = 0.f;
@@ -869,7 +872,7 @@ __global__ void __launch_bounds__(WG, (SHP || DP) ? 2 : 4) gl_main_kernel(MainAr
             for (int t = 0; t < T; ++t) nfw_ell_vjp<float>(d, x[t], y[t], gbx[t], gby[t], acc);
             wave_acc<NFE_NACC>(acc, ac, cd.a_off);
           } break;
-          case K_TNFW: if constexpr (DP) {
+          case K_TNFW: if constexpr (XF) {
             float acc[TNF_NACC];
 #pragma unroll
             for (int k = 0; k < TNF_NACC; ++k) acc[k] = 0.f;
