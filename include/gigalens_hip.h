@@ -2,9 +2,12 @@
  *
  * Plain pointers and sizes only: no torch / C++ types cross this boundary.
  * Every device buffer is owned by the caller (PyTorch in this repo); the
- * library allocates device memory only inside gl_model_create (the immutable
- * model descriptor, grid and PSF) and never per call, so every entry point is
- * hipGraph-capturable.  All arithmetic is fp32, as in the reference
+ * library allocates device memory only inside gl_model_create and the
+ * gl_model_set_* set-up calls (model descriptor, grid, PSF, prior table, image
+ * positions, galaxy catalogues, series fields) and never per compute call, so
+ * every compute entry point is hipGraph-capturable.  All arithmetic is fp32, as in
+ * the reference (two documented exceptions run in fp64: the one-off series
+ * precompute and the core of the TNFW bracket)
  * (every constant there is tf.float32: tf/simulator.py:27-32,46-51;
  * tf/model.py:63-68,301-306).
  *
@@ -90,7 +93,8 @@ typedef struct gl_grid {
   int32_t psf_h, psf_w;
 } gl_grid;
 
-typedef struct gl_model gl_model; /* opaque, immutable after create; safe to share between host threads */
+typedef struct gl_model gl_model; /* opaque; immutable once set up (create + the gl_model_set_* calls, which are host-side
+                                     set-up and must not race with compute calls); then safe to share between host threads */
 
 /* Build the model descriptor for PhysicalModel(lenses, lens_light, source_light)
  * (model.py:24-44, tf/model.py:290-306) on LensSimulator's grid.  `comps` lists the
