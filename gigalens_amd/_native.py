@@ -65,6 +65,10 @@ SYMBOLS = {
     "gl_model_set_series": (c_int, [c_void_p, c_int, c_float, c_void_p]),
     "gl_series_eval": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                c_void_p]),
+    "gl_series_precompute_hessian": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, POINTER(c_float), c_int, c_int,
+                                             c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "gl_series_hessian_eval": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "gl_model_set_series_hessian": (c_int, [c_void_p, c_int, c_void_p]),
     "gl_lens_maps": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "gl_model_num_linear": (c_int, [c_void_p]),
     "gl_model_linear_column": (c_int, [c_void_p, c_int]),
@@ -177,18 +181,39 @@ def scaled_eval(profile, x, y, scales):
     return out0.reshape(out_shape), out1.reshape(out_shape)
 
 
-def series_precompute(series):
-    """MassSeries.set_deriv (series_profile.py:61-62) through gl_series_precompute: device [2, order+1, n_points]."""
+def series_precompute(series, hessian=False):
+    """MassSeries.set_deriv / set_hessian (series_profile.py:61-65) through gl_series_precompute[_hessian]: device
+    ``[2, order+1, n_points]`` (alpha_x, alpha_y) or ``[3, order+1, n_points]`` (f_xx, f_xy, f_yy)."""
     dev = device()
     base_kind, cols, table, scales = series._series_inputs()
     x = torch.as_tensor(series.x, dtype=torch.float32, device=dev).reshape(-1).contiguous()
     y = torch.as_tensor(series.y, dtype=torch.float32, device=dev).reshape(-1).contiguous()
     tab = torch.from_numpy(np.ascontiguousarray(table, dtype=np.float32)).to(dev)
     sc = (c_float * len(scales))(*[float(v) for v in scales])
-    out = torch.empty((2, series.order + 1, x.numel()), dtype=torch.float32, device=dev)
-    _check(lib().gl_series_precompute(int(base_kind), tab.shape[0], (c_int32 * 3)(*cols), _ptr(tab), sc, len(scales),
-                                      series.order, _ptr(x), _ptr(y), x.numel(), _ptr(out), _stream()))
+    out = torch.empty((3 if hessian else 2, series.order + 1, x.numel()), dtype=torch.float32, device=dev)
+    fn = lib().gl_series_precompute_hessian if hessian else lib().gl_series_precompute
+    _check(fn(int(base_kind), tab.shape[0], (c_int32 * 3)(*cols), _ptr(tab), sc, len(scales), series.order, _ptr(x),
+              _ptr(y), x.numel(), _ptr(out), _stream()))
     return out
+
+
+def series_hessian_eval(series, amplitude, var):
+    """MassSeries.hessian (series_profile.py:83-89): ``(f_xx, f_xy, f_xy, f_yy)``, field shape + trailing batch axis."""
+    dev = device()
+    a = torch.as_tensor(amplitude, dtype=torch.float32, device=dev).reshape(-1)
+    v = torch.as_tensor(var, dtype=torch.float32, device=dev).reshape(-1)
+    B = max(a.numel(), v.numel())
+    a, v = a.expand(B).contiguous(), v.expand(B).contiguous()
+    n = series._hcoefs.shape[-1]
+    out = torch.empty((3, n, B), dtype=torch.float32, device=dev)
+    _check(lib().gl_series_hessian_eval(_ptr(series._hcoefs), series.order, n, B, _ptr(a), _ptr(v),
+                                        float(series.series_var_0), _ptr(out), _stream()))
+    shape = tuple(torch.as_tensor(series.x).shape)
+    if shape and shape[-1] == B and len(shape) > 1:
+        shape = shape[:-1]
+        out = out.reshape(3, -1, B, B).diagonal(dim1=2, dim2=3)
+    out = out.reshape((3,) + shape + (B,))
+    return out[0], out[1], out[1], out[2]
 
 
 def series_eval(series, amplitude, var):
@@ -318,6 +343,10 @@ class Model:
         """gl_lens_maps: ``x, y`` broadcastable to ``(..., B)``; returns ``(6, ...)`` = beta_x, beta_y, f_xx, f_xy, f_yx, f_yy."""
         params = self._params(params)
         B = params.shape[0]
+        if x is None and y is None:  # the model's own grid (the only form series-expansion lenses accept)
+            out = torch.empty((6, self.N, B), dtype=torch.float32, device=self.device)
+            _check(lib().gl_lens_maps(self._h, _ptr(params), B, None, None, self.N, 0, _ptr(out), _stream()))
+            return out
         x = torch.as_tensor(x, dtype=torch.float32, device=self.device)
         y = torch.as_tensor(y, dtype=torch.float32, device=self.device)
         shape = torch.broadcast_shapes(x.shape, y.shape, (B,))
@@ -353,6 +382,14 @@ class Model:
             raise NativeLibraryError(f"series field has {coeffs.shape[-1]} points, the model grid {self.N}")
         with torch.cuda.device(self.device):
             _check(lib().gl_model_set_series(self._h, int(component), float(r0), _ptr(coeffs.contiguous())))
+
+    def set_series_hessian(self, component, coeffs):
+        """Attach the Hessian field of a GL_SERIES lens (gl_model_set_series_hessian)."""
+        _require_cuda(coeffs, "series Hessian coefficients")
+        if coeffs.shape[-1] != self.N or coeffs.shape[0] != 3:
+            raise NativeLibraryError(f"series Hessian field is {tuple(coeffs.shape)}, expected (3, order+1, {self.N})")
+        with torch.cuda.device(self.device):
+            _check(lib().gl_model_set_series_hessian(self._h, int(component), _ptr(coeffs.contiguous())))
 
     def set_prior(self, columns, const_row):
         """columns: list of (param_col, bijector, prior, a, b, lo, hi, log_norm); const_row: [P] floats."""

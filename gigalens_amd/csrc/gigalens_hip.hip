@@ -619,7 +619,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     if (c.kind == GL_SCALED) cd.iparam = -1;  // catalogue slot, set by gl_model_set_catalogue
     if (c.kind == GL_SERIES) {
       cd.flags = (unsigned)m->n_series++;
-      m->series.push_back(SeriesDev{nullptr, 0.f, iparam});
+      m->series.push_back(SeriesDev{nullptr, nullptr, 0.f, iparam});
       m->series_comp.push_back(i);
     }
     cd.lin_off = (int)m->lin_cols.size();
@@ -747,8 +747,10 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_src) (void)hipFree(m->d_src);
   if (m->d_const) (void)hipFree(m->d_const);
   if (m->d_lin_cols) (void)hipFree(m->d_lin_cols);
-  for (auto& sv : m->series)
+  for (auto& sv : m->series) {
     if (sv.coef) (void)hipFree((void*)sv.coef);
+    if (sv.hcoef) (void)hipFree((void*)sv.hcoef);
+  }
   if (m->d_series) (void)hipFree(m->d_series);
   if (m->d_cats) (void)hipFree(m->d_cats);
   if (m->d_gal_table) (void)hipFree(m->d_gal_table);
@@ -941,9 +943,9 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   return GL_OK;
 }
 
-int gl_series_precompute(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev,
-                         const float* scales, int n_scales, int order, const float* x_dev, const float* y_dev,
-                         int64_t n_pts, float* coeffs_dev, void* hip_stream) {
+static int series_precompute(bool hessian, int base_kind, int n_galaxies, const int32_t scale_col[3],
+                             const float* table_dev, const float* scales, int n_scales, int order, const float* x_dev,
+                             const float* y_dev, int64_t n_pts, float* coeffs_dev, void* hip_stream) {
   if (!scale_col || !table_dev || !scales || !x_dev || !y_dev || !coeffs_dev) return fail(GL_EINVAL, "null argument");
   if (base_kind != GL_DPIS && base_kind != GL_DPIE && base_kind != GL_DPIEP)
     return fail(GL_EUNSUPPORTED, "series expansion over profile kind %d is not built (dPIS, dPIE, dPIEP are)", base_kind);
@@ -957,13 +959,60 @@ int gl_series_precompute(int base_kind, int n_galaxies, const int32_t scale_col[
   for (int k = 0; k < n_scales; ++k) s[k] = scales[k];
   dim3 grid((unsigned)((n_pts + 63) / 64)), block(64);
   hipStream_t stream = (hipStream_t)hip_stream;
-  if (order <= 3)
-    hipLaunchKernelGGL((gl_series_precompute_kernel<3>), grid, block, 0, stream, sd, table_dev, s[0], s[1], s[2], order,
-                       x_dev, y_dev, (long long)n_pts, coeffs_dev);
-  else
-    hipLaunchKernelGGL((gl_series_precompute_kernel<5>), grid, block, 0, stream, sd, table_dev, s[0], s[1], s[2], order,
-                       x_dev, y_dev, (long long)n_pts, coeffs_dev);
+#define GL_SERIES_LAUNCH(KERNEL, NN) \
+  hipLaunchKernelGGL((KERNEL<NN>), grid, block, 0, stream, sd, table_dev, s[0], s[1], s[2], order, x_dev, y_dev, \
+                     (long long)n_pts, coeffs_dev)
+  if (hessian) {
+    if (order <= 3) GL_SERIES_LAUNCH(gl_series_hessian_precompute_kernel, 3);
+    else GL_SERIES_LAUNCH(gl_series_hessian_precompute_kernel, 5);
+  } else {
+    if (order <= 3) GL_SERIES_LAUNCH(gl_series_precompute_kernel, 3);
+    else GL_SERIES_LAUNCH(gl_series_precompute_kernel, 5);
+  }
+#undef GL_SERIES_LAUNCH
   GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+int gl_series_precompute(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev,
+                         const float* scales, int n_scales, int order, const float* x_dev, const float* y_dev,
+                         int64_t n_pts, float* coeffs_dev, void* hip_stream) {
+  return series_precompute(false, base_kind, n_galaxies, scale_col, table_dev, scales, n_scales, order, x_dev, y_dev,
+                           n_pts, coeffs_dev, hip_stream);
+}
+
+int gl_series_precompute_hessian(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev,
+                                 const float* scales, int n_scales, int order, const float* x_dev, const float* y_dev,
+                                 int64_t n_pts, float* coeffs_dev, void* hip_stream) {
+  return series_precompute(true, base_kind, n_galaxies, scale_col, table_dev, scales, n_scales, order, x_dev, y_dev,
+                           n_pts, coeffs_dev, hip_stream);
+}
+
+int gl_series_hessian_eval(const float* coeffs_dev, int order, int64_t n_pts, int B, const float* theta_E,
+                           const float* r_cut, float r0, float* out, void* hip_stream) {
+  if (!coeffs_dev || !theta_E || !r_cut || !out) return fail(GL_EINVAL, "null argument");
+  if (order < 0 || order > SERIES_MAX_ORDER || n_pts <= 0 || B <= 0) return fail(GL_EINVAL, "bad sizes");
+  const long long total = (long long)n_pts * B;
+  hipLaunchKernelGGL(gl_series_fields_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)hip_stream, coeffs_dev, 3, order, (long long)n_pts, B, theta_E, r_cut, r0, out);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+int gl_model_set_series_hessian(gl_model* m, int component, const float* coeffs_dev) {
+  if (!m || !coeffs_dev) return fail(GL_EINVAL, "null argument");
+  if (component < 0 || component >= m->n_lens || m->comps[component].kind != K_SERIES)
+    return fail(GL_EINVAL, "component %d is not a GL_SERIES lens", component);
+  SeriesDev& sv = m->series[(int)m->comps[component].flags];
+  if (!sv.coef) return fail(GL_EINVAL, "gl_model_set_series must be called on component %d first", component);
+  const size_t bytes = sizeof(float) * 3 * (size_t)(sv.order + 1) * m->N;
+  if (!sv.hcoef) {
+    float* p = nullptr;
+    GL_HIP(hipMalloc((void**)&p, bytes));
+    sv.hcoef = p;
+  }
+  GL_HIP(hipMemcpy((void*)sv.hcoef, coeffs_dev, bytes, hipMemcpyDeviceToDevice));
+  GL_HIP(hipMemcpy(m->d_series, m->series.data(), sizeof(SeriesDev) * m->series.size(), hipMemcpyHostToDevice));
   return GL_OK;
 }
 
@@ -1148,10 +1197,20 @@ int gl_profile_hessian(const gl_component* comp, const float* x, const float* y,
 
 int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, const float* y, int64_t n_pts,
                  int xy_batched, float* out, void* hip_stream) {
-  if (!m || !params || !x || !y || !out) return fail(GL_EINVAL, "null argument");
+  if (!m || !params || !out) return fail(GL_EINVAL, "null argument");
+  if ((x == nullptr) != (y == nullptr)) return fail(GL_EINVAL, "x and y must both be given or both be null");
   if (B <= 0 || n_pts <= 0) return fail(GL_EINVAL, "B and n_pts must be positive");
   if ((int)m->cats.size() != m->n_scaled) return fail(GL_EINVAL, "GL_SCALED component without a catalogue");
-  if (m->n_series) return fail(GL_EUNSUPPORTED, "a series-expansion lens lives on the pixel grid only (series_profile.py:76-81)");
+  if (!x) {
+    if (n_pts != m->N || xy_batched) return fail(GL_EINVAL, "the model grid has %d points and is not batched", m->N);
+    x = m->d_gx;
+    y = m->d_gy;
+    for (const SeriesDev& sv : m->series)
+      if (!sv.coef || !sv.hcoef)
+        return fail(GL_EINVAL, "GL_SERIES lens without its deflection / Hessian field (gl_model_set_series, gl_model_set_series_hessian)");
+  } else if (m->n_series) {
+    return fail(GL_EUNSUPPORTED, "a series-expansion lens lives on the model grid only (series_profile.py:76-89): pass x = y = NULL");
+  }
   PosArgs a{};
   a.comps = m->d_comps;
   a.n_lens = m->n_lens;
@@ -1161,6 +1220,7 @@ int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, 
   a.cats = m->d_cats;
   a.gal_table = m->d_gal_table;
   a.gal_static = m->d_gal_static;
+  a.series = m->d_series;
   const long long total = (long long)n_pts * B;
   hipLaunchKernelGGL(gl_lens_maps_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, a,
                      x, y, (long long)n_pts, xy_batched, out);

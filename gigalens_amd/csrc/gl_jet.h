@@ -97,6 +97,12 @@ GLJ_T Jet<T, N> p_atan2(const Jet<T, N>& y, const Jet<T, N>& x) { return j_atan2
 GLJ_T Jet<T, N> fabs_(const Jet<T, N>& a) { return a.c[0] < T(0) ? -a : a; }
 GLJ_T Jet<T, N> fmin_(const Jet<T, N>& a, const Jet<T, N>& b) { return a < b ? a : b; }
 GLJ_T Jet<T, N> fmax_(const Jet<T, N>& a, const Jet<T, N>& b) { return a > b ? a : b; }
+// leaf names of gl_dual.h, so that Dual<Jet<F, N>, 2> (space derivatives of a series in r_cut: the Hessian half of
+// the accelerator, series_profile.py:64-65) instantiates the same profile templates
+GLJ_T T val(const Jet<T, N>& a) { return a.c[0]; }
+GLJ_T Jet<T, N> l_sqrt(const Jet<T, N>& a) { return j_sqrt(a); }
+GLJ_T Jet<T, N> l_log(const Jet<T, N>& a) { return j_log(a); }
+GLJ_T Jet<T, N> l_atan2(const Jet<T, N>& y, const Jet<T, N>& x) { return j_atan2(y, x); }
 #undef GLJ_T
 
 }  // namespace glj

@@ -44,7 +44,8 @@ struct CatDev {
 
 // coefficient field of one K_SERIES lens (gl_model_set_series): coef[2][order+1][N]
 struct SeriesDev {
-  const float* coef;
+  const float* coef;   // [2][order+1][N]  deflection series
+  const float* hcoef;  // [3][order+1][N]  Hessian series (f_xx, f_xy, f_yy) or null: lens maps only
   float r0;
   int order;
 };
@@ -1111,6 +1112,44 @@ __global__ void __launch_bounds__(64) gl_series_precompute_kernel(ScaledDesc sd,
   for (int n = 0; n <= order; ++n) {
     coeffs[(size_t)n * n_pts + i] = (float)cx[n];
     coeffs[(size_t)(order + 1 + n) * n_pts + i] = (float)cy[n];
+  }
+}
+
+// Taylor coefficients of the population Hessian: coeffs[3][order+1][n_pts] = f_xx, f_xy, f_yy (one-off, fp64 jets)
+template <int N>
+__global__ void __launch_bounds__(64) gl_series_hessian_precompute_kernel(ScaledDesc sd, const float* __restrict__ table,
+                                                                         float s0, float s1, float s2, int order,
+                                                                         const float* __restrict__ x,
+                                                                         const float* __restrict__ y, long long n_pts,
+                                                                         float* __restrict__ coeffs) {
+  const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_pts) return;
+  const double scales[3] = {(double)s0, (double)s1, (double)s2};
+  double hxx[N + 1], hxy[N + 1], hyy[N + 1];
+  series_point_hessian<N, double>(sd, table, scales, (double)x[i], (double)y[i], hxx, hxy, hyy);
+  for (int n = 0; n <= order; ++n) {
+    coeffs[(size_t)n * n_pts + i] = (float)hxx[n];
+    coeffs[(size_t)(order + 1 + n) * n_pts + i] = (float)hxy[n];
+    coeffs[(size_t)(2 * (order + 1) + n) * n_pts + i] = (float)hyy[n];
+  }
+}
+
+// theta_E[b] * sum_n coeffs[f][n][pt] (r_cut[b] - r0)^n for n_fields fields: out[n_fields][n_pts][B]
+__global__ void __launch_bounds__(256) gl_series_fields_kernel(const float* __restrict__ coeffs, int n_fields, int order,
+                                                               long long n_pts, int B,
+                                                               const float* __restrict__ theta_E,
+                                                               const float* __restrict__ r_cut, float r0,
+                                                               float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pts * B) return;
+  const long long pt = i / B;
+  const int b = (int)(i - pt * B);
+  const float dl = r_cut[b] - r0, te = theta_E[b];
+  for (int f = 0; f < n_fields; ++f) {
+    const float* c = coeffs + (size_t)f * (order + 1) * n_pts + pt;
+    float v = c[(size_t)order * n_pts];
+    for (int n = order - 1; n >= 0; --n) v = v * dl + c[(size_t)n * n_pts];
+    out[(size_t)f * n_pts * B + i] = te * v;
   }
 }
 

@@ -38,6 +38,8 @@ struct PosArgs {
   const CatDev* cats;
   const float* gal_table;   // [G][7]
   const float* gal_static;  // [G][DP_NS]
+  // series-expansion lenses (gl_lens_maps on the model's own grid only)
+  const SeriesDev* series;
 };
 
 // deflection of one lens at (x, y) with raw parameters p, generic in the real type (catalogues are summed)
@@ -143,6 +145,21 @@ __global__ void __launch_bounds__(64) gl_lens_maps_kernel(PosArgs a, const float
     R p[7];
     float pf[7];
     for (int k = 0; k < cd.n_par; ++k) { pf[k] = a.params[(size_t)b * a.P + cd.p_off + k]; p[k] = R(pf[k]); }
+    if (cd.kind == glp::K_SERIES) {  // host guarantees: points = the model grid, both fields attached
+      const SeriesDev sv = a.series[cd.flags];
+      const float dl = pf[1] - sv.r0;
+      float acc[5];
+      for (int f = 0; f < 5; ++f) {
+        const float* c = (f < 2 ? sv.coef + (size_t)f * (sv.order + 1) * n_pts
+                                : sv.hcoef + (size_t)(f - 2) * (sv.order + 1) * n_pts) + pt;
+        float v = c[(size_t)sv.order * n_pts];
+        for (int n = sv.order - 1; n >= 0; --n) v = v * dl + c[(size_t)n * n_pts];
+        acc[f] = pf[0] * v;
+      }
+      bx -= acc[0]; by -= acc[1];
+      fxx += acc[2]; fxy += acc[3]; fyx += acc[3]; fyy += acc[4];
+      continue;
+    }
     R ax, ay;
     lens_point<R>(a, cd, p, xd, yd, ax, ay);
     const float ex = lens_kappa_excess<float>(a, cd, pf, px, py);

@@ -42,7 +42,8 @@ class MassSeries(MassProfile):
         if params is not None:
             self.set_constants(params)
         self._x, self._y = grid
-        self._coefs = None  # device [2, order + 1, n_points] Taylor coefficients
+        self._coefs = None  # device [2, order + 1, n_points] Taylor coefficients of the deflection
+        self._hcoefs = None  # device [3, order + 1, n_points] Taylor coefficients of f_xx, f_xy, f_yy
 
     order = property(lambda self: self._order)
     series_var_0 = property(lambda self: self._series_var_0)
@@ -53,11 +54,11 @@ class MassSeries(MassProfile):
     def set_constants(self, params):
         self._series_var_0 = float(np.asarray(params[self.series_param], dtype=np.float32).reshape(-1)[0])
         self._constants_dict = dict(params)
-        self._coefs = None
+        self._coefs = self._hcoefs = None
 
     def set_grid(self, x, y):
         self._x, self._y = x, y
-        self._coefs = None
+        self._coefs = self._hcoefs = None
 
     def set_deriv(self):
         """series_profile.py:61-62: precompute the expansion on the grid (one native launch, gl_series_precompute)."""
@@ -66,7 +67,18 @@ class MassSeries(MassProfile):
         self._coefs = _native.series_precompute(self)
 
     def set_hessian(self):
-        raise NotImplementedError("Hessian series (image positions on a series lens) are not built")
+        """series_profile.py:64-65: precompute the expansion of the Hessian on the grid (gl_series_precompute_hessian).
+        The reference's ScalingRelationSeries hands a 4-tuple to this 3-way unpacking (scaling_series.py:54) and so
+        raises for catalogues; here the catalogue's Hessian series is built like its deflection series."""
+        if self._x is None or self._series_var_0 is None:
+            raise ValueError("set_grid(x, y) and set_constants(params) must be called before set_hessian()")
+        self._hcoefs = _native.series_precompute(self, hessian=True)
+
+    def hessian(self, x, y, **kwargs):
+        """series_profile.py:83-89: ``(f_xx, f_xy, f_xy, f_yy)`` on the set grid (``(x, y)`` are NOT used)."""
+        if self._hcoefs is None:
+            self.set_hessian()
+        return _native.series_hessian_eval(self, kwargs[self.amplitude_param], kwargs[self.series_param])
 
     def deriv(self, x, y, **kwargs):
         """series_profile.py:76-81: like the reference, ``(x, y)`` are NOT used -- the field lives on the set grid."""
@@ -128,6 +140,15 @@ class ScalingRelationSeries(MassSeries, ScalingRelation):
 
     def deriv(self, x, y, **kwargs):
         return MassSeries.deriv(self, x, y, **kwargs)
+
+    def hessian(self, x, y, **kwargs):
+        return MassSeries.hessian(self, x, y, **kwargs)
+
+    def convergence(self, x, y, **kwargs):  # scaling_series.py:56-60: the generic ones, from the series Hessian
+        return MassProfile.convergence(self, x, y, **kwargs)
+
+    def shear(self, x, y, **kwargs):
+        return MassProfile.shear(self, x, y, **kwargs)
 
     def _component(self):
         return MassSeries._component(self)

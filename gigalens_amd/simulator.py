@@ -168,7 +168,24 @@ class LensSimulator(LensSimulatorInterface):
 
     def _lens_maps(self, x, y, lens_params):
         packed = self._pack_partial({"lens_mass": lens_params}) if not torch.is_tensor(lens_params) else lens_params
-        return self._model.lens_maps(packed, x, y)
+        series = [(i, l) for i, l in enumerate(self.phys_model.lenses) if getattr(l, "_kind", 0) == 10]
+        if not series:
+            return self._model.lens_maps(packed, x, y)
+        # a series lens answers on its own grid whatever (x, y) it is handed (series_profile.py:76,83 TODO); the
+        # reference then silently mixes grids -- here anything but the simulator's grid is refused
+        xt = torch.as_tensor(x, dtype=torch.float32, device=self.device)
+        yt = torch.as_tensor(y, dtype=torch.float32, device=self.device)
+        n = self.img_X.numel()
+        if xt.numel() % n or yt.numel() % n or xt.shape[0] != n or yt.shape[0] != n or \
+                not (torch.equal(xt.reshape(n, -1)[:, 0], self.img_X) and torch.equal(yt.reshape(n, -1)[:, 0], self.img_Y)):
+            raise ValueError("a model with series-expansion lenses maps only the simulator's own grid (img_X, img_Y)")
+        for i, lens in series:
+            if lens._hcoefs is None:
+                lens.set_hessian()
+            if getattr(lens, "_hessian_bound", None) is not lens._hcoefs:
+                self._model.set_series_hessian(i, lens._hcoefs)
+                lens._hessian_bound = lens._hcoefs
+        return self._model.lens_maps(packed, None, None)
 
     def magnification(self, x, y, lens_params: List[Dict]):
         """tf/simulator.py:80-91: ``1 / det(1 - Hessian)`` at ``(x, y)`` (trailing axis = batch)."""

@@ -189,13 +189,25 @@ int gl_scaled_hessian(int base_kind, int n_galaxies, const int32_t scale_col[3],
  *   The reference's f_n (n-th derivatives, summed with 1/n!) are n! C_n.
  * gl_model_set_series: attach a field computed on the model's own pixel list ([2][order+1][N], DEVICE; copied) to a
  *   GL_SERIES lens; at run time  alpha = theta_E * sum_n C_n (r_cut - r0)^n  (series_profile.py:76-95).
- * gl_series_eval: that polynomial on a field, out0/out1 [n_pts][B]  (MassSeries.deriv at plugin level). */
+ * gl_series_eval: that polynomial on a field, out0/out1 [n_pts][B]  (MassSeries.deriv at plugin level).
+ * The Hessian half (MassSeries.set_hessian / .hessian, series_profile.py:64-65,83-89; DPIESeries.precompute_hessian,
+ * dpie_series.py:35-49; ScalingRelationSeries.precompute_hessian, scaling_series.py:37-54):
+ * gl_series_precompute_hessian: same arguments, coeffs [3][order+1][n_pts] = series of f_xx, f_xy, f_yy.
+ * gl_series_hessian_eval: out [3][n_pts][B] = theta_E * sum_n C_n (r_cut - r0)^n per field.
+ * gl_model_set_series_hessian: attach the Hessian field of a GL_SERIES lens ([3][order+1][N], DEVICE; copied) so that
+ *   gl_lens_maps on the model's own grid (x = y = NULL) can include the lens; gl_model_set_series must come first. */
 int gl_series_precompute(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev,
                          const float* scales, int n_scales, int order, const float* x_dev, const float* y_dev,
                          int64_t n_pts, float* coeffs_dev, void* hip_stream);
 int gl_model_set_series(gl_model* m, int component, float r0, const float* coeffs_dev);
 int gl_series_eval(const float* coeffs_dev, int order, int64_t n_pts, int B, const float* theta_E, const float* r_cut,
                    float r0, float* out0, float* out1, void* hip_stream);
+int gl_series_precompute_hessian(int base_kind, int n_galaxies, const int32_t scale_col[3], const float* table_dev,
+                                 const float* scales, int n_scales, int order, const float* x_dev, const float* y_dev,
+                                 int64_t n_pts, float* coeffs_dev, void* hip_stream);
+int gl_series_hessian_eval(const float* coeffs_dev, int order, int64_t n_pts, int B, const float* theta_E,
+                           const float* r_cut, float r0, float* out, void* hip_stream);
+int gl_model_set_series_hessian(gl_model* m, int component, const float* coeffs_dev);
 
 /* Linear-amplitude solve, LensSimulator.lstsq_simulate (tf/simulator.py:158-240): every light component is rendered
  * as `depth` basis images of unit amplitude (Sersic: 1; Shapelets: (n_max+1)(n_max+2)/2), NaN -> 0, PSF and
@@ -234,7 +246,10 @@ int gl_scaled_eval(int base_kind, int n_galaxies, const int32_t scale_col[3], co
 /* LensSimulator.beta / .magnification / .convergence / .shear on arbitrary points (tf/simulator.py:72-107):
  * out [6][n_pts][B] = beta_x, beta_y, f_xx, f_xy, f_yx, f_yy, the Hessian summed over the lenses as `lens.hessian`
  * resolves it in the reference (tf/profile.py:9-43 autodiff; analytic overrides incl. piemd.py:62-83).
- * x, y as in gl_profile_eval ([n_pts,B] when xy_batched, else [n_pts]); params [B,P] (only lens columns are read). */
+ * x, y as in gl_profile_eval ([n_pts,B] when xy_batched, else [n_pts]); params [B,P] (only lens columns are read).
+ * x = y = NULL selects the model's own evaluation grid (n_pts must equal its size, xy_batched 0); that is the only
+ * form a model with GL_SERIES lenses accepts -- their fields live on that grid (series_profile.py:76-89) -- and it
+ * needs gl_model_set_series_hessian on each of them. */
 int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, const float* y, int64_t n_pts,
                  int xy_batched, float* out, void* hip_stream);
 

@@ -458,6 +458,74 @@ def dpie_series_precompute(order, x, y, theta_E, r_core, r_cut, e1, e2, center_x
     return f[0], f[1]
 
 
+def _dpie_series_hessian_single(x, y, r_w, e, q):
+    """series_codegen/profiles/dpie.py:73-105 ``complex_hessian_single``: Lenstool's closed-form second derivatives of
+    one PIEMD term of radius ``r_w`` in the rotated frame (f_xy is ``didyre`` as written)."""
+    sqe = torch.sqrt(e)
+    qinv = 1.0 / q
+    cxro, cyro = (1.0 + e) * (1.0 + e), (1.0 - e) * (1.0 - e)
+    ci = 0.5 * (1.0 - e ** 2) / sqe
+    wrem = torch.sqrt(r_w ** 2 + x ** 2 / cxro + y ** 2 / cyro)
+    den1 = 2.0 * sqe * wrem - y * qinv
+    den1 = q ** 2 * x ** 2 + den1 ** 2
+    num2 = 2.0 * r_w * sqe - y
+    den2 = x ** 2 + num2 ** 2
+    didxre = ci * (q * (2.0 * sqe * x ** 2 / cxro / wrem - 2.0 * sqe * wrem + y * qinv) / den1 + num2 / den2)
+    didyre = ci * ((2 * sqe * x * y * q / cyro / wrem - x) / den1 + x / den2)
+    didyim = ci * ((2 * sqe * wrem * qinv - y * qinv ** 2 - 4 * e * y / cyro
+                    + 2 * sqe * y ** 2 / cyro / wrem * qinv) / den1 - num2 / den2)
+    return didxre, didyre, didyim
+
+
+def dpie_series_precompute_hessian(order, x, y, theta_E, r_core, r_cut, e1, e2, center_x, center_y):
+    """DPIESeries.precompute_hessian (dpie_series.py:35-49): derivatives w.r.t. r_cut of
+    ``r_cut/(r_cut - r_core) * (H(r_core) - H(r_cut))`` (series_codegen/profiles/dpie.py:60-70), each order rotated
+    back with ``_hessian_rotate(-phi)`` (dpie_series.py:64-88); trailing axis of length order + 1."""
+    r_core, r_cut, e1, e2, center_x, center_y = (_t(v, x) for v in (r_core, r_cut, e1, e2, center_x, center_y))
+    phi = torch.atan2(e2, e1) / 2
+    e = torch.sqrt(e1 ** 2 + e2 ** 2)
+    q = (1 - e) / (1 + e)
+    xs, ys = x - center_x, y - center_y
+    xr, yr = _rotate(xs, ys, phi)
+    c2, s2 = torch.cos(2 * -phi), torch.sin(2 * -phi)
+
+    def unit(rc):
+        core = _dpie_series_hessian_single(xr, yr, r_core, e, q)
+        cut = _dpie_series_hessian_single(xr, yr, rc, e, q)
+        sc = rc / (rc - r_core)
+        fxx, fxy, fyy = (sc * (a - b) for a, b in zip(core, cut))
+        a, b, c, d, ee = 0.5 * (fxx + fyy), 0.5 * (fxx - fyy) * c2, fxy * s2, fxy * c2, 0.5 * (fxx - fyy) * s2
+        return torch.stack((a + b + c, d - ee, a - b - c))
+
+    tower = _derivative_tower(unit, r_cut * torch.ones_like(xr * r_cut), order)
+    f = torch.stack(tower, dim=-1)
+    return f[0], f[1], f[2]
+
+
+def scaled_series_precompute_hessian(profile, order, x, y, **scales):
+    """ScalingRelationSeries.precompute_hessian (scaling_series.py:37-54), same weights as the deflection series.
+    (The reference returns ``f_xx, f_xy, f_xy, f_yy`` into MassSeries.set_hessian's 3-way unpacking,
+    series_profile.py:65, which raises; the three distinct fields are restated here.)"""
+    scales = dict(scales)
+    scales[profile.amplitude_param] = 1.0
+    kw = _scaled_galaxy_kwargs(profile, scales, x)
+    un = scaled_unscaled_factors(profile)
+    n = torch.arange(order + 1, dtype=x.dtype)
+    pre = un[profile.amplitude_param].to(x.dtype)[:, None] * un[profile.series_param].to(x.dtype)[:, None] ** n
+    f = dpie_series_precompute_hessian(order, x.unsqueeze(-1), y.unsqueeze(-1), **kw)
+    return tuple((pre * c).sum(-2) for c in f)
+
+
+def series_hessian(coefs, order, var, var0, scale):
+    """MassSeries.hessian (series_profile.py:83-89) on ``coefs = (f_xx, f_xy, f_yy)``: returns the 4-tuple."""
+    n = torch.arange(order + 1, dtype=coefs[0].dtype)
+    fact = torch.exp(torch.lgamma(n + 1))
+    powers = (_t(var, coefs[0]).unsqueeze(-1) - var0) ** n
+    scale = _t(scale, coefs[0])
+    fxx, fxy, fyy = (scale * (c * powers / fact).sum(-1) for c in coefs)
+    return fxx, fxy, fxy, fyy
+
+
 def scaled_series_precompute(profile, order, x, y, **scales):
     """ScalingRelationSeries.precompute_deriv (scaling_series.py:19-35): amplitude scale set to 1, every galaxy's
     derivative tower weighted by ``(L/L*)^p_amp * ((L/L*)^p_series)^n`` and summed over the catalogue."""

@@ -223,6 +223,13 @@ void hm_series_f64(int base_kind, int n_gal, const float* table, const int* cols
   ScaledDesc sd{base_kind, n_gal, {cols[0], cols[1], cols[2]}};
   for (int i = 0; i < n; ++i) series_point<5, double>(sd, table, scales, x[i], y[i], out + 12 * i, out + 12 * i + 6);
 }
+// ... and of its Hessian (Dual<Jet<double,5>,2>): out [n][3][6] = f_xx, f_xy, f_yy
+void hm_series_hessian_f64(int base_kind, int n_gal, const float* table, const int* cols, const double* scales, int n,
+                           const double* x, const double* y, double* out) {
+  ScaledDesc sd{base_kind, n_gal, {cols[0], cols[1], cols[2]}};
+  for (int i = 0; i < n; ++i)
+    series_point_hessian<5, double>(sd, table, scales, x[i], y[i], out + 18 * i, out + 18 * i + 6, out + 18 * i + 12);
+}
 void hm_scaled_f32(int base_kind, int n_gal, const float* table, const int* cols, const float* scales, int n,
                    const float* x, const float* y, const float* gx, const float* gy, float* ax, float* ay,
                    float* gscales) {

@@ -246,3 +246,38 @@ def test_jet_series_coefficients_vs_autodiff_tower(hostmath):
                             r_cut=torch.tensor([2.6], dtype=F64))
     sx = 0.3 * (out[:, 0, :] * 0.1 ** np.arange(6)).sum(-1)
     assert np.allclose(sx, ex[:, 0].numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_jet_series_hessian_coefficients_vs_closed_form_tower(hostmath):
+    """The Hessian half: space duals of r_cut jets through the member templates against the derivative tower of the
+    closed-form dPIE Hessian the reference's generated hessian_0..hessian_5 come from
+    (series_codegen/profiles/dpie.py:60-105) -- two independent routes to d^n/dr^n of d alpha/d(x, y)."""
+    n_gal, n = 9, 300
+    cat = make_catalogue(n_gal, 8)
+    power = {'theta_E': 0.5, 'r_core': 0.5, 'r_cut': 0.4}
+    prof = oracle_scaled_profile("dPIE", cat, ['theta_E', 'r_core', 'r_cut'], power, lum_star=1.3)
+    prof.amplitude_param, prof.series_param = 'theta_E', 'r_cut'
+    t, cols = catalogue_table(prof, n_gal)
+    r = np.random.default_rng(4)
+    x, y = r.uniform(-7, 7, n), r.uniform(-7, 7, n)
+    scales = np.array([9.0, 0.04, 2.5])
+    out = np.zeros((n, 3, 6))
+    hostmath.hm_series_hessian_f64(c_int(7), c_int(n_gal), _fp(t), cols.ctypes.data_as(POINTER(c_int)), _dp(scales),
+                                   c_int(n), _dp(x), _dp(y), _dp(out))
+    f = ref.scaled_series_precompute_hessian(prof, 5, torch.as_tensor(x)[:, None], torch.as_tensor(y)[:, None],
+                                             theta_E=torch.tensor([1.0], dtype=F64),
+                                             r_core=torch.tensor([0.04], dtype=F64),
+                                             r_cut=torch.tensor([2.5], dtype=F64))
+    fact = np.array([math.factorial(k) for k in range(6)], dtype=np.float64)
+    for j in range(3):
+        o = f[j][:, 0].numpy() / fact
+        for k in range(6):
+            sc = np.abs(o[:, k]).max()
+            assert np.allclose(out[:, j, k], o[:, k], rtol=1e-6, atol=1e-7 * sc), (j, k)
+    # order 0 is the Hessian of the scaled population itself (oracle: autograd of its deflection)
+    fxx, fxy, fyx, fyy = ref.mass_hessian(prof, torch.as_tensor(x)[:, None], torch.as_tensor(y)[:, None],
+                                          theta_E=torch.tensor([1.0], dtype=F64), r_core=torch.tensor([0.04], dtype=F64),
+                                          r_cut=torch.tensor([2.5], dtype=F64))
+    assert np.allclose(out[:, 0, 0], fxx[:, 0].numpy(), rtol=1e-7, atol=1e-10)
+    assert np.allclose(out[:, 1, 0], fxy[:, 0].numpy(), rtol=1e-7, atol=1e-10)
+    assert np.allclose(out[:, 2, 0], fyy[:, 0].numpy(), rtol=1e-7, atol=1e-10)
