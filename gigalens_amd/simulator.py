@@ -75,6 +75,22 @@ class LensSimulatorInterface:
         self.wcs = LensWCS(n=sim_config.num_pix, supersample=sim_config.supersample,
                            transform_pix2angle=sim_config.transform_pix2angle, pix_scale=sim_config.delta_pix)
 
+    @staticmethod
+    def get_coords(supersample: int, num_pix: int, transform_pix2angle):
+        """src/gigalens/simulator.py:129-162 (a legacy helper no simulator of the reference calls): the grid with mean
+        coordinate (0, 0).  The reference builds it with lenstronomy's ``PixelGrid`` (third party); its published rule is
+        ``ra = ra_at_xy_0 + T00 ix + T01 iy``, ``dec = dec_at_xy_0 + T10 ix + T11 iy`` with ``ix`` along the columns,
+        restated here.  Returns ``(ra_at_xy_0, dec_at_xy_0, img_x, img_y)`` with float32 ``(n, n)`` grids."""
+        n = int(supersample) * int(num_pix)
+        T = np.asarray(transform_pix2angle, dtype=np.float64)
+        lo = np.arange(0, n, dtype=np.float32)
+        lo = np.min(lo - np.mean(lo))
+        ra0, dec0 = np.squeeze(T @ np.array([[lo], [lo]], dtype=np.float64))
+        ix, iy = np.meshgrid(np.arange(n), np.arange(n))
+        img_x = (ra0 + T[0, 0] * ix + T[0, 1] * iy).astype(np.float32)
+        img_y = (dec0 + T[1, 0] * ix + T[1, 1] * iy).astype(np.float32)
+        return ra0, dec0, img_x, img_y
+
 
 class _SimulateFn(torch.autograd.Function):
     """autograd glue: forward = gl_simulate_fwd, backward = gl_simulate_bwd (both HIP)."""

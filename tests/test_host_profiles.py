@@ -77,3 +77,22 @@ def test_series_bookkeeping():
     one.set_constants(dict(r_core=0.1, center_x=0.0, center_y=0.0, e1=0.1, e2=0.0, r_cut=3.0, theta_E=1.0))
     kind, cols, table, scales = one._series_inputs()
     assert cols == [-1, -1, 0] and table.shape == (1, 7) and scales == [3.0]
+
+
+def test_get_coords_centres_the_grid():
+    """LensSimulatorInterface.get_coords (src/gigalens/simulator.py:129-162): mean coordinate (0, 0); for the diagonal
+    transform it is the simulator's own grid (simulator.py:47-55) at supersample 1 scale."""
+    from gigalens_amd.simulator import LensSimulatorInterface, LensWCS
+    d, n, ss = 0.065, 8, 2
+    T = np.array([[d / ss, 0.0], [0.0, d / ss]])
+    ra0, dec0, X, Y = LensSimulatorInterface.get_coords(ss, n, T)
+    assert X.shape == (16, 16) and X.dtype == np.float32
+    assert abs(X.mean()) < 1e-7 and abs(Y.mean()) < 1e-7
+    assert np.isclose(ra0, X[0, 0]) and np.isclose(dec0, Y[0, 0])
+    gx, gy = LensWCS(n=n, supersample=ss, pix_scale=d).pixel_grid()
+    assert np.allclose(X, gx.reshape(16, 16), atol=1e-7) and np.allclose(Y, gy.reshape(16, 16), atol=1e-7)
+    # a rotated / sheared transform keeps the centring
+    T2 = np.array([[0.03, 0.01], [-0.012, 0.031]])
+    _, _, X2, Y2 = LensSimulatorInterface.get_coords(1, 9, T2)
+    assert abs(X2.mean()) < 1e-6 and abs(Y2.mean()) < 1e-6
+    assert np.isclose(X2[0, 1] - X2[0, 0], 0.03) and np.isclose(Y2[1, 0] - Y2[0, 0], 0.031)
