@@ -65,6 +65,8 @@ SYMBOLS = {
     "gl_model_set_series": (c_int, [c_void_p, c_int, c_float, c_void_p]),
     "gl_series_eval": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                c_void_p]),
+    "gl_profile_basis": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p]),
     "gl_series_precompute_hessian": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, POINTER(c_float), c_int, c_int,
                                              c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "gl_series_hessian_eval": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
@@ -287,6 +289,33 @@ def profile_eval(profile, x, y, kwargs):
     if is_mass:
         return out0.reshape(out_shape), out1.reshape(out_shape)
     return (out0.reshape(out_shape),)
+
+
+def profile_basis(profile, x, y, kwargs):
+    """``light`` of a ``use_lstsq`` profile (gl_profile_basis): ``(depth,) + broadcast shape`` unit-amplitude images."""
+    dev = device()
+    comp = component_of(profile)
+    names = list(profile.params)  # without the amplitudes (profile.py:40-41)
+    missing = [n for n in names if n not in kwargs]
+    if missing:
+        raise TypeError(f"{profile.name}: missing parameters {missing}")
+    x = torch.as_tensor(x, dtype=torch.float32, device=dev)
+    y = torch.as_tensor(y, dtype=torch.float32, device=dev)
+    vals = [torch.as_tensor(kwargs[n], dtype=torch.float32, device=dev) for n in names]
+    out_shape = torch.broadcast_shapes(x.shape, y.shape, *[v.shape for v in vals])
+    B = out_shape[-1] if len(out_shape) else 1
+    for n, v in zip(names, vals):
+        if v.dim() > 1 and any(s != 1 for s in v.shape[:-1]):
+            raise NativeLibraryError(f"{profile.name}.{n}: parameters may only vary along the last (batch) axis")
+    cols = {n: (v.reshape(-1)[-B:].expand(B) if v.numel() > 1 else v.reshape(()).expand(B)) for n, v in zip(names, vals)}
+    one = torch.ones(B, dtype=torch.float32, device=dev)
+    P = torch.stack([cols.get(n, one) for n in profile._native_params()], dim=1).contiguous()
+    xb = x.expand(out_shape).reshape(-1, B).contiguous()
+    yb = y.expand(out_shape).reshape(-1, B).contiguous()
+    out = torch.empty((int(profile.depth),) + tuple(xb.shape), dtype=torch.float32, device=dev)
+    _check(lib().gl_profile_basis(ctypes.byref(comp), _ptr(xb), _ptr(yb), xb.shape[0], B, 1, _ptr(P), _ptr(out),
+                                  _stream()))
+    return out.reshape((int(profile.depth),) + tuple(out_shape))
 
 
 # --------------------------------------------------------------------------------------------------

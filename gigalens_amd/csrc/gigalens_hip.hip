@@ -943,6 +943,23 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   return GL_OK;
 }
 
+// process-lifetime table for plugin-level table-mode shapelets (n_max = cap), built on first use
+static int point_shapelet_table(float** tab_out, int* stride_out) {
+  static float* s_tab = nullptr;
+  static int s_stride = 0;
+  if (!s_tab) {
+    std::vector<float> tab;
+    glh::build_shapelet_table(GL_SHAPELETS_NMAX_CAP, tab, &s_stride);
+    float* p = nullptr;
+    GL_HIP(hipMalloc((void**)&p, tab.size() * sizeof(float)));
+    GL_HIP(hipMemcpy(p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    s_tab = p;
+  }
+  *tab_out = s_tab;
+  *stride_out = s_stride;
+  return GL_OK;
+}
+
 static int series_precompute(bool hessian, int base_kind, int n_galaxies, const int32_t scale_col[3],
                              const float* table_dev, const float* scales, int n_scales, int order, const float* x_dev,
                              const float* y_dev, int64_t n_pts, float* coeffs_dev, void* hip_stream) {
@@ -1313,21 +1330,42 @@ int gl_profile_eval(const gl_component* comp, const float* x, const float* y, in
   cd.n_par = npar;
   if (cd.kind == GL_EPL && cd.iparam <= 0) cd.iparam = 50;
   hipStream_t stream = (hipStream_t)hip_stream;
-  static float* s_tab = nullptr;  // process-lifetime table for table-mode shapelets (n_max = cap)
-  static int s_stride = 0;
-  if (cd.kind == GL_SHAPELETS) {
-    if (cd.iparam < 0 || cd.iparam > GL_SHAPELETS_NMAX_CAP)
-      return fail(GL_EUNSUPPORTED, "shapelets n_max=%d outside [0,%d]", cd.iparam, GL_SHAPELETS_NMAX_CAP);
-    if ((cd.flags & GL_FLAG_SHAPELETS_INTERPOLATE) && !s_tab) {
-      std::vector<float> tab;
-      glh::build_shapelet_table(GL_SHAPELETS_NMAX_CAP, tab, &s_stride);
-      GL_HIP(hipMalloc((void**)&s_tab, tab.size() * sizeof(float)));
-      GL_HIP(hipMemcpy(s_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
-  }
+  float* s_tab = nullptr;
+  int s_stride = 0, rc_tab = 0;
+  if (cd.kind == GL_SHAPELETS && (cd.iparam < 0 || cd.iparam > GL_SHAPELETS_NMAX_CAP))
+    return fail(GL_EUNSUPPORTED, "shapelets n_max=%d outside [0,%d]", cd.iparam, GL_SHAPELETS_NMAX_CAP);
+  if (cd.kind == GL_SHAPELETS && (cd.flags & GL_FLAG_SHAPELETS_INTERPOLATE) && (rc_tab = point_shapelet_table(&s_tab, &s_stride)))
+    return rc_tab;
   long long total = (long long)n_pts * B;
   hipLaunchKernelGGL(gl_point_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, cd, x, y,
                      (long long)n_pts, B, xy_batched, params, out0, mass ? out1 : nullptr, s_tab, s_stride);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+
+int gl_profile_basis(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
+                     const float* params, float* out, void* hip_stream) {
+  if (!comp || !x || !y || !params || !out) return fail(GL_EINVAL, "null argument");
+  if (n_pts <= 0 || B <= 0) return fail(GL_EINVAL, "n_pts and B must be positive");
+  int npar = kind_num_params(comp->kind, comp->iparam);
+  if (npar < 0) return fail(GL_EINVAL, "unknown profile kind %d", comp->kind);
+  if (kind_num_linear(comp->kind, comp->iparam) <= 0) return fail(GL_EINVAL, "kind %d has no linear amplitudes", comp->kind);
+  CompDesc cd{};
+  cd.kind = comp->kind;
+  cd.iparam = comp->iparam;
+  cd.flags = comp->flags;
+  cd.n_par = npar;
+  float* s_tab = nullptr;
+  int s_stride = 0, rc_tab = 0;
+  if (cd.kind == GL_SHAPELETS) {
+    if (cd.iparam < 0 || cd.iparam > GL_SHAPELETS_NMAX_CAP)
+      return fail(GL_EUNSUPPORTED, "shapelets n_max=%d outside [0,%d]", cd.iparam, GL_SHAPELETS_NMAX_CAP);
+    if ((cd.flags & GL_FLAG_SHAPELETS_INTERPOLATE) && (rc_tab = point_shapelet_table(&s_tab, &s_stride))) return rc_tab;
+  }
+  long long total = (long long)n_pts * B;
+  hipLaunchKernelGGL(gl_basis_point_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                     cd, x, y, (long long)n_pts, B, xy_batched, params, out, s_tab, s_stride);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

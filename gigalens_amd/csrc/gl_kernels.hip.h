@@ -1069,6 +1069,42 @@ __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float*
   if (out1) out1[i] = o1;
 }
 
+// LightProfile.light of a use_lstsq profile at plugin level: the unit-amplitude basis images (sersic.py:30-34
+// `Ie = ones`, `ret[tf.newaxis]`; shapelets.py:61-62,71-72), out[depth][n_pts][B]; amplitude columns are not read
+__global__ void __launch_bounds__(256) gl_basis_point_kernel(CompDesc cd, const float* __restrict__ x,
+                                                             const float* __restrict__ y, long long n_pts, int B,
+                                                             int xy_batched, const float* __restrict__ params,
+                                                             float* __restrict__ out,
+                                                             const float* __restrict__ shp_tab, int shp_stride) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = n_pts * B;
+  if (i >= total) return;
+  long long pt = i / B;
+  int b = (int)(i - pt * B);
+  float px = xy_batched ? x[i] : x[pt], py = xy_batched ? y[i] : y[pt];
+  const float* p = params + (size_t)b * cd.n_par;
+  if (cd.kind == K_SHAPELETS) {
+    float d[SHP_AMP];
+    d[SHP_CX] = p[1];
+    d[SHP_CY] = p[2];
+    d[SHP_IB] = 1.f / p[0];
+    d[SHP_NMAX] = (float)cd.iparam;
+    shapelets_basis<float, SH_CAP>(d, shp_tab, shp_stride, cd.flags & 1u, px, py,
+                                   [&](int k, float v) { out[(size_t)k * total + i] = v; });
+    return;
+  }
+  float q[10];
+  for (int k = 0; k < cd.n_par; ++k) q[k] = p[k];
+  q[kind_linear_col(cd.kind, cd.iparam)] = 1.f;
+  float v = 0.f;
+  switch (cd.kind) {
+    case K_CORE_SERSIC: { float d[CSR_ND]; core_sersic_prep<float>(q, d); v = core_sersic_fwd<float>(d, px, py); } break;
+    case K_SERSIC: { float d[SER_ND + 2]; sersic_prep<float>(q, false, d); v = sersic_fwd(d, px, py); } break;
+    case K_SERSIC_ELLIPSE: { float d[SER_ND + 2]; sersic_prep<float>(q, true, d); v = sersic_fwd(d, px, py); } break;
+  }
+  out[i] = v;
+}
+
 // ScalingRelation.deriv on arbitrary points (scaling_relation.py:61-70)
 __global__ void __launch_bounds__(256) gl_scaled_point_kernel(ScaledDesc sd, const float* __restrict__ table,
                                                               const float* __restrict__ x, const float* __restrict__ y,

@@ -35,7 +35,7 @@ class Parameterized(ABC):
 
 class LightProfile(Parameterized, ABC):
     """src/gigalens/profile.py:24-60.  ``use_lstsq`` removes the amplitude from ``params``
-    (profile.py:40-41); the least-squares solve itself is a later row."""
+    (profile.py:40-41) and turns ``light`` into the stack of unit-amplitude basis images."""
 
     _amp = ""
 
@@ -57,9 +57,8 @@ class LightProfile(Parameterized, ABC):
 
     def light(self, x, y, **kwargs):
         """Surface brightness at ``(x, y)``; parameters broadcast on the last axis like the reference."""
-        if self.use_lstsq:
-            raise NotImplementedError("plugin-level light() of a use_lstsq profile (the stacked basis images) is not "
-                                      "built; LensSimulator.lstsq_simulate(return_stacked=True) renders them")
+        if self.use_lstsq:  # the unit-amplitude basis images, leading axis = depth (sersic.py:30-34, shapelets.py:61-62)
+            return _native.profile_basis(self, x, y, kwargs)
         return _native.profile_eval(self, x, y, kwargs)[0]
 
 

@@ -261,6 +261,13 @@ int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, 
 int gl_profile_eval(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B,
                     int xy_batched, const float* params, float* out0, float* out1, void* hip_stream);
 
+/* LightProfile.light of a `use_lstsq=True` profile (the unit-amplitude basis images: sersic.py:30-34 `Ie = ones`,
+ * `ret[tf.newaxis]`; shapelets.py:61-62,71-72): out [depth][n_pts][B], depth = 1 for the Sersic family and
+ * (n_max+1)(n_max+2)/2 for Shapelets.  Other arguments as gl_profile_eval; params keeps the kind's full row width,
+ * its amplitude columns are not read. */
+int gl_profile_basis(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
+                     const float* params, float* out, void* hip_stream);
+
 /* MassProfile.hessian / convergence / shear at plugin level (tf/profile.py:9-43 and the analytic overrides of
  * nfw.py:77-94, shear.py:18-26, sis.py:19-29, piemd.py:62-83,121-138): out [4][n_pts][B] = f_xx, f_xy, f_yx, f_yy.
  * Free-standing mass kinds only (catalogues and series: gl_lens_maps on a model). */

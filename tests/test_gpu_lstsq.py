@@ -176,3 +176,50 @@ def test_map_on_backward_prob_model(gl):
     z = seq.MAP(Adam(2e-2), None, n_samples=8, num_steps=40, seed=1, progress=lambda s, red: hist.append(float(red.min())))
     assert z.shape == (8, 17) and torch.isfinite(z).all()  # 6 + 2 + 6 + 3 non-linear parameters
     assert hist[-1] < hist[0]
+
+
+@pytest.mark.parametrize("which", ["sersic", "sersic_ellipse", "core_sersic", "shapelets_table", "shapelets_direct"])
+def test_plugin_level_light_of_lstsq_profiles(gl, which):
+    """``LightProfile.light`` with ``use_lstsq=True`` returns the stack of unit-amplitude basis images on a leading
+    ``depth`` axis (sersic.py:30-34, shapelets.py:61-62,71-72), and the amplitude leaves ``params`` (profile.py:40-41)."""
+    from oracle import ref_torch as ref
+    from gigalens_amd.profiles.light.sersic import CoreSersic, Sersic, SersicEllipse
+    from gigalens_amd.profiles.light.shapelets import Shapelets
+    r = np.random.default_rng(5)
+    n, B = 700, 3
+    x = (r.normal(size=(n, 1)) * 0.8).astype(np.float32)
+    y = (r.normal(size=(n, 1)) * 0.8).astype(np.float32)
+    if which == "sersic":
+        prof = Sersic(use_lstsq=True)
+        kw = dict(R_sersic=[0.3, 0.5, 0.8], n_sersic=[1.0, 2.5, 4.0], center_x=[0.0, 0.1, -0.1], center_y=[0.05, 0.0, 0.2])
+    elif which == "sersic_ellipse":
+        prof = SersicEllipse(use_lstsq=True)
+        kw = dict(R_sersic=[0.3, 0.5, 0.8], n_sersic=[1.0, 2.5, 4.0], e1=[0.1, -0.2, 0.0], e2=[0.05, 0.1, -0.3],
+                  center_x=[0.0, 0.1, -0.1], center_y=[0.05, 0.0, 0.2])
+    elif which == "core_sersic":
+        prof = CoreSersic(use_lstsq=True)
+        kw = dict(R_sersic=[0.5, 0.7, 0.9], n_sersic=[2.0, 3.0, 4.0], Rb=[0.1, 0.2, 0.15], alpha=[2.0, 3.0, 1.5],
+                  gamma=[0.1, 0.3, 0.2], e1=[0.1, -0.1, 0.0], e2=[0.0, 0.1, -0.2], center_x=[0.0, 0.1, -0.1],
+                  center_y=[0.05, 0.0, 0.2])
+    else:
+        prof = Shapelets(6, use_lstsq=True, interpolate=(which == "shapelets_table"))
+        kw = dict(beta=[0.3, 0.45, 0.6], center_x=[0.0, 0.1, -0.1], center_y=[0.05, 0.0, 0.2])
+    assert not any(p.startswith("amp") or p == "Ie" for p in prof.params)
+    kw = {k: np.asarray(v, np.float32) for k, v in kw.items()}
+    got = prof.light(x, y, **kw)
+    assert got.shape == (prof.depth, n, B)
+    okw = {k: torch.as_tensor(v, dtype=F64) for k, v in kw.items()}
+    want = ref.light_basis(prof, torch.as_tensor(x, dtype=F64), torch.as_tensor(y, dtype=F64), **okw)
+    want = want.expand(prof.depth, n, B).numpy()
+    g = got.cpu().numpy()
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(g), ok)
+    assert np.abs(g[ok] - want[ok]).max() <= 2e-5 * np.abs(want[ok]).max()
+    # the basis times the amplitudes is the ordinary profile
+    if which.startswith("shapelets"):
+        full = Shapelets(6, interpolate=(which == "shapelets_table"))
+        amps = {nm: r.normal(size=B).astype(np.float32) for nm in full._amp_names}
+        img = full.light(x, y, **kw, **amps)
+        A = torch.stack([torch.as_tensor(amps[nm], device=got.device) for nm in full._amp_names])  # (depth, B)
+        comb = (got * A[:, None, :]).sum(0)
+        assert torch.allclose(torch.nan_to_num(img), torch.nan_to_num(comb), rtol=1e-4, atol=1e-5 * float(comb.abs().max()))
