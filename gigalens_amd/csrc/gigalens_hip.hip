@@ -924,16 +924,17 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   else
     hipLaunchKernelGGL(gl_normal_tiled_kernel, dim3(lw.n_chunks, B), dim3(256), sizeof(float2) * LS_TPP * lw.Dp, stream, na);
   GL_HIP(hipGetLastError());
-  const int n = (D + 1) & ~1;
-  const size_t sm = sizeof(float) * ((size_t)2 * n * (n + 1) + 3 * n + 8);
   float* coeffs = coeffs_or_null ? coeffs_or_null : lw.coeffs;
-  // the Jacobi steps are barrier-latency bound: large systems get a full 1024-thread workgroup per sample
-  if (n > 24)
-    hipLaunchKernelGGL((gl_pinv_solve_kernel<1024>), dim3(B), dim3(1024), sm, stream, lw.partial, lw.n_chunks, D, lw.Dp,
-                       1e-6f, 12, coeffs);
-  else
-    hipLaunchKernelGGL((gl_pinv_solve_kernel<256>), dim3(B), dim3(256), sm, stream, lw.partial, lw.n_chunks, D, lw.Dp,
-                       1e-6f, 12, coeffs);
+  int n_sum = lw.n_chunks;
+  if (n_sum > 8) {  // many chunks (small batches): reduce them with the whole chip first
+    hipLaunchKernelGGL(gl_partial_sum_kernel, dim3((lw.Dp * lw.Dp + 255) / 256, B), dim3(256), 0, stream, lw.partial,
+                       lw.n_chunks, lw.Dp * lw.Dp);
+    GL_HIP(hipGetLastError());
+    n_sum = 1;
+  }
+  const size_t sm = sizeof(float) * ((size_t)2 * D * (D | 1) + 7 * D + 8);
+  hipLaunchKernelGGL(gl_eigh_solve_kernel, dim3(B), dim3(64), sm, stream, lw.partial, lw.n_chunks, n_sum, D, lw.Dp, 1e-6f,
+                     coeffs);
   GL_HIP(hipGetLastError());
   if (image_or_null) {
     hipLaunchKernelGGL(gl_combine_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, stream, lw.stack, coeffs, D, HW,
@@ -1343,6 +1344,13 @@ int gl_profile_eval(const gl_component* comp, const float* x, const float* y, in
   return GL_OK;
 }
 
+
+#ifdef GL_EIGH_STAMPS
+int gl_debug_eigh_stamps(long long* out) {
+  GL_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(glk::g_eigh_stamps), sizeof(long long) * 8));
+  return GL_OK;
+}
+#endif
 
 int gl_profile_basis(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
                      const float* params, float* out, void* hip_stream) {

@@ -3,19 +3,24 @@
 // Three kernels on the stack of basis images  S[b][d][p]  the IMG_BASIS pass (+ PSF / pooling) produced:
 //   gl_normal_*_kernel   per (sample, pixel chunk): the symmetric normal matrix of the augmented system [X | Y]
 //                        (last row/column = X^T Y, Y^T Y), register-tiled packed-fp32 SYRK
-//   gl_pinv_solve_kernel per sample: sum the chunk partials (fixed order), parallel-ordered cyclic Jacobi
-//                        eigendecomposition in LDS, pseudo-inverse with the reference's relative cutoff, coefficients
+//   gl_eigh_solve_kernel per sample, one wavefront: sum the chunk partials (fixed order), Householder + implicit-QL
+//                        eigendecomposition in LDS (gl_eigh.h), pseudo-inverse with the reference's relative cutoff
 //   gl_combine_kernel    image = sum_d coeffs_d S_d   (tf/simulator.py:239)
 // fp32 MFMA and packed fp32 FMA have the same peak on CDNA4 (157 TFLOP/s), so the SYRK stays on the vector ALU:
 // 4x4 register tiles over pixel PAIRS (v_pk_fma_f32), operands staged through LDS as [pixel pair][channel][2].
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifdef GL_EIGH_STAMPS  // debug build only: wall-clock stamps of the solve's phases (block 0)
+namespace glk { __device__ long long g_eigh_stamps[8]; }
+#define GL_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) ::glk::g_eigh_stamps[k] = wall_clock64(); } while (0)
+#endif
+#include "gl_eigh.h"
 #include "gl_kernels.hip.h"
 
 namespace glk {
 
-constexpr int LS_MAXD = 80;   // channels incl. the observation column (LDS: A and V of the Jacobi solve)
+constexpr int LS_MAXD = 80;   // channels incl. the observation column (LDS: A and V of the eigen solve)
 constexpr int LS_TPP = 32;    // pixel pairs per LDS tile
 constexpr int LS_SMALL = 8;   // <= this many channels (incl. Y): pixel-parallel kernel with register accumulators
 
@@ -121,118 +126,144 @@ __global__ void __launch_bounds__(256) gl_normal_tiled_kernel(NormalArgs a) {
 }
 
 // ---- per sample: A = sum of partials, eigendecomposition, coeffs = pinv(A_DD, rcond) A_DY -------------------------
-// Parallel-ordered cyclic Jacobi (round-robin tournament: n-1 steps of n/2 disjoint rotations per sweep); all n/2
-// rotations of a step are applied together: columns (A J, V J), then rows (J^T A).  tf.linalg.pinv cuts singular
-// values <= rcond * max (here |eigenvalues| of the symmetric normal matrix).
-template <int NT>
-__global__ void __launch_bounds__(NT) gl_pinv_solve_kernel(const float* __restrict__ partial, int n_chunks, int D,
-                                                            int Dp, float rcond, int sweeps, float* __restrict__ coeffs) {
+// One wavefront per system (gl_eigh.h): Householder tridiagonalisation + implicit QL in LDS, tf.linalg.pinv's cutoff
+// (singular values <= rcond * max, here |eigenvalues| of the symmetric normal matrix).  The workgroup IS the wave, so
+// __syncthreads() is a single-wave barrier.  (The first version of this step was a parallel-ordered cyclic Jacobi
+// solve with 1024 threads per system: 3.8 ms for 1024 systems of 66 unknowns, barrier- and LDS-bound; this one does
+// ~1/10 of the arithmetic and has no barrier in its longest phase.)
+struct WaveCtx {
+  static constexpr int ROWS = 2;  // rows k and k + 64 of V (n <= 79)
+  // the tridiagonal, lane-distributed: entry i lives in lane i & 63 of register (i >> 6); uniform reads are
+  // v_readlane (a few cycles) instead of an LDS round trip on the critical path of every rotation
+  float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
+  int n_ = 0;
+  __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
+  __device__ __forceinline__ int lanes() const { return 64; }
+  __device__ __forceinline__ float sum(float v) const { return rl(wave_sum63(v), 63); }
+  __device__ __forceinline__ float max(float v) const {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+  }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ float rsq(float x) const { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ float rl(float v, int i) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+  }
+  static __device__ __forceinline__ float wl(float reg, int i, float v) { return (int)threadIdx.x == i ? v : reg; }
+  __device__ __forceinline__ void load_tridiagonal(const float* d, const float* es, int n) {
+    const int k = (int)threadIdx.x;
+    n_ = n;
+    d0 = k < n ? d[k] : 0.f;
+    e0 = k < n ? es[k] : 0.f;
+    d1 = k + 64 < n ? d[k + 64] : 0.f;
+    e1 = k + 64 < n ? es[k + 64] : 0.f;
+  }
+  __device__ __forceinline__ void store_diagonal(float* d, int n) const {
+    const int k = (int)threadIdx.x;
+    if (k < n) d[k] = d0;
+    if (k + 64 < n) d[k + 64] = d1;
+  }
+  // branch-free: both halves are read / conditionally written, the index picks
+  __device__ __forceinline__ float d(int i) const {
+    const float a = rl(d0, i & 63), b = rl(d1, i & 63);
+    return i < 64 ? a : b;
+  }
+  __device__ __forceinline__ float e(int i) const {
+    const float a = rl(e0, i & 63), b = rl(e1, i & 63);
+    return i < 64 ? a : b;
+  }
+  __device__ __forceinline__ void set_d(int i, float v) {
+    d0 = wl(d0, i, v);
+    d1 = wl(d1, i - 64, v);
+  }
+  __device__ __forceinline__ void set_e(int i, float v) {
+    e0 = wl(e0, i, v);
+    e1 = wl(e1, i - 64, v);
+  }
+  // all couplings are tested at once: lane k looks at es[k] against |d[k]| + |d[k+1]|, a ballot finds the first split
+  __device__ __forceinline__ int first_split(int l, int n) const {
+    const int k = (int)threadIdx.x;
+    const float a0 = fabsf(d0), a1 = fabsf(d1);
+    float nx0 = __shfl_down(a0, 1, 64);       // |d[k+1]| for k < 63
+    const float a1_first = rl(a1, 0);
+    if (k == 63) nx0 = a1_first;               // |d[64]|
+    const float nx1 = __shfl_down(a1, 1, 64);  // |d[k+65]|
+    const float s0 = a0 + nx0, s1 = a1 + nx1;
+    const bool t0 = k < n - 1 && (fabsf(e0) + s0 == s0);
+    const bool t1 = k + 64 < n - 1 && (fabsf(e1) + s1 == s1);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(t0), m1 = __builtin_amdgcn_ballot_w64(t1);
+    if (l < 64) {
+      const unsigned long long mm = m0 >> l;
+      if (mm) return l + __builtin_ctzll(mm);
+      if (m1) return 64 + __builtin_ctzll(m1);
+      return n - 1;
+    }
+    const unsigned long long mm = m1 >> (l - 64);
+    return mm ? l + __builtin_ctzll(mm) : n - 1;
+  }
+};
+
+// partial[b][0] += partial[b][1..n_chunks-1]  (fixed order), so that the solve reads one matrix per sample
+__global__ void __launch_bounds__(256) gl_partial_sum_kernel(float* __restrict__ partial, int n_chunks, int DpDp) {
+  const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= DpDp) return;
+  float* src = partial + (size_t)b * n_chunks * DpDp + e;
+  float v = src[0];
+  for (int ch = 1; ch < n_chunks; ++ch) v += src[(size_t)ch * DpDp];
+  src[0] = v;
+}
+
+__global__ void __launch_bounds__(64) gl_eigh_solve_kernel(const float* __restrict__ partial, int n_chunks, int n_sum,
+                                                           int D, int Dp, float rcond, float* __restrict__ coeffs) {
   extern __shared__ float sm[];
-  const int n = (D + 1) & ~1;  // even size for the tournament (a padded row/column of zeros is inert)
-  const int ld = n + 1;        // odd row stride: column sweeps hit distinct LDS banks
+  const int n = D, ld = n | 1;
   float* A = sm;               // [n][ld]
-  float* V = A + n * ld;       // [n][ld]
-  float* cs = V + n * ld;      // [n/2][2] rotations, then scratch
-  float* rhs = cs + n;         // [n]
-  int* pr = reinterpret_cast<int*>(rhs + n);  // [n/2][2] pairs
-  const int b = blockIdx.x, tid = threadIdx.x;
+  float* Z = A + n * ld;       // [n][ld]
+  float* d = Z + n * ld;       // [n]
+  float* e = d + n;            // [n+1]
+  float* v = e + n + 1;        // [n]
+  float* p = v + n;            // [n]
+  float* bet = p + n;          // [n]
+  float* rhs = bet + n;        // [n]
+  float* g = rhs + n;          // [n]
+  const int b = blockIdx.x, lane = threadIdx.x;
   const float* src = partial + (size_t)b * n_chunks * Dp * Dp;
-  for (int e = tid; e < n * n; e += NT) {
-    const int i = e / n, j = e - i * n;
-    float v = 0.f;
-    if (i < D && j < D) {
-      const int hi = max(i, j), lo = min(i, j);
-      for (int ch = 0; ch < n_chunks; ++ch) v += src[(size_t)ch * Dp * Dp + hi * Dp + lo];
+  GL_STAMP(0);
+  // lower triangle (valid in the partials) -> full symmetric A; row D = X^T Y
+  for (int i = 0; i < n; ++i)
+    for (int j = lane; j <= i; j += 64) {
+      float s = 0.f;
+      for (int ch = 0; ch < n_sum; ++ch) s += src[(size_t)ch * Dp * Dp + i * Dp + j];
+      A[i * ld + j] = s;
+      A[j * ld + i] = s;
     }
-    A[i * ld + j] = v;
-    V[i * ld + j] = (i == j) ? 1.f : 0.f;
-  }
-  for (int i = tid; i < n; i += NT) {
-    float v = 0.f;
-    if (i < D)
-      for (int ch = 0; ch < n_chunks; ++ch) v += src[(size_t)ch * Dp * Dp + D * Dp + i];  // row D = X^T Y
-    rhs[i] = v;
+  for (int i = lane; i < n; i += 64) {
+    float s = 0.f;
+    for (int ch = 0; ch < n_sum; ++ch) s += src[(size_t)ch * Dp * Dp + D * Dp + i];
+    rhs[i] = s;
+    bet[i] = 0.f;
   }
   __syncthreads();
-  const int half = n / 2;
-  __shared__ int s_rot;
-  for (int sw = 0; sw < sweeps; ++sw) {
-    if (tid == 0) s_rot = 0;
-    __syncthreads();
-    for (int r = 0; r < n - 1; ++r) {
-      if (tid < half) {
-        int p, q;
-        if (tid == 0) { p = n - 1; q = r; }
-        else { p = (r + tid) % (n - 1); q = (r - tid + (n - 1)) % (n - 1); }
-        if (p > q) { int t = p; p = q; q = t; }
-        const float app = A[p * ld + p], aqq = A[q * ld + q], apq = A[p * ld + q];
-        float c = 1.f, s = 0.f;
-        // rotations below fp32 resolution of the two diagonal entries change nothing: skip, and stop sweeping once a
-        // whole sweep consisted of such rotations
-        if (fabsf(apq) > 3e-8f * sqrtf(fabsf(app * aqq)) && fabsf(apq) > 1e-30f) {
-          s_rot = 1;
-          const float tau = (aqq - app) / (2.f * apq);
-          const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
-          c = 1.f / sqrtf(1.f + t * t);
-          s = t * c;
-        }
-        cs[2 * tid] = c; cs[2 * tid + 1] = s;
-        pr[2 * tid] = p; pr[2 * tid + 1] = q;
-      }
-      __syncthreads();
-      // columns: (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q) for every row of A and V
-      for (int e = tid; e < half * n; e += NT) {
-        const int k = e / n, i = e - k * n;
-        const float c = cs[2 * k], s = cs[2 * k + 1];
-        const int p = pr[2 * k], q = pr[2 * k + 1];
-        const float ap = A[i * ld + p], aq = A[i * ld + q];
-        A[i * ld + p] = c * ap - s * aq;
-        A[i * ld + q] = s * ap + c * aq;
-        const float vp = V[i * ld + p], vq = V[i * ld + q];
-        V[i * ld + p] = c * vp - s * vq;
-        V[i * ld + q] = s * vp + c * vq;
-      }
-      __syncthreads();
-      // rows of A
-      for (int e = tid; e < half * n; e += NT) {
-        const int k = e / n, j = e - k * n;
-        const float c = cs[2 * k], s = cs[2 * k + 1];
-        const int p = pr[2 * k], q = pr[2 * k + 1];
-        const float ap = A[p * ld + j], aq = A[q * ld + j];
-        A[p * ld + j] = c * ap - s * aq;
-        A[q * ld + j] = s * ap + c * aq;
-      }
-      __syncthreads();
-    }
-    if (!s_rot) break;  // uniform: read after the step's last barrier
+  WaveCtx cx;
+  float scale = 0.f;
+  for (int k = lane; k < n; k += 64) scale = fmaxf(scale, fabsf(A[k * ld + k]));
+  scale = cx.max(scale);
+  if (!(scale > 0.f) || !(scale < 3.0e38f)) {  // empty system: the pseudo-inverse of 0 is 0; non-finite input: NaN
+    const float out = scale == 0.f ? 0.f : __builtin_nanf("");
+    for (int i = lane; i < n; i += 64) coeffs[(size_t)b * D + i] = out;
+    return;
   }
-  // eigenvalues on the diagonal, eigenvectors in the columns of V
-  float* g = cs;  // reuse: g_k = (V^T rhs)_k / lambda_k  or 0
-  __shared__ float s_max;
-  if (tid == 0) {
-    float m = 0.f;
-    for (int k = 0; k < D; ++k) m = fmaxf(m, fabsf(A[k * ld + k]));
-    s_max = m;
-  }
+  const float inv = 1.0f / scale;
+  for (int i = lane; i < n; i += 64)
+    for (int k = 0; k < n; ++k) A[i * ld + k] *= inv;
   __syncthreads();
-  for (int k = tid; k < n; k += NT) {
-    float v = 0.f;
-    if (k < D) {
-      const float lam = A[k * ld + k];
-      if (fabsf(lam) > rcond * s_max) {
-        float dot = 0.f;
-        for (int i = 0; i < D; ++i) dot += V[i * ld + k] * rhs[i];
-        v = dot / lam;
-      }
-    }
-    g[k] = v;
-  }
+  GL_STAMP(1);
+  gle::sym_eig(cx, A, Z, n, ld, d, e, v, p, bet);
   __syncthreads();
-  for (int i = tid; i < D; i += NT) {
-    float v = 0.f;
-    for (int k = 0; k < D; ++k) v += V[i * ld + k] * g[k];
-    coeffs[(size_t)b * D + i] = v;
-  }
+  GL_STAMP(5);
+  gle::pinv_apply(cx, Z, n, ld, d, rhs, rcond, inv, g, coeffs + (size_t)b * D);
+  GL_STAMP(6);
 }
 
 // image[b][p] = sum_d coeffs[b][d] stack[b][d][p]

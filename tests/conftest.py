@@ -20,7 +20,8 @@ def hostmath():
     import ctypes
     src = os.path.join(ROOT, "tests", "hostmath", "hostmath.cpp")
     so = os.path.join(ROOT, "tests", "hostmath", "libhostmath.so")
-    deps = [src] + [os.path.join(ROOT, "gigalens_amd", "csrc", f) for f in ("gl_profiles.h", "gl_math.h", "gl_host_tables.h", "gl_dual.h")]
+    csrc = os.path.join(ROOT, "gigalens_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h") and not f.endswith(".hip.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
     return ctypes.CDLL(so)
