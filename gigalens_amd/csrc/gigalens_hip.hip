@@ -932,7 +932,7 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
     GL_HIP(hipGetLastError());
     n_sum = 1;
   }
-  const size_t sm = sizeof(float) * ((size_t)2 * D * (D | 1) + 7 * D + 8);
+  const size_t sm = sizeof(float) * ((size_t)2 * D * (D | 1) + 8 * D + 8);
   hipLaunchKernelGGL(gl_eigh_solve_kernel, dim3(B), dim3(64), sm, stream, lw.partial, lw.n_chunks, n_sum, D, lw.Dp, 1e-6f,
                      coeffs);
   GL_HIP(hipGetLastError());

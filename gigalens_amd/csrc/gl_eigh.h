@@ -32,6 +32,8 @@ struct SerialCtx {
   GL_HD float max(float v) const { return v; }
   GL_HD void sync() const {}
   GL_HD float rsq(float x) const { return 1.0f / ::sqrtf(x); }
+  GL_HD float rcp(float x) const { return 1.0f / x; }
+  GL_HD int first_lane(bool pred) const { return pred ? 0 : -1; }  // smallest lane whose predicate holds, or -1
   GL_HD void load_tridiagonal(const float* d, const float* es, int n) {
     for (int i = 0; i < n; ++i) { dd_[i] = d[i]; ee_[i] = es[i]; }
   }
@@ -55,10 +57,11 @@ struct SerialCtx {
 // e [n+1], v, p, bet [n]: scratch.  ld odd keeps lane-strided row accesses on distinct LDS banks.
 // The context must be ONE lock-step wavefront (or serial): the QL phase relies on every lane executing the same
 // scalar instruction stream, so that uniform writes to d / e need no ordering between lanes.
+// ---- Householder tridiagonalisation, rows n-1 .. 2; reflector i acts on coordinates 0..i-1 and stays in row i of
+// A (columns < i) with its factor in bet[i]:  T = Q^T A Q,  Q = H_{n-1} ... H_2;  d = diag(T), e[i] = T[i][i-1] ----
 template <class C>
-GL_HD void sym_eig(C& cx, float* A, float* Z, int n, int ld, float* d, float* e, float* v, float* p, float* bet) {
+GL_HD void tridiagonalize(C& cx, float* A, int n, int ld, float* d, float* e, float* v, float* p, float* bet) {
   const int lane = cx.lane(), NL = cx.lanes();
-  // ---- Householder tridiagonalisation, rows n-1 .. 2; reflector i acts on coordinates 0..i-1 ----
   for (int i = n - 1; i >= 2; --i) {
     float ss = 0.f;
     for (int k = lane; k < i - 1; k += NL) { const float t = A[i * ld + k]; ss += t * t; }
@@ -89,7 +92,18 @@ GL_HD void sym_eig(C& cx, float* A, float* Z, int n, int ld, float* d, float* e,
     cx.sync();
     for (int j = lane; j < i; j += NL) {  // A -= v w^T + w v^T on the leading i x i block
       const float vj = v[j], wj = p[j];
-      for (int k = 0; k < i; ++k) A[j * ld + k] -= vj * p[k] + wj * v[k];
+      float* row = A + j * ld;
+      int k = 0;
+      for (; k + 4 <= i; k += 4) {  // loads of a group before its stores: the row does not alias v / p
+        const float a0 = row[k], a1 = row[k + 1], a2 = row[k + 2], a3 = row[k + 3];
+        const float p0 = p[k], p1 = p[k + 1], p2 = p[k + 2], p3 = p[k + 3];
+        const float v0 = v[k], v1 = v[k + 1], v2 = v[k + 2], v3 = v[k + 3];
+        row[k] = a0 - (vj * p0 + wj * v0);
+        row[k + 1] = a1 - (vj * p1 + wj * v1);
+        row[k + 2] = a2 - (vj * p2 + wj * v2);
+        row[k + 3] = a3 - (vj * p3 + wj * v3);
+      }
+      for (; k < i; ++k) row[k] -= vj * p[k] + wj * v[k];
     }
     for (int k = lane; k < i; k += NL) A[i * ld + k] = v[k];  // keep the reflector in the (now unused) row i
     e[i] = alpha;
@@ -102,7 +116,11 @@ GL_HD void sym_eig(C& cx, float* A, float* Z, int n, int ld, float* d, float* e,
   if (n > 1) e[1] = A[ld];
   for (int k = lane; k < n; k += NL) d[k] = A[k * ld + k];
   cx.sync();
-  // ---- Q = H_{n-1} ... H_2, built from the small end so that only the leading block is touched ----
+}
+
+// ---- Q = H_{n-1} ... H_2 explicitly, built from the small end so that only the leading block is touched ----
+template <class C> GL_HD void accumulate_q(C& cx, const float* A, float* Z, int n, int ld, const float* bet) {
+  const int lane = cx.lane(), NL = cx.lanes();
   for (int j = lane; j < n; j += NL)
     for (int k = 0; k < n; ++k) Z[k * ld + j] = (k == j) ? 1.f : 0.f;
   cx.sync();
@@ -117,9 +135,12 @@ GL_HD void sym_eig(C& cx, float* A, float* Z, int n, int ld, float* d, float* e,
     }
   }
   cx.sync();  // columns of Z were owned by lanes above, rows below
-  GL_STAMP(3);
-  // ---- implicit QL on (d, es); every lane runs the scalar chain, lane k rotates rows k, k + lanes, .. of Z ----
-  // es[i] = e[i+1] couples d[i] and d[i+1]; es[n-1] = 0
+}
+
+// ---- implicit QL on (d, es); every lane runs the scalar chain, lane k rotates rows k, k + lanes, .. of Z ----
+// es[i] = e[i+1] couples d[i] and d[i+1]; es[n-1] = 0.  On return d holds the eigenvalues, Z's columns the vectors.
+template <class C> GL_HD void ql_implicit(C& cx, float* Z, int n, int ld, float* d, const float* e) {
+  const int lane = cx.lane(), NL = cx.lanes();
   cx.load_tridiagonal(d, e + 1, n);
   for (int l = 0; l < n; ++l) {
     int iter = 0;
@@ -215,6 +236,104 @@ GL_HD void pinv_apply(const C& cx, const float* Z, int n, int ld, const float* d
     for (int k = 0; k < n; ++k) val += Z[i * ld + k] * g[k];
     coeffs[i] = val * inv_scale;
   }
+}
+
+// ---- the well-conditioned short cut ---------------------------------------------------------------------------------
+// When no eigenvalue is cut, pinv(A) b = A^{-1} b = Q T^{-1} Q^T b: no eigenvectors are needed, only the proof that the
+// spectrum of T lies above the cutoff.  Sturm counts give it: the largest eigenvalue by multi-section (every lane
+// counts at its own shift), then ONE count at  rcond * lambda_max:  zero eigenvalues below it means T is positive
+// definite with nothing to cut, and the solve is a tridiagonal LDL^T between two sweeps of the reflectors.
+
+// number of eigenvalues of T below x (T = tridiag(d, e), e[i] couples i-1 and i)
+template <class C> GL_HD int sturm_count(const C& cx, const float* d, const float* e, int n, float x) {
+  float q = d[0] - x;
+  int cnt = q < 0.f;
+  for (int i = 1; i < n; ++i) {
+    if (::fabsf(q) < 1e-30f) q = -1e-30f;
+    q = (d[i] - x) - e[i] * e[i] * cx.rcp(q);
+    cnt += q < 0.f;
+  }
+  return cnt;
+}
+
+// an upper bound of the largest eigenvalue, tight to ~1e-4 relative (of the Gershgorin span)
+template <class C> GL_HD float largest_eigenvalue(const C& cx, const float* d, const float* e, int n) {
+  const int lane = cx.lane(), NL = cx.lanes();
+  float lo = 3.0e38f, hi = -3.0e38f;
+  for (int i = lane; i < n; i += NL) {
+    const float r = ::fabsf(e[i]) + ::fabsf(e[i + 1]);  // e[0] = e[n] = 0
+    lo = ::fminf(lo, d[i] - r);
+    hi = ::fmaxf(hi, d[i] + r);
+  }
+  lo = -cx.max(-lo);
+  hi = cx.max(hi);
+  const float span = hi - lo;
+  hi += 1e-6f * span;  // strictly above the spectrum: count(hi) == n
+  for (int round = 0; round < 32 && hi - lo > 1e-4f * span; ++round) {
+    const float step = (hi - lo) / (float)(NL + 1);
+    const float x = lo + step * (float)(lane + 1);
+    const int j = cx.first_lane(sturm_count(cx, d, e, n, x) == n);  // smallest shift already above everything
+    if (j < 0) lo = lo + step * (float)NL;
+    else { hi = lo + step * (float)(j + 1); lo = lo + step * (float)j; }
+  }
+  return hi;
+}
+
+// y = Q^T y (forward = true) or y = Q y, Q = H_{n-1} ... H_2 with the reflectors in the rows of A; y [n] shared
+template <class C> GL_HD void apply_reflectors(const C& cx, const float* A, int n, int ld, const float* bet, float* y, bool transpose) {
+  const int lane = cx.lane(), NL = cx.lanes();
+  for (int s = 0; s < n - 2; ++s) {
+    const int i = transpose ? n - 1 - s : 2 + s;
+    const float b = bet[i];
+    if (b == 0.f) continue;
+    float dot = 0.f;
+    for (int k = lane; k < i; k += NL) dot += A[i * ld + k] * y[k];
+    dot = b * cx.sum(dot);
+    for (int k = lane; k < i; k += NL) y[k] -= dot * A[i * ld + k];
+    cx.sync();
+  }
+}
+
+// T y = c for a positive-definite tridiagonal T (LDL^T, no pivoting needed); c is overwritten with y; w [n] scratch.
+// Every lane runs the same chain (uniform values, uniform writes).
+GL_HD void tridiagonal_spd_solve(const float* d, const float* e, int n, float* c, float* w) {
+  w[0] = d[0];
+  for (int i = 1; i < n; ++i) {
+    const float m = e[i] / w[i - 1];
+    w[i] = d[i] - m * e[i];
+    c[i] -= m * c[i - 1];
+  }
+  c[n - 1] = c[n - 1] / w[n - 1];
+  for (int i = n - 2; i >= 0; --i) c[i] = (c[i] - e[i + 1] * c[i + 1]) / w[i];
+}
+
+// coeffs = pinv(A, rcond) rhs for the symmetric A [n][ld] (already divided by 1/inv_scale; destroyed).
+// Z [n][ld] and the [n]-sized scratch arrays d, v, p, bet, g, y and e [n+1] live in the same (LDS) space as A.
+// Returns 1 when the short cut was taken (diagnostics / tests).
+template <class C>
+GL_HD int pinv_solve(C& cx, float* A, float* Z, int n, int ld, const float* rhs, float rcond, float inv_scale, float* d,
+                     float* e, float* v, float* p, float* bet, float* g, float* y, float* coeffs, bool allow_shortcut) {
+  const int lane = cx.lane(), NL = cx.lanes();
+  tridiagonalize(cx, A, n, ld, d, e, v, p, bet);
+  GL_STAMP(2);
+  if (allow_shortcut) {
+    const float lmax = largest_eigenvalue(cx, d, e, n);
+    if (lmax > 0.f && sturm_count(cx, d, e, n, rcond * lmax) == 0) {
+      for (int k = lane; k < n; k += NL) y[k] = rhs[k];
+      cx.sync();
+      apply_reflectors(cx, A, n, ld, bet, y, true);
+      tridiagonal_spd_solve(d, e, n, y, v);
+      cx.sync();
+      apply_reflectors(cx, A, n, ld, bet, y, false);
+      for (int k = lane; k < n; k += NL) coeffs[k] = y[k] * inv_scale;
+      return 1;
+    }
+  }
+  accumulate_q(cx, A, Z, n, ld, bet);
+  GL_STAMP(3);
+  ql_implicit(cx, Z, n, ld, d, e);
+  pinv_apply(cx, Z, n, ld, d, rhs, rcond, inv_scale, g, coeffs);
+  return 0;
 }
 
 }  // namespace gle

@@ -126,8 +126,9 @@ __global__ void __launch_bounds__(256) gl_normal_tiled_kernel(NormalArgs a) {
 }
 
 // ---- per sample: A = sum of partials, eigendecomposition, coeffs = pinv(A_DD, rcond) A_DY -------------------------
-// One wavefront per system (gl_eigh.h): Householder tridiagonalisation + implicit QL in LDS, tf.linalg.pinv's cutoff
-// (singular values <= rcond * max, here |eigenvalues| of the symmetric normal matrix).  The workgroup IS the wave, so
+// One wavefront per system (gl_eigh.h): Householder tridiagonalisation in LDS; when Sturm counts prove that no
+// eigenvalue falls under tf.linalg.pinv's cutoff (singular values <= rcond * max, here |eigenvalues| of the symmetric
+// normal matrix) the solve is a tridiagonal LDL^T between two reflector sweeps, otherwise implicit QL with vectors.  The workgroup IS the wave, so
 // __syncthreads() is a single-wave barrier.  (The first version of this step was a parallel-ordered cyclic Jacobi
 // solve with 1024 threads per system: 3.8 ms for 1024 systems of 66 unknowns, barrier- and LDS-bound; this one does
 // ~1/10 of the arithmetic and has no barrier in its longest phase.)
@@ -147,6 +148,11 @@ struct WaveCtx {
   }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ float rsq(float x) const { return __builtin_amdgcn_rsqf(x); }
+  __device__ __forceinline__ float rcp(float x) const { return __builtin_amdgcn_rcpf(x); }
+  __device__ __forceinline__ int first_lane(bool pred) const {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+    return m ? (int)__builtin_ctzll(m) : -1;
+  }
   static __device__ __forceinline__ float rl(float v, int i) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
   }
@@ -227,6 +233,7 @@ __global__ void __launch_bounds__(64) gl_eigh_solve_kernel(const float* __restri
   float* bet = p + n;          // [n]
   float* rhs = bet + n;        // [n]
   float* g = rhs + n;          // [n]
+  float* y = g + n;            // [n]
   const int b = blockIdx.x, lane = threadIdx.x;
   const float* src = partial + (size_t)b * n_chunks * Dp * Dp;
   GL_STAMP(0);
@@ -259,10 +266,7 @@ __global__ void __launch_bounds__(64) gl_eigh_solve_kernel(const float* __restri
     for (int k = 0; k < n; ++k) A[i * ld + k] *= inv;
   __syncthreads();
   GL_STAMP(1);
-  gle::sym_eig(cx, A, Z, n, ld, d, e, v, p, bet);
-  __syncthreads();
-  GL_STAMP(5);
-  gle::pinv_apply(cx, Z, n, ld, d, rhs, rcond, inv, g, coeffs + (size_t)b * D);
+  gle::pinv_solve(cx, A, Z, n, ld, rhs, rcond, inv, d, e, v, p, bet, g, y, coeffs + (size_t)b * D, true);
   GL_STAMP(6);
 }
 

@@ -235,18 +235,20 @@ void hm_series_hessian_f64(int base_kind, int n_gal, const float* table, const i
 }
 // the pseudo-inverse solve of the linear-amplitude normal equations (gl_eigh.h), serial context:
 // A [n][n] symmetric float32, rhs [n] -> coeffs [n], eigenvalues [n] (of A / max|diag|, unsorted)
-void hm_eigh_pinv_f32(const float* A_in, int n, const float* rhs, float rcond, float* coeffs, float* eigs) {
+int hm_eigh_pinv_f32(const float* A_in, int n, const float* rhs, float rcond, int allow_shortcut, float* coeffs, float* eigs) {
   const int ld = n | 1;
-  std::vector<float> A((size_t)n * ld, 0.f), Z((size_t)n * ld, 0.f), d(n + 1), e(n + 2), v(n + 1), p(n + 1), bet(n + 1, 0.f), g(n + 1);
+  std::vector<float> A((size_t)n * ld, 0.f), Z((size_t)n * ld, 0.f), d(n + 1), e(n + 2), v(n + 1), p(n + 1), bet(n + 1, 0.f),
+      g(n + 1), y(n + 1);
   float scale = 0.f;
   for (int i = 0; i < n; ++i) scale = std::max(scale, std::fabs(A_in[(size_t)i * n + i]));
   const float inv = scale > 0.f ? 1.0f / scale : 0.f;
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) A[(size_t)i * ld + j] = A_in[(size_t)i * n + j] * inv;
   static gle::SerialCtx cx;
-  gle::sym_eig(cx, A.data(), Z.data(), n, ld, d.data(), e.data(), v.data(), p.data(), bet.data());
-  gle::pinv_apply(cx, Z.data(), n, ld, d.data(), rhs, rcond, inv, g.data(), coeffs);
-  for (int i = 0; i < n; ++i) eigs[i] = d[i];
+  const int took = gle::pinv_solve(cx, A.data(), Z.data(), n, ld, rhs, rcond, inv, d.data(), e.data(), v.data(), p.data(),
+                                   bet.data(), g.data(), y.data(), coeffs, allow_shortcut != 0);
+  for (int i = 0; i < n; ++i) eigs[i] = d[i];  // eigenvalues on the general path, diag(T) on the short cut
+  return took;
 }
 void hm_scaled_f32(int base_kind, int n_gal, const float* table, const int* cols, const float* scales, int n,
                    const float* x, const float* y, const float* gx, const float* gy, float* ax, float* ay,

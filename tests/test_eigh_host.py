@@ -11,12 +11,15 @@ def _fp(a):
     return a.ctypes.data_as(POINTER(c_float))
 
 
-def _solve(hostmath, A, rhs, rcond=1e-6):
+def _solve(hostmath, A, rhs, rcond=1e-6, shortcut=False, want_path=False):
+    """shortcut=False: the general path (eigenvectors, implicit QL); True: let the Sturm test pick the LDL^T short cut."""
     n = A.shape[0]
     A32 = np.ascontiguousarray(A, dtype=np.float32)
     r32 = np.ascontiguousarray(rhs, dtype=np.float32)
     co, ev = np.zeros(n, np.float32), np.zeros(n, np.float32)
-    hostmath.hm_eigh_pinv_f32(_fp(A32), c_int(n), _fp(r32), c_float(rcond), _fp(co), _fp(ev))
+    took = hostmath.hm_eigh_pinv_f32(_fp(A32), c_int(n), _fp(r32), c_float(rcond), c_int(int(shortcut)), _fp(co), _fp(ev))
+    if want_path:
+        return co, took, A32, r32
     return co, ev, A32, r32
 
 
@@ -73,3 +76,39 @@ def test_degenerate_inputs(hostmath):
     T = np.diag([2.0] * 6) + np.diag([-1.0] * 5, 1) + np.diag([-1.0] * 5, -1)
     co, ev, A32, r32 = _solve(hostmath, T * 1e12, np.arange(6.0) * 1e12)
     assert np.allclose(co, np.linalg.solve(T, np.arange(6.0)), rtol=2e-5)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 21, 66, 79])
+@pytest.mark.parametrize("cond", [1e1, 1e4])
+def test_short_cut_equals_the_general_path_when_nothing_is_cut(hostmath, n, cond):
+    """No eigenvalue under the cutoff: pinv = inverse, and the tridiagonal LDL^T between two reflector sweeps must give
+    what the eigenvector path gives (both within the float32 forward error of the float64 pinv)."""
+    A, X = _gram(n, 4 * n + 3, cond, seed=100 + n)
+    y = np.random.default_rng(2).normal(size=X.shape[0])
+    fast, took, A32, r32 = _solve(hostmath, A, X.T @ y, shortcut=True, want_path=True)
+    slow, took0, _, _ = _solve(hostmath, A, X.T @ y, shortcut=False, want_path=True)
+    assert took == 1 and took0 == 0
+    want = np.linalg.pinv(A32.astype(np.float64), rcond=1e-6, hermitian=True) @ r32.astype(np.float64)
+    tol = 30 * cond * 6e-8 * np.abs(want).max() + 1e-6 * np.abs(want).max()
+    assert np.abs(fast - want).max() <= tol and np.abs(slow - want).max() <= tol
+
+
+@pytest.mark.parametrize("case", ["duplicate", "zero_column", "cond_1e8", "negative"])
+def test_short_cut_is_refused_when_the_cutoff_bites(hostmath, case):
+    r = np.random.default_rng(7)
+    X = r.normal(size=(300, 14))
+    if case == "duplicate":
+        X[:, 3] = X[:, 11]
+    elif case == "zero_column":
+        X[:, 6] = 0.0
+    elif case == "cond_1e8":
+        A, X = _gram(14, 80, 1e8, seed=9)
+    A = X.T @ X
+    if case == "negative":  # not a Gram matrix: a large negative eigenvalue (kept by pinv through |lambda|)
+        A = A - 1.5 * np.outer(X[0], X[0]) * 300
+    y = r.normal(size=X.shape[0])
+    rhs = X.T @ y
+    co, took, A32, r32 = _solve(hostmath, A, rhs, shortcut=True, want_path=True)
+    assert took == 0
+    want = np.linalg.pinv(A32.astype(np.float64), rcond=1e-6, hermitian=True) @ r32.astype(np.float64)
+    assert np.abs(co - want).max() <= 5e-3 * np.abs(want).max()
