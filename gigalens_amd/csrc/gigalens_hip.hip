@@ -921,8 +921,22 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   na.partial = lw.partial;
   if (D + 1 <= LS_SMALL)
     hipLaunchKernelGGL((gl_normal_small_kernel<LS_SMALL>), dim3(lw.n_chunks, B), dim3(256), 0, stream, na);
-  else
-    hipLaunchKernelGGL(gl_normal_tiled_kernel, dim3(lw.n_chunks, B), dim3(256), sizeof(float2) * LS_TPP * lw.Dp, stream, na);
+  else {
+    // 16-byte loads need every channel row, obs and err on a 16-byte pitch
+    const int vec_ok = (HW % 4 == 0) && ((uintptr_t)obs % 16 == 0) && ((uintptr_t)err % 16 == 0) && ((uintptr_t)lw.stack % 16 == 0);
+    const dim3 grid(lw.n_chunks, B), block(256);
+#define GL_NORMAL_MFMA(NT_)                                                                          \
+  if (vec_ok) hipLaunchKernelGGL((gl_normal_mfma_kernel<NT_, true>), grid, block, 0, stream, na);   \
+  else hipLaunchKernelGGL((gl_normal_mfma_kernel<NT_, false>), grid, block, 0, stream, na)
+    switch ((D + 1 + 15) / 16) {
+      case 1: GL_NORMAL_MFMA(1); break;
+      case 2: GL_NORMAL_MFMA(2); break;
+      case 3: GL_NORMAL_MFMA(3); break;
+      case 4: GL_NORMAL_MFMA(4); break;
+      default: GL_NORMAL_MFMA(5); break;
+    }
+#undef GL_NORMAL_MFMA
+  }
   GL_HIP(hipGetLastError());
   float* coeffs = coeffs_or_null ? coeffs_or_null : lw.coeffs;
   int n_sum = lw.n_chunks;

@@ -2,12 +2,12 @@
 //   W = 1/err_map,  Y = obs W,  X = stack W  (bs, HW, depth),  coeffs = pinv(X^T X, rcond=1e-6) X^T Y.
 // Three kernels on the stack of basis images  S[b][d][p]  the IMG_BASIS pass (+ PSF / pooling) produced:
 //   gl_normal_*_kernel   per (sample, pixel chunk): the symmetric normal matrix of the augmented system [X | Y]
-//                        (last row/column = X^T Y, Y^T Y), register-tiled packed-fp32 SYRK
+//                        (last row/column = X^T Y, Y^T Y); MFMA SYRK, or register accumulators for <= 7 channels
 //   gl_eigh_solve_kernel per sample, one wavefront: sum the chunk partials (fixed order), Householder + implicit-QL
 //                        eigendecomposition in LDS (gl_eigh.h), pseudo-inverse with the reference's relative cutoff
 //   gl_combine_kernel    image = sum_d coeffs_d S_d   (tf/simulator.py:239)
-// fp32 MFMA and packed fp32 FMA have the same peak on CDNA4 (157 TFLOP/s), so the SYRK stays on the vector ALU:
-// 4x4 register tiles over pixel PAIRS (v_pk_fma_f32), operands staged through LDS as [pixel pair][channel][2].
+// The SYRK runs on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32): same peak as packed fp32 FMA on CDNA4, but
+// one operand register per lane instead of LDS-staged 4x4 register tiles, and the vector ALU stays free for the weights.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,7 +21,7 @@ namespace glk { __device__ long long g_eigh_stamps[8]; }
 namespace glk {
 
 constexpr int LS_MAXD = 80;   // channels incl. the observation column (LDS: A and V of the eigen solve)
-constexpr int LS_TPP = 32;    // pixel pairs per LDS tile
+constexpr int LS_TPP = 32;    // chunk granularity: 2 * LS_TPP = 64 pixels (4 waves x 16-pixel MFMA groups)
 constexpr int LS_SMALL = 8;   // <= this many channels (incl. Y): pixel-parallel kernel with register accumulators
 
 struct NormalArgs {
@@ -70,58 +70,120 @@ __global__ void __launch_bounds__(256) gl_normal_small_kernel(NormalArgs a) {
   }
 }
 
-// ---- many channels: 4x4 register tiles of the lower triangle, pixel pairs packed --------------------------------
-__global__ void __launch_bounds__(256) gl_normal_tiled_kernel(NormalArgs a) {
-  extern __shared__ float2 s_x[];  // [LS_TPP][Dp]
-  __shared__ float s_w[2 * LS_TPP];  // 1/err of the tile's pixels (0 beyond the chunk)
-  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const int Dp = a.Dp, nt = Dp / 4, ntiles = nt * (nt + 1) / 2;
-  int ti = 0, tj = 0;
-  const bool active = tid < ntiles;
-  if (active) {
-    while ((ti + 1) * (ti + 2) / 2 <= tid) ++ti;
-    tj = tid - ti * (ti + 1) / 2;
-  }
-  v2f acc[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[r][c] = v2f(0.f);
-  const float* S = a.stack + (size_t)b * a.D * a.HW;
+// ---- many channels: the SYRK on the matrix cores -------------------------------------------------------------------
+// C = X^T X with X = [pixels][channels]: v_mfma_f32_16x16x4_f32 takes A = X^T (16 channels x 4 pixels) and B = X
+// (4 pixels x 16 channels) in the SAME lane layout -- lane l holds channel (l & 15) of pixel slot (l >> 4) -- so one
+// register per 16-channel block serves as the A operand of its tile row and the B operand of its tile column.  A lane
+// fetches 4 consecutive pixels of its channel with one 16-byte load straight from the stack (16 lanes x 64 B per
+// channel block; no LDS staging), weighs them by 1/err and feeds them as 4 k-steps.  Only the NT (NT+1) / 2 lower
+// tiles are accumulated (4 accumulator registers each).  Exact fp32: every product is rounded once, sums are k-ordered
+// fma chains.  The 4 waves of a workgroup take interleaved 16-pixel groups of the chunk and are summed through LDS.
+// (Round-1 history: the packed-fp32 VALU version of this kernel, 4x4 register tiles fed from LDS, ran 2.9 ms on C3L.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT, bool VEC>  // VEC: every channel row, obs and err sit on a 16-byte pitch
+__global__ void __launch_bounds__(256) gl_normal_mfma_kernel(NormalArgs a) {
+  constexpr int NTILES = NT * (NT + 1) / 2;
+  __shared__ float s_red[NTILES * 256];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, l = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: group bounds below are wave-uniform
+  const int c = l & 15, q = l >> 4;
   const int p0 = chunk * a.chunk, p1 = min(p0 + a.chunk, a.HW);
-  for (int base = p0; base < p1; base += 2 * LS_TPP) {
-    __syncthreads();
-    if (tid < 2 * LS_TPP) s_w[tid] = (base + tid < p1) ? 1.0f / a.err[base + tid] : 0.f;
-    __syncthreads();
-    // stage [channel][64 pixels] -> LDS [pixel pair][channel] as (even pixel, odd pixel), weighted by 1/err
-    for (int e = tid; e < Dp * 2 * LS_TPP; e += 256) {
-      const int d = e / (2 * LS_TPP), q = e - d * (2 * LS_TPP);
-      const int p = min(base + q, p1 - 1);
-      const float v = d < a.D ? S[(size_t)d * a.HW + p] : (d == a.D ? a.obs[p] : 0.f);
-      reinterpret_cast<float*>(s_x)[((q >> 1) * Dp + d) * 2 + (q & 1)] = v * s_w[q];
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll 4
-      for (int pp = 0; pp < LS_TPP; ++pp) {
-        const float4* ra = reinterpret_cast<const float4*>(s_x + pp * Dp + 4 * ti);
-        const float4* rb = reinterpret_cast<const float4*>(s_x + pp * Dp + 4 * tj);
-        const float4 a01 = ra[0], a23 = ra[1], b01 = rb[0], b23 = rb[1];
-        const v2f av[4] = {v2f{a01.x, a01.y}, v2f{a01.z, a01.w}, v2f{a23.x, a23.y}, v2f{a23.z, a23.w}};
-        const v2f bv[4] = {v2f{b01.x, b01.y}, v2f{b01.z, b01.w}, v2f{b23.x, b23.y}, v2f{b23.z, b23.w}};
+  const float* S = a.stack + (size_t)b * a.D * a.HW;
+  // the lane's channel of block t: a basis row, the observation (channel D) or padding (reads obs, multiplied by 0)
+  const float* row[NT];
+  float keep[NT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_elementwise_fma(av[r], bv[c], acc[r][c]);
-      }
-    }
+  for (int t = 0; t < NT; ++t) {
+    const int ch = 16 * t + c;
+    row[t] = ch < a.D ? S + (size_t)ch * a.HW : a.obs;
+    keep[t] = ch <= a.D ? 1.f : 0.f;
   }
-  if (active) {
-    float* out = a.partial + ((size_t)b * a.n_chunks + chunk) * Dp * Dp;
+  f32x4 acc[NTILES];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+  for (int k = 0; k < NTILES; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // 4 consecutive pixels from pb.  Whole groups (the wave-uniform common case) load without any per-lane condition, so
+  // that the NT + 1 loads of a group are in flight together; the last, partial group of a chunk is guarded per pixel.
+  auto fetch_whole = [&](const float* src, int pb) -> float4 {
+    if constexpr (VEC) return *reinterpret_cast<const float4*>(src + pb);
+    else return float4{src[pb], src[pb + 1], src[pb + 2], src[pb + 3]};
+  };
+  auto fetch_part = [&](const float* src, int pb) -> float4 {
+    float4 v;
+    v.x = pb < p1 ? src[pb] : 0.f;
+    v.y = pb + 1 < p1 ? src[pb + 1] : 0.f;
+    v.z = pb + 2 < p1 ? src[pb + 2] : 0.f;
+    v.w = pb + 3 < p1 ? src[pb + 3] : 0.f;
+    return v;
+  };
+  auto load_group = [&](int pg, float4* x, float4& er) {
+    const int pb = pg + 4 * q;
+    if (pg + 16 <= p1) {  // uniform over the wave
+      er = fetch_whole(a.err, pb);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) out[(4 * ti + r) * Dp + 4 * tj + c] = acc[r][c].x + acc[r][c].y;
+      for (int t = 0; t < NT; ++t) x[t] = fetch_whole(row[t], pb);
+    } else {
+      er = fetch_part(a.err, pb);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) x[t] = fetch_part(row[t], pb);
+    }
+  };
+
+  float4 x[NT], xn[NT], er, ern;
+  int pg = p0 + 16 * wave;
+  if (pg < p1) load_group(pg, x, er);
+  for (; pg < p1; pg += 64) {
+    const int nxt = pg + 64;
+    if (nxt < p1) load_group(nxt, xn, ern);  // in flight while this group multiplies
+    const int pb = pg + 4 * q;
+    float w[4];
+    w[0] = pb < p1 ? 1.0f / er.x : 0.f;
+    w[1] = pb + 1 < p1 ? 1.0f / er.y : 0.f;
+    w[2] = pb + 2 < p1 ? 1.0f / er.z : 0.f;
+    w[3] = pb + 3 < p1 ? 1.0f / er.w : 0.f;
+    float xv[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      xv[t][0] = x[t].x * (w[0] * keep[t]);
+      xv[t][1] = x[t].y * (w[1] * keep[t]);
+      xv[t][2] = x[t].z * (w[2] * keep[t]);
+      xv[t][3] = x[t].w * (w[3] * keep[t]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int k = 0;
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj, ++k)
+          acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[ti][r], xv[tj][r], acc[k], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) x[t] = xn[t];
+    er = ern;
+  }
+  // sum the four waves (fixed order), then write the tiles: element (row 4 (l >> 4) + r, column l & 15) of tile k
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int k = 0; k < NTILES; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int idx = (k * 4 + r) * 64 + l;
+          s_red[idx] = (wv == 0 ? 0.f : s_red[idx]) + acc[k][r];
+        }
+    }
+    __syncthreads();
+  }
+  float* out = a.partial + ((size_t)b * a.n_chunks + chunk) * a.Dp * a.Dp;
+  for (int e = tid; e < NTILES * 256; e += 256) {
+    const int k = e >> 8, r = (e >> 6) & 3, ll = e & 63;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= k) ++ti;
+    const int tj = k - ti * (ti + 1) / 2;
+    const int i = 16 * ti + 4 * (ll >> 4) + r, j = 16 * tj + (ll & 15);
+    if (i < a.Dp && j < a.Dp) out[i * a.Dp + j] = s_red[e];
   }
 }
 

@@ -57,7 +57,9 @@ def _observation(wl, seed=3):
 
 @pytest.mark.parametrize("kind,num_pix,batch,psf,ss", [("sersic", 32, 5, False, 1), ("sersic", 30, 3, True, 2),
                                                        ("shapelets", 36, 4, False, 1), ("shapelets_direct", 32, 3, True, 1),
-                                                       ("shapelets6", 40, 2, False, 1)])
+                                                       ("shapelets6", 40, 2, False, 1),
+                                                       ("shapelets6", 37, 2, False, 1),    # 1369 pixels: no 16-byte pitch
+                                                       ("shapelets", 35, 70, False, 1)])  # one 64-pixel-multiple chunk / sample
 def test_lstsq_simulate_vs_oracle(gl, kind, num_pix, batch, psf, ss):
     from oracle import ref_torch as ref
     wl = _model(kind, num_pix, batch, psf, ss)
