@@ -225,3 +225,44 @@ def test_plugin_level_light_of_lstsq_profiles(gl, which):
         A = torch.stack([torch.as_tensor(amps[nm], device=got.device) for nm in full._amp_names])  # (depth, B)
         comb = (got * A[:, None, :]).sum(0)
         assert torch.allclose(torch.nan_to_num(img), torch.nan_to_num(comb), rtol=1e-4, atol=1e-5 * float(comb.abs().max()))
+
+
+@pytest.mark.parametrize("n_max", [3, 7])
+def test_duplicate_components_take_the_pseudo_inverse_path(gl, n_max):
+    """Two identical shapelet sources: the normal matrix is exactly rank deficient, every duplicated direction has a zero
+    eigenvalue that ``pinv(rcond=1e-6)`` must cut (tf/simulator.py:233).  The Sturm test refuses the LDL^T short cut and the
+    solve runs the eigenvector path (n_max = 7: 73 unknowns, both halves of the lane-distributed tridiagonal).  The fitted
+    image -- the projection of the data on the span of the basis -- is unique and must match the oracle's."""
+    from oracle import ref_torch as ref
+    from gigalens_amd import prior as tfd
+    from gigalens_amd import workloads
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import SersicEllipse
+    from gigalens_amd.profiles.light.shapelets import Shapelets
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.simulator import SimulatorConfig
+    base = _model("shapelets", 40, 3)
+    J, S = tfd.JointDistributionNamed, tfd.JointDistributionSequential
+    shp = J(dict(beta=tfd.LogNormal(math.log(0.2), 0.1), center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05)))
+    phys = PhysicalModel([EPL(), Shear()], [SersicEllipse(use_lstsq=True)],
+                         [Shapelets(n_max, use_lstsq=True, interpolate=False), Shapelets(n_max, use_lstsq=True, interpolate=False)])
+    bp = base.prior.model
+    prior = J(dict(lens_mass=bp["lens_mass"], lens_light=bp["lens_light"], source_light=S([shp, shp])))
+    wl = workloads.Workload("DUP", phys, prior, SimulatorConfig(delta_pix=0.08, num_pix=40), 3)
+    x = wl.prior.sample(3, seed=8)
+    x["source_light"][1] = {k: v.clone() for k, v in x["source_light"][0].items()}  # exact duplicate
+    obs, err = _observation(wl)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=3)
+    rs = ref.RefSimulator(wl.phys_model, wl.sim_config, 3, dtype=F64)
+    x64 = {g: [{k: v.double() for k, v in d.items()} for d in lst] for g, lst in x.items()}
+    img_o = ref.lstsq_simulate(rs, x64, obs, err).numpy()
+    img = sim.lstsq_simulate(x, obs, err).cpu().numpy()
+    assert np.isfinite(img).all()
+    assert np.abs(img - img_o).max() <= 5e-4 * np.abs(img_o).max()
+    c = sim.lstsq_simulate(x, obs, err, return_coeffs=True).cpu().numpy()
+    L = (n_max + 1) * (n_max + 2) // 2
+    assert c.shape[-1] == 1 + 2 * L
+    # minimum-norm solution: the duplicates share their amplitude (cut directions carry nothing)
+    a, b2 = c[..., 1:1 + L], c[..., 1 + L:]
+    assert np.abs(a - b2).max() <= 2e-2 * np.abs(a).max()
