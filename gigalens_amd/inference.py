@@ -40,6 +40,31 @@ class Adam:
         x.sub_(lr * mhat / (vhat.sqrt() + self.eps))
         return x
 
+    # -- the same update with the step counter on the device, so that one step can be captured in a HIP graph ------
+    @property
+    def capturable(self):
+        return not callable(self.lr)
+
+    def step_captured(self, x: torch.Tensor, grad: torch.Tensor):
+        """Identical arithmetic to :meth:`step`; ``t`` lives in ``self._t_dev`` (float64 scalar on the device) and the
+        bias corrections are computed from it in the graph.  ``sync_from_device`` brings ``t`` back afterwards."""
+        if self.m is None:
+            self.m, self.v = torch.zeros_like(x), torch.zeros_like(x)
+        if getattr(self, "_t_dev", None) is None or self._t_dev.device != x.device:
+            self._t_dev = torch.tensor(float(self.t), dtype=torch.float64, device=x.device)
+        self._t_dev.add_(1.0)
+        self.m.mul_(self.b1).add_(grad, alpha=1 - self.b1)
+        self.v.mul_(self.b2).addcmul_(grad, grad, value=1 - self.b2)
+        c1 = (1.0 - torch.pow(float(self.b1), self._t_dev)).to(x.dtype)  # scalar base: no host-to-device copy in capture
+        c2 = (1.0 - torch.pow(float(self.b2), self._t_dev)).to(x.dtype)
+        x.sub_(self.lr * (self.m / c1) / ((self.v / c2).sqrt() + self.eps))
+        return x
+
+    def sync_from_device(self):
+        if getattr(self, "_t_dev", None) is not None:
+            self.t = int(round(float(self._t_dev)))
+            self._t_dev = None
+
 
 # ---- full-rank Gaussian surrogate ------------------------------------------------------------------
 def tril_unpack(packed: torch.Tensor, d: int, diag_shift: float = 1e-6) -> torch.Tensor:
@@ -101,9 +126,16 @@ class ModellingSequence:
             n += pm.n_position
         return n
 
-    def MAP(self, optimizer: Adam, start=None, n_samples=500, num_steps=350, seed=0, progress=None):
+    def MAP(self, optimizer: Adam, start=None, n_samples=500, num_steps=350, seed=0, progress=None, graph=None):
         """tf/inference.py:18-45.  ``n_samples`` is the GLOBAL count; each rank optimises its own shard and the
-        solutions are gathered at the end (jax/inference.py:62-68)."""
+        solutions are gathered at the end (jax/inference.py:62-68).
+
+        ``graph``: one optimisation step -- the native launch sequence of ``log_prob_and_grad`` plus the Adam update,
+        ~15 short kernels -- is captured once in a HIP graph and replayed.  Measured on one MI355X: the stepwise loop
+        is host-issue bound at 89 us per step, the replay runs 55 us for SIE+Sersic 64x64 at 1-64 samples, break-even
+        near 60x60 x 500 samples, and 11 % SLOWER than stream launches once the kernels fill the step (128x128 x 1024).
+        ``None`` (default) therefore picks the graph below 1e6 pixel-samples per step; ``True`` / ``False`` force it.
+        Learning-rate schedules and the autograd path always launch step by step."""
         rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
         lo, hi = gdist.shard_bounds(n_samples, rank, world)
         n_local = hi - lo
@@ -115,12 +147,41 @@ class ModellingSequence:
         lens_sim = LensSimulator(self.phys_model, self.sim_config, bs=n_local)
         event_size = self._event_size(lens_sim)
         red = None
-        for step in range(num_steps):
-            log_prob, red, g = pm.log_prob_and_grad(lens_sim, trial)
-            # agg_loss = mean(-log_prob / event_size)  (tf/inference.py:36)
-            optimizer.step(trial, -g / (event_size * n_local))
-            if progress is not None:
-                progress(step, red)
+        denom = event_size * n_local  # agg_loss = mean(-log_prob / event_size)  (tf/inference.py:36)
+        if graph is None:
+            graph = lens_sim.img_X.numel() * n_local <= 1_000_000
+        use_graph = (graph and trial.is_cuda and num_steps > 8 and getattr(optimizer, "capturable", False)
+                     and getattr(pm, "_fused_ok", lambda s: False)(lens_sim))
+        step0 = 0
+        if use_graph:
+            side = torch.cuda.Stream(device=trial.device)
+            side.wait_stream(torch.cuda.current_stream(trial.device))
+            with torch.cuda.stream(side):  # warm-up off the default stream: binds the prior, sizes the workspaces
+                for step0 in range(3):
+                    _, red, g = pm.log_prob_and_grad(lens_sim, trial)
+                    optimizer.step_captured(trial, -g / denom)
+                    if progress is not None:
+                        progress(step0, red)
+                step0 = 3
+            torch.cuda.current_stream(trial.device).wait_stream(side)
+            hip_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(hip_graph):
+                _, red_static, g = pm.log_prob_and_grad(lens_sim, trial)
+                optimizer.step_captured(trial, -g / denom)
+            # capture records, it does not run: every replay below is one real step
+            for step in range(step0, num_steps):
+                hip_graph.replay()
+                if progress is not None:
+                    progress(step, red_static)
+            red = red_static.clone()
+            optimizer.sync_from_device()
+            del hip_graph
+        else:
+            for step in range(num_steps):
+                log_prob, red, g = pm.log_prob_and_grad(lens_sim, trial)
+                optimizer.step(trial, -g / denom)
+                if progress is not None:
+                    progress(step, red)
         self.last_red_chi2 = red
         return gdist.gather_rows(trial)
 

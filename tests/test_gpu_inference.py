@@ -80,3 +80,23 @@ def test_smc(setup):
     chain, _ = seq.SMC(num_particles=32, num_leapfrog_steps=3, post_sampling_steps=4, max_sampling_per_stage=2,
                        target="pixels", auxiliar="none", seed=5, max_stage=200)
     assert chain.shape == (4, 32, 13) and torch.isfinite(chain).all()
+
+
+def test_map_graph_matches_stepwise(setup):
+    """The HIP-graph replay of one MAP step (native launch sequence + Adam) walks the same trajectory as launching every
+    step, and leaves the optimiser's step counter where the loop would."""
+    from gigalens_amd.inference import Adam
+    wl, pm, seq = setup
+    start = pm.prior.sample(16, seed=3)
+    o1, o2 = Adam(2e-2), Adam(2e-2)
+    r1 = seq.MAP(o1, start, n_samples=16, num_steps=40, seed=0, graph=False)
+    red1 = seq.last_red_chi2.clone()
+    r2 = seq.MAP(o2, start, n_samples=16, num_steps=40, seed=0, graph=True)
+    red2 = seq.last_red_chi2.clone()
+    assert o1.t == o2.t == 40
+    assert torch.allclose(r1, r2, rtol=2e-4, atol=2e-5)
+    assert torch.allclose(red1, red2, rtol=1e-3)
+    # a learning-rate schedule cannot be captured: falls back to stepwise launches
+    o3 = Adam(lambda t: 2e-2)
+    r3 = seq.MAP(o3, start, n_samples=16, num_steps=40, seed=0, graph=True)
+    assert torch.allclose(r1, r3, rtol=1e-6, atol=1e-7)
