@@ -65,6 +65,8 @@ SYMBOLS = {
     "gl_model_set_series": (c_int, [c_void_p, c_int, c_float, c_void_p]),
     "gl_series_eval": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                c_void_p]),
+    "gl_adam_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                               c_float, c_int64, c_void_p, c_void_p]),
     "gl_profile_basis": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p]),
     "gl_series_precompute_hessian": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, POINTER(c_float), c_int, c_int,
@@ -289,6 +291,18 @@ def profile_eval(profile, x, y, kwargs):
     if is_mass:
         return out0.reshape(out_shape), out1.reshape(out_shape)
     return (out0.reshape(out_shape),)
+
+
+def adam_update(x, grad, m, v, grad_scale, lr, b1, b2, eps, t, t_dev=None):
+    """gl_adam_update: one fused optimiser step in place on ``x``, ``m``, ``v`` (contiguous float32 CUDA tensors)."""
+    for name, a in (("x", x), ("grad", grad), ("m", m), ("v", v)):
+        _require_cuda(a, name)
+        if a.dtype != torch.float32 or not a.is_contiguous():
+            raise NativeLibraryError(f"adam_update: {name} must be a contiguous float32 tensor")
+    if not (x.numel() == grad.numel() == m.numel() == v.numel()):
+        raise NativeLibraryError("adam_update: size mismatch")
+    _check(lib().gl_adam_update(_ptr(x), _ptr(grad), _ptr(m), _ptr(v), x.numel(), float(grad_scale), float(lr),
+                                float(b1), float(b2), float(eps), int(t), _ptr(t_dev), _stream()))
 
 
 def profile_basis(profile, x, y, kwargs):

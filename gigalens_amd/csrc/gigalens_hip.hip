@@ -1366,6 +1366,19 @@ int gl_debug_eigh_stamps(long long* out) {
 }
 #endif
 
+int gl_adam_update(float* x, const float* grad, float* m, float* v, int64_t n, float grad_scale, float lr, float beta1,
+                   float beta2, float eps, int64_t t, double* t_dev_or_null, void* hip_stream) {
+  if (!x || !grad || !m || !v) return fail(GL_EINVAL, "null argument");
+  if (n <= 0) return fail(GL_EINVAL, "n must be positive");
+  if (!t_dev_or_null && t < 1) return fail(GL_EINVAL, "the step count t starts at 1");
+  // t_dev layout: [0] the counter as a double, [1] 8 bytes of launch ticket (zero-initialised by the caller)
+  unsigned* ticket = t_dev_or_null ? reinterpret_cast<unsigned*>(t_dev_or_null + 1) : nullptr;
+  hipLaunchKernelGGL(gl_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, x, grad, m,
+                     v, (long long)n, grad_scale, lr, beta1, beta2, eps, (double)t, t_dev_or_null, ticket);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
 int gl_profile_basis(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
                      const float* params, float* out, void* hip_stream) {
   if (!comp || !x || !y || !params || !out) return fail(GL_EINVAL, "null argument");

@@ -1034,6 +1034,40 @@ __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __rest
 // the hand-over of the partial rows needs agent-scope release / L2-bypassing traffic per workgroup, which cost more
 // (0.172 ms per step) than the separate 5 us launch (0.137 ms).)
 
+// ---- the optimiser update of the MAP / SVI loops (tf/inference.py:33-39 hands the gradient to a Keras Adam) ----------
+// One launch instead of ~10 elementwise ones: x -= lr * (m / c1) / (sqrt(v / c2) + eps) with m, v updated in place,
+// grad scaled by grad_scale first; c1 = 1 - b1^t, c2 = 1 - b2^t with t from the host or, inside a captured graph,
+// from a device counter that thread 0 of block 0 advances AFTER every block has read it (it is read at kernel start
+// and written only by the last block to finish, see the ticket).
+__global__ void __launch_bounds__(256) gl_adam_kernel(float* __restrict__ x, const float* __restrict__ grad,
+                                                      float* __restrict__ m, float* __restrict__ v, long long n,
+                                                      float grad_scale, float lr, float b1, float b2, float eps,
+                                                      double t_host, double* __restrict__ t_dev,
+                                                      unsigned* __restrict__ ticket) {
+  const double t = (t_dev ? t_dev[0] : t_host) + (t_dev ? 1.0 : 0.0);
+  const float c1 = (float)(1.0 - ::pow((double)b1, t)), c2 = (float)(1.0 - ::pow((double)b2, t));
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float g = grad[i] * grad_scale;
+    const float mi = m[i] * b1 + g * (1.0f - b1);
+    const float vi = v[i] * b2 + (g * g) * (1.0f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    x[i] -= lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+  }
+  if (t_dev) {  // advance the device counter once per launch, after the last reader
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned done = atomicAdd(ticket, 1u);
+      if (done == gridDim.x - 1) {
+        t_dev[0] = t;
+        *ticket = 0u;
+      }
+    }
+  }
+}
+
 // ---- plugin-level point evaluation (MassProfile.deriv / LightProfile.light on arbitrary points) ----
 __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float* __restrict__ x,
                                                        const float* __restrict__ y, long long n_pts, int B,

@@ -9,13 +9,14 @@ forward+gradient call.  Data parallelism follows the JAX substrate: the sample b
 
 Differences from the TFP drivers, stated plainly: the HMC here is preconditioned HMC with dual-averaging
 step-size adaptation and a fixed number of leapfrog steps (TFP's gradient-based trajectory-length adaptation
-is not restated); SMC is not provided.
+is not restated); SMC (adaptive tempering + HMC mutations) follows the reference's driver.
 """
 import math
 from typing import Callable, Optional, Tuple
 
 import torch
 
+from gigalens_amd import _native
 from gigalens_amd import dist as gdist
 from gigalens_amd.simulator import LensSimulator
 
@@ -28,11 +29,21 @@ class Adam:
         self.m = self.v = None
         self.t = 0
 
-    def step(self, x: torch.Tensor, grad: torch.Tensor):
+    def _native_ok(self, x, grad):
+        return (x.is_cuda and grad.is_cuda and x.dtype == torch.float32 and grad.dtype == torch.float32
+                and x.is_contiguous() and grad.is_contiguous() and x.shape == grad.shape)
+
+    def step(self, x: torch.Tensor, grad: torch.Tensor, scale: float = 1.0):
+        """``x -= lr * mhat / (sqrt(vhat) + eps)`` for the gradient ``scale * grad``.  On the GPU the whole update is one
+        native launch (gl_adam_update); CPU tensors (the gloo tests of the sharding logic) take the same formula in torch."""
         if self.m is None:
             self.m, self.v = torch.zeros_like(x), torch.zeros_like(x)
         self.t += 1
         lr = self.lr(self.t) if callable(self.lr) else self.lr
+        if self._native_ok(x, grad):
+            _native.adam_update(x, grad, self.m, self.v, scale, lr, self.b1, self.b2, self.eps, self.t)
+            return x
+        grad = grad * scale if scale != 1.0 else grad
         self.m.mul_(self.b1).add_(grad, alpha=1 - self.b1)
         self.v.mul_(self.b2).addcmul_(grad, grad, value=1 - self.b2)
         mhat = self.m / (1 - self.b1 ** self.t)
@@ -45,24 +56,20 @@ class Adam:
     def capturable(self):
         return not callable(self.lr)
 
-    def step_captured(self, x: torch.Tensor, grad: torch.Tensor):
-        """Identical arithmetic to :meth:`step`; ``t`` lives in ``self._t_dev`` (float64 scalar on the device) and the
-        bias corrections are computed from it in the graph.  ``sync_from_device`` brings ``t`` back afterwards."""
+    def step_captured(self, x: torch.Tensor, grad: torch.Tensor, scale: float = 1.0):
+        """:meth:`step` with ``t`` in a device counter the kernel advances itself (gl_adam_update's ``t_dev``), so the
+        launch can be replayed from a graph.  ``sync_from_device`` brings ``t`` back afterwards."""
         if self.m is None:
             self.m, self.v = torch.zeros_like(x), torch.zeros_like(x)
         if getattr(self, "_t_dev", None) is None or self._t_dev.device != x.device:
-            self._t_dev = torch.tensor(float(self.t), dtype=torch.float64, device=x.device)
-        self._t_dev.add_(1.0)
-        self.m.mul_(self.b1).add_(grad, alpha=1 - self.b1)
-        self.v.mul_(self.b2).addcmul_(grad, grad, value=1 - self.b2)
-        c1 = (1.0 - torch.pow(float(self.b1), self._t_dev)).to(x.dtype)  # scalar base: no host-to-device copy in capture
-        c2 = (1.0 - torch.pow(float(self.b2), self._t_dev)).to(x.dtype)
-        x.sub_(self.lr * (self.m / c1) / ((self.v / c2).sqrt() + self.eps))
+            self._t_dev = torch.zeros(2, dtype=torch.float64, device=x.device)
+            self._t_dev[0] = float(self.t)
+        _native.adam_update(x, grad, self.m, self.v, scale, self.lr, self.b1, self.b2, self.eps, 0, self._t_dev)
         return x
 
     def sync_from_device(self):
         if getattr(self, "_t_dev", None) is not None:
-            self.t = int(round(float(self._t_dev)))
+            self.t = int(round(float(self._t_dev[0])))
             self._t_dev = None
 
 
@@ -130,12 +137,12 @@ class ModellingSequence:
         """tf/inference.py:18-45.  ``n_samples`` is the GLOBAL count; each rank optimises its own shard and the
         solutions are gathered at the end (jax/inference.py:62-68).
 
-        ``graph``: one optimisation step -- the native launch sequence of ``log_prob_and_grad`` plus the Adam update,
-        ~15 short kernels -- is captured once in a HIP graph and replayed.  Measured on one MI355X: the stepwise loop
-        is host-issue bound at 89 us per step, the replay runs 55 us for SIE+Sersic 64x64 at 1-64 samples, break-even
-        near 60x60 x 500 samples, and 11 % SLOWER than stream launches once the kernels fill the step (128x128 x 1024).
-        ``None`` (default) therefore picks the graph below 1e6 pixel-samples per step; ``True`` / ``False`` force it.
-        Learning-rate schedules and the autograd path always launch step by step."""
+        ``graph``: one optimisation step -- the native launch sequence of ``log_prob_and_grad`` plus the fused Adam
+        update, 5-6 short kernels -- is captured once in a HIP graph and replayed.  Measured on one MI355X: the stepwise
+        loop is host-issue bound at 30 us per step for SIE+Sersic 64x64 at 1-64 samples, the replay runs 25 us; at
+        60x60 x 500 samples the graph is already 9 % slower than stream launches (53 vs 49 us) and 3 % slower at
+        128x128 x 1024.  ``None`` (default) therefore picks the graph below 3e5 pixel-samples per step; ``True`` /
+        ``False`` force it.  Learning-rate schedules and the autograd path always launch step by step."""
         rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
         lo, hi = gdist.shard_bounds(n_samples, rank, world)
         n_local = hi - lo
@@ -149,7 +156,7 @@ class ModellingSequence:
         red = None
         denom = event_size * n_local  # agg_loss = mean(-log_prob / event_size)  (tf/inference.py:36)
         if graph is None:
-            graph = lens_sim.img_X.numel() * n_local <= 1_000_000
+            graph = lens_sim.img_X.numel() * n_local <= 300_000
         use_graph = (graph and trial.is_cuda and num_steps > 8 and getattr(optimizer, "capturable", False)
                      and getattr(pm, "_fused_ok", lambda s: False)(lens_sim))
         step0 = 0
@@ -159,7 +166,7 @@ class ModellingSequence:
             with torch.cuda.stream(side):  # warm-up off the default stream: binds the prior, sizes the workspaces
                 for step0 in range(3):
                     _, red, g = pm.log_prob_and_grad(lens_sim, trial)
-                    optimizer.step_captured(trial, -g / denom)
+                    optimizer.step_captured(trial, g, -1.0 / denom)
                     if progress is not None:
                         progress(step0, red)
                 step0 = 3
@@ -167,7 +174,7 @@ class ModellingSequence:
             hip_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(hip_graph):
                 _, red_static, g = pm.log_prob_and_grad(lens_sim, trial)
-                optimizer.step_captured(trial, -g / denom)
+                optimizer.step_captured(trial, g, -1.0 / denom)
             # capture records, it does not run: every replay below is one real step
             for step in range(step0, num_steps):
                 hip_graph.replay()
@@ -179,7 +186,7 @@ class ModellingSequence:
         else:
             for step in range(num_steps):
                 log_prob, red, g = pm.log_prob_and_grad(lens_sim, trial)
-                optimizer.step(trial, -g / denom)
+                optimizer.step(trial, g, -1.0 / denom)
                 if progress is not None:
                     progress(step, red)
         self.last_red_chi2 = red

@@ -261,6 +261,16 @@ int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, 
 int gl_profile_eval(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B,
                     int xy_batched, const float* params, float* out0, float* out1, void* hip_stream);
 
+/* The optimiser update of the MAP / SVI loops (the reference hands the gradient to a Keras / optax Adam,
+ * tf/inference.py:33-39; jax/inference.py:62-68) as ONE launch:
+ *   g = grad_scale * grad;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   x -= lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps)        (all [n], DEVICE, x / m / v updated in place)
+ * t: the 1-based step count from the host; or t_dev (DEVICE, 16 bytes: a double counter holding the number of steps
+ * already taken, followed by 8 zero-initialised bytes the library uses) -- the kernel then uses counter + 1 and
+ * advances the counter itself, so the call can sit in a captured HIP graph and be replayed. */
+int gl_adam_update(float* x, const float* grad, float* m, float* v, int64_t n, float grad_scale, float lr, float beta1,
+                   float beta2, float eps, int64_t t, double* t_dev_or_null, void* hip_stream);
+
 /* LightProfile.light of a `use_lstsq=True` profile (the unit-amplitude basis images: sersic.py:30-34 `Ie = ones`,
  * `ret[tf.newaxis]`; shapelets.py:61-62,71-72): out [depth][n_pts][B], depth = 1 for the Sersic family and
  * (n_max+1)(n_max+2)/2 for Shapelets.  Other arguments as gl_profile_eval; params keeps the kind's full row width,

@@ -100,3 +100,27 @@ def test_map_graph_matches_stepwise(setup):
     o3 = Adam(lambda t: 2e-2)
     r3 = seq.MAP(o3, start, n_samples=16, num_steps=40, seed=0, graph=True)
     assert torch.allclose(r1, r3, rtol=1e-6, atol=1e-7)
+
+
+def test_fused_adam_matches_the_formula():
+    """gl_adam_update (one launch) against the textbook update in float64, host step count and device counter."""
+    from gigalens_amd.inference import Adam
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(700, 13, generator=g)
+    grads = [torch.randn(700, 13, generator=g) * (10.0 ** torch.randint(-3, 3, (1,), generator=g)) for _ in range(6)]
+    lr, b1, b2, eps, scale = 3e-2, 0.9, 0.999, 1e-7, -0.25
+    x, m, v = x0.double().clone(), torch.zeros_like(x0).double(), torch.zeros_like(x0).double()
+    for t, gr in enumerate(grads, 1):
+        gg = gr.double() * scale
+        m = b1 * m + (1 - b1) * gg
+        v = b2 * v + (1 - b2) * gg * gg
+        x = x - lr * (m / (1 - b1 ** t)) / (torch.sqrt(v / (1 - b2 ** t)) + eps)
+    for captured in (False, True):
+        opt = Adam(lr, b1, b2, eps)
+        xd = x0.cuda().clone()
+        for gr in grads:
+            (opt.step_captured if captured else opt.step)(xd, gr.cuda(), scale)
+        if captured:
+            opt.sync_from_device()
+        assert opt.t == len(grads)
+        assert torch.allclose(xd.cpu().double(), x, rtol=2e-5, atol=2e-6)
