@@ -78,7 +78,7 @@ def tril_unpack(packed: torch.Tensor, d: int, diag_shift: float = 1e-6) -> torch
     """FillScaleTriL(diag_bijector=Exp, diag_shift=1e-6) (tf/inference.py:69-72).  Packing order here is
     ``torch.tril_indices`` (row-major lower triangle); TFP's fill_triangular uses a different but equivalent
     ordering -- only the coordinate labels of the variational parameters differ."""
-    idx = torch.tril_indices(d, d, device=packed.device)
+    idx = _tril_idx(d, packed.device)
     L = torch.zeros((d, d), dtype=packed.dtype, device=packed.device)
     L = L.index_put((idx[0], idx[1]), packed)
     diag = torch.diagonal(L)
@@ -93,26 +93,66 @@ def tril_pack(L: torch.Tensor, diag_shift: float = 1e-6) -> torch.Tensor:
     return M[idx[0], idx[1]]
 
 
-def svi_step(mu: torch.Tensor, l_packed: torch.Tensor, log_prob_fn: Callable[[torch.Tensor], torch.Tensor],
-             n_local: int, generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+_TRIL_IDX = {}
+
+
+def _tril_idx(d, device):
+    key = (d, str(device))
+    if key not in _TRIL_IDX:
+        _TRIL_IDX[key] = torch.tril_indices(d, d, device=device)
+    return _TRIL_IDX[key]
+
+
+def svi_step(mu: torch.Tensor, l_packed: torch.Tensor, log_prob_fn: Optional[Callable[[torch.Tensor], torch.Tensor]],
+             n_local: int, generator: Optional[torch.Generator] = None,
+             value_and_grad_fn: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None
+             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """One ELBO evaluation on this rank's particle shard, all-reduced over ranks.
 
     Returns ``(loss, grad_mu, grad_l_packed)`` identical on every rank: the mean over ranks of the per-rank
     means (== the mean over all particles, shards being equal-sized).  ``l_packed`` of length ``d`` is the mean-field
     surrogate (``MultivariateNormalDiag`` with ``Exp`` on the scales, tf/inference.py:75-83), of length
-    ``d (d + 1) / 2`` the full-rank one."""
+    ``d (d + 1) / 2`` the full-rank one.
+
+    The reparameterisation gradient is written out instead of taped: with ``z = mu + L eps`` and
+    ``G = d log p / d z`` (one native forward+gradient call through ``value_and_grad_fn``; ``log_prob_fn`` is
+    differentiated with autograd when only that is given),
+    ``d ELBO / d mu = -mean G``,  ``d ELBO / d L = -mean G eps^T`` on the lower triangle, and the ``Exp`` diagonal
+    contributes ``dL_ii / dp_ii = exp(p_ii)`` plus ``-exp(p_ii) / L_ii`` from ``-log det L`` in ``log q``."""
     d = mu.numel()
-    mu_ = mu.detach().clone().requires_grad_(True)
-    lp_ = l_packed.detach().clone().requires_grad_(True)
-    L = torch.diag(torch.exp(lp_)) if l_packed.numel() == d and d > 1 else tril_unpack(lp_, d)
+    mu, l_packed = mu.detach(), l_packed.detach()
+    diag_mode = l_packed.numel() == d and d > 1
     eps = torch.randn((n_local, d), generator=generator, dtype=mu.dtype,
                       device=generator.device if generator is not None else mu.device).to(mu.device)
-    z = mu_ + eps @ L.T
+    if diag_mode:
+        sdiag = torch.exp(l_packed)
+        z = mu + eps * sdiag
+        log_det = l_packed.sum()
+    else:
+        L = tril_unpack(l_packed, d)
+        z = mu + eps @ L.T
+        ldiag = torch.diagonal(L)
+        log_det = torch.log(ldiag).sum()
+    if value_and_grad_fn is not None:
+        lp, G = value_and_grad_fn(z)
+    else:
+        zz = z.clone().requires_grad_(True)
+        lp = log_prob_fn(zz)
+        (G,) = torch.autograd.grad(lp.sum(), zz)
+        lp = lp.detach()
     # log q(z) of MultivariateNormalTriL: -1/2 |eps|^2 - sum log diag(L) - d/2 log 2pi
-    log_q = -0.5 * (eps * eps).sum(-1) - torch.log(torch.diagonal(L)).sum() - 0.5 * d * math.log(2 * math.pi)
-    elbo = (log_q - log_prob_fn(z)).mean()  # jax/inference.py:113-119
-    g_mu, g_lp = torch.autograd.grad(elbo, (mu_, lp_))
-    buf = torch.cat([elbo.detach().reshape(1), g_mu, g_lp])  # ONE fused buffer -> ONE collective
+    log_q = -0.5 * (eps * eps).sum(-1) - log_det - 0.5 * d * math.log(2 * math.pi)
+    elbo = (log_q - lp).mean()  # jax/inference.py:113-119
+    g_mu = -G.mean(0)
+    if diag_mode:
+        g_lp = -(G * eps).mean(0) * sdiag - 1.0
+    else:
+        idx = _tril_idx(d, mu.device)
+        gl = (-(G.T @ eps) / n_local)[idx[0], idx[1]]
+        on_diag = idx[0] == idx[1]
+        e = torch.exp(l_packed)  # only its diagonal entries are used: L_ii = exp(p_ii) + shift
+        g_lp = torch.where(on_diag, gl * e - e / ldiag[idx[0]], gl)
+    buf = torch.cat([elbo.reshape(1), g_mu, g_lp])  # ONE fused buffer -> ONE collective
     gdist.allreduce_mean_(buf)
     return buf[0], buf[1:1 + d], buf[1 + d:]
 
@@ -205,15 +245,21 @@ class ModellingSequence:
         scale = (torch.eye(d, device=pm.device) * float(init_scales) if not torch.is_tensor(init_scales)
                  else init_scales.to(pm.device))
         lp = tril_pack(scale) if full_rank else torch.log(torch.diagonal(scale))
-        gen = gdist.rank_generator(seed, rank, device="cpu")
+        gen = gdist.rank_generator(seed, rank, device=pm.device if torch.device(pm.device).type == "cuda" else "cpu")
         params = torch.cat([mu, lp])
         losses = []
+
+        def value_and_grad(z):
+            lp_, _, g_ = pm.log_prob_and_grad(lens_sim, z)
+            return lp_, g_
+
         for step in range(num_steps):
-            loss, g_mu, g_lp = svi_step(params[:d], params[d:], lambda z: pm.log_prob(lens_sim, z)[0], n_local, gen)
+            loss, g_mu, g_lp = svi_step(params[:d], params[d:], None, n_local, gen, value_and_grad_fn=value_and_grad)
             optimizer.step(params, torch.cat([g_mu, g_lp]))
-            losses.append(float(loss))
+            losses.append(loss)  # stays on the device: no host round trip per step
             if progress is not None:
                 progress(step, loss)
+        losses = torch.stack(losses).tolist() if losses else []
         self.q_mean = params[:d].clone()
         self.q_scale_tril = tril_unpack(params[d:], d) if full_rank else torch.diag(torch.exp(params[d:]))
         return (self.q_mean, self.q_scale_tril), losses
@@ -233,11 +279,13 @@ class ModellingSequence:
         mean, L = q_z
         mean, L = mean.to(pm.device), L.to(pm.device)
         d = mean.numel()
-        gen = gdist.rank_generator(seed, rank, device="cpu")
-        rnd = lambda *s: torch.randn(*s, generator=gen).to(pm.device)
+        on_gpu = torch.device(pm.device).type == "cuda"
+        gen = gdist.rank_generator(seed, rank, device=pm.device if on_gpu else "cpu")  # no host round trip per draw
+        rnd = lambda *s: torch.randn(*s, generator=gen, device=gen.device).to(pm.device)
         z = mean + rnd(n_local, d) @ L.T
         # momentum ~ N(0, Sigma^-1)  <=>  p = L^-T xi ; kinetic energy 1/2 p^T Sigma p = 1/2 |L^T p|^2
         Linv_T = torch.linalg.inv(L).T
+        Sigma = L @ L.T
 
         def value_and_grad(zz):
             lp, _, g = pm.log_prob_and_grad(lens_sim, zz)
@@ -253,19 +301,20 @@ class ModellingSequence:
             zn, pn, gn, lpn = z, p0, g, lp
             pn = pn + 0.5 * eps * gn
             for i in range(n_leap):
-                zn = zn + eps * (pn @ (L @ L.T))
+                zn = zn + eps * (pn @ Sigma)
                 lpn, gn = value_and_grad(zn)
                 pn = pn + (eps if i < n_leap - 1 else 0.5 * eps) * gn
             ke0 = 0.5 * ((p0 @ L) ** 2).sum(-1)
             ke1 = 0.5 * ((pn @ L) ** 2).sum(-1)
             log_acc = (lpn - ke1) - (lp - ke0)
             log_acc = torch.where(torch.isfinite(log_acc), log_acc, torch.full_like(log_acc, -float("inf")))
-            acc = torch.log(torch.rand(n_local, generator=gen).to(pm.device)) < log_acc
+            acc = torch.log(torch.rand(n_local, generator=gen, device=gen.device).to(pm.device)) < log_acc
             z = torch.where(acc[:, None], zn, z)
             g = torch.where(acc[:, None], gn, g)
             lp = torch.where(acc, lpn, lp)
-            a = float(torch.exp(torch.clamp(log_acc, max=0.0)).mean())
-            accept_hist.append(a)
+            a_dev = torch.exp(torch.clamp(log_acc, max=0.0)).mean()
+            accept_hist.append(a_dev)  # read back once at the end; only the adaptation below needs it on the host
+            a = float(a_dev) if it < num_burnin_steps else 0.0
             if it < num_burnin_steps and adapt_mode == "simple":
                 # tfp.mcmc.SimpleStepSizeAdaptation (tf/inference.py:159-162): multiplicative nudge towards the target
                 log_eps += math.log1p(adapt_rate) if a > target_accept else -math.log1p(adapt_rate)
@@ -282,6 +331,7 @@ class ModellingSequence:
         out = torch.stack(samples)  # (num_results, n_local, d)
         if world > 1:
             out = gdist.gather_rows(out.permute(1, 0, 2).contiguous()).permute(1, 0, 2)
+        accept_hist = torch.stack(accept_hist).tolist() if accept_hist else []
         return out, {"accept": accept_hist, "step_size": math.exp(log_eps), "num_leapfrog_steps": n_leap}
 
     def SMC(self, start=None, num_particles=1000, num_ensembles=1, num_leapfrog_steps=10, post_sampling_steps=100,
