@@ -440,7 +440,9 @@ class BackwardProbModel(ProbabilisticModel):
         log_prior = self._flat.log_prob(x) + self._flat.fldj_columns(z).sum(-1)
         packed = simulator.pack(self.pack_bij.forward(x))
         coeffs = simulator._model.lstsq(packed.detach(), self.observed_image, self.err_map, 7, want="coeffs")[0]
-        lin = torch.tensor(simulator._layout.linear, dtype=torch.int64, device=packed.device)
+        lin = getattr(simulator, "_linear_cols_dev", None)  # uploaded once per simulator, not per call
+        if lin is None or lin.device != packed.device:
+            lin = simulator._linear_cols_dev = torch.tensor(simulator._layout.linear, dtype=torch.int64, device=packed.device)
         full = packed.index_copy(1, lin, coeffs / simulator.conversion_factor)  # amplitude = coeff / det(T)
         ll, chi2 = _LogLikeFn.apply(full, simulator._model, self.observed_image, self.err_map, None, 0.0, 1.0)
         return ll + log_prior, chi2 / float(self.observed_image.numel())
