@@ -14,11 +14,14 @@ for W in C2 C3 C4 C6; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_C3L -- python3 $R/tools/prof_kernel.py --workload C3L --mode lstsq --iters 8 > $OUT/kernel_stats_C3L.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_C6 -- python3 $R/tools/prof_kernel.py --workload C6 --iters 6 > $OUT/pmc_C6.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_C3L -- python3 $R/tools/prof_kernel.py --workload C3L --mode lstsq --iters 4 > $OUT/pmc_C3L.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_mix -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_mix.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmc_clk -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_clk.log 2>&1
+python3 $R/tools/map_step_time.py > $OUT/map_step_time.log 2>&1
+python3 $R/tools/svi_hmc_step_time.py > $OUT/svi_hmc_step_time.log 2>&1
 python3 $R/tools/bench_configs.py > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
 python3 $R/bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json

@@ -54,6 +54,14 @@ for w in ("C2", "C3", "C4", "C6", "C3L"):
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mix", "pmc_clk"):
     summary[d] = pmc(d)
 summary["pmc_C6"] = pmc("pmc_C6", kernel_filter=("gl_main_kernel<3",))
+c3l = summary["pmc_C3L"] = pmc("pmc_C3L", kernel_filter=("gl_normal_mfma_kernel",))
+if c3l.get("SQ_VALU_MFMA_BUSY_CYCLES") and c3l.get("GRBM_GUI_ACTIVE"):
+    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles over all SIMDs (MI355X_MICROARCH.md, PMC units); 1024 SIMDs
+    c3l["mfma_busy_frac"] = c3l["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c3l["GRBM_GUI_ACTIVE"] / 8.0)
+for name in ("map_step_time", "svi_hmc_step_time"):
+    f = os.path.join(src, name + ".log")
+    if os.path.exists(f):
+        summary[name] = [l.strip() for l in open(f) if "ms per" in l]
 fetch_kb = summary.get("pmc_fetch", {}).get("FETCH_SIZE")
 write_kb = summary.get("pmc_write", {}).get("WRITE_SIZE")
 if fetch_kb is not None and write_kb is not None:
