@@ -8,6 +8,10 @@ one MAP / SVI / HMC-leapfrog step of the reference evaluates (tf/inference.py:33
 rank owns its own 1024 samples and a step also carries the one SVI collective of the path: an all-reduce of
 the fused [ELBO, grad] buffer (1 + d + d(d+1)/2 floats; jax/inference.py:126-128).
 
+Defaults: 1000 timed steps after 100 warm-up steps (0.14 s of GPU time).  The chip needs a few tens of milliseconds of
+sustained load to settle at its working clock: a 50-step burst (7 ms) reads 0.140 ms per step, the same binary in a
+400+ step run 0.123 ms -- what a 350-step MAP or a 500-step SVI run of the reference's pipeline sees.
+
 Prints ONE JSON line on rank 0 (contract in the round prompt) with two extra objects:
   roofline     -- dominant kernel (gl_main_kernel, fused fwd+grad), HIP-event timed on its launch stream
   cpu_baseline -- the oracle (reference algorithm restated op-for-op on torch-CPU, float32 + autograd) timed on
@@ -85,8 +89,8 @@ def cpu_baseline(wl, obs, seconds=12.0, sample_batch=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
     ap.add_argument("--num-pix", type=int, default=None)

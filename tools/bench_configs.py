@@ -16,9 +16,7 @@ from gigalens_amd.model import ForwardProbModel, PhysicalModel  # noqa: E402
 from gigalens_amd.simulator import LensSimulator, SimulatorConfig  # noqa: E402
 
 
-def time_step(pm, sim, z, iters=30, warm=5):
-    for _ in range(warm):
-        pm.log_prob_and_grad(sim, z)
+def _timed(pm, sim, z, iters):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -27,6 +25,17 @@ def time_step(pm, sim, z, iters=30, warm=5):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+def time_step(pm, sim, z, warm=5, seconds=0.25):
+    """Steady-state time per step: a short probe sizes the run to ~``seconds`` of sustained load (the chip settles at its
+    working clock only after tens of milliseconds; 30-step bursts read up to 15 % slow), like bench.py's 1000 steps."""
+    for _ in range(warm):
+        pm.log_prob_and_grad(sim, z)
+    probe = _timed(pm, sim, z, 20)
+    iters = int(min(max(seconds * 1e3 / probe, 30), 3000))
+    _timed(pm, sim, z, max(iters // 4, 10))  # ramp
+    return _timed(pm, sim, z, iters)
 
 
 def run(name, wl, supersampled_kernel=None, obs=None):

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
 for W in C2 C3 C4 C6; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_$W -- python3 $R/tools/prof_kernel.py --workload $W --iters 20 > $OUT/kernel_stats_$W.log 2>&1
 done
@@ -23,5 +23,5 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $
 python3 $R/tools/map_step_time.py > $OUT/map_step_time.log 2>&1
 python3 $R/tools/svi_hmc_step_time.py > $OUT/svi_hmc_step_time.log 2>&1
 python3 $R/tools/bench_configs.py > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
-python3 $R/bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
+python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
