@@ -67,6 +67,8 @@ SYMBOLS = {
                                c_void_p]),
     "gl_adam_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_int64, c_void_p, c_void_p]),
+    "gl_svi_sample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "gl_svi_grad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "gl_profile_basis": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p]),
     "gl_series_precompute_hessian": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, POINTER(c_float), c_int, c_int,
@@ -303,6 +305,24 @@ def adam_update(x, grad, m, v, grad_scale, lr, b1, b2, eps, t, t_dev=None):
         raise NativeLibraryError("adam_update: size mismatch")
     _check(lib().gl_adam_update(_ptr(x), _ptr(grad), _ptr(m), _ptr(v), x.numel(), float(grad_scale), float(lr),
                                 float(b1), float(b2), float(eps), int(t), _ptr(t_dev), _stream()))
+
+
+def svi_sample(mu, l_packed, eps, full_rank, diag_shift=1e-6):
+    """gl_svi_sample: ``z = mu + L eps`` for the packed surrogate (float32 CUDA tensors)."""
+    n, d = eps.shape
+    z = torch.empty_like(eps)
+    _check(lib().gl_svi_sample(_ptr(mu), _ptr(l_packed), d, int(bool(full_rank)), _ptr(eps), n, float(diag_shift), _ptr(z),
+                               _stream()))
+    return z
+
+
+def svi_grad(l_packed, eps, logp, grad_z, full_rank, diag_shift=1e-6):
+    """gl_svi_grad: the fused ``[ELBO, dELBO/dmu, dELBO/dl_packed]`` buffer."""
+    n, d = eps.shape
+    buf = torch.empty(1 + d + l_packed.numel(), dtype=torch.float32, device=eps.device)
+    _check(lib().gl_svi_grad(_ptr(l_packed), d, int(bool(full_rank)), _ptr(eps), _ptr(logp), _ptr(grad_z), n,
+                             float(diag_shift), _ptr(buf), _stream()))
+    return buf
 
 
 def profile_basis(profile, x, y, kwargs):

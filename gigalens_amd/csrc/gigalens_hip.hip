@@ -1379,6 +1379,28 @@ int gl_adam_update(float* x, const float* grad, float* m, float* v, int64_t n, f
   return GL_OK;
 }
 
+int gl_svi_sample(const float* mu, const float* l_packed, int d, int full_rank, const float* eps, int n, float diag_shift,
+                  float* z, void* hip_stream) {
+  if (!mu || !l_packed || !eps || !z) return fail(GL_EINVAL, "null argument");
+  if (d <= 0 || n <= 0) return fail(GL_EINVAL, "d and n must be positive");
+  const long long total = (long long)n * d;
+  hipLaunchKernelGGL(gl_svi_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, mu,
+                     l_packed, d, full_rank, eps, n, diag_shift, z);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+int gl_svi_grad(const float* l_packed, int d, int full_rank, const float* eps, const float* logp, const float* grad_z, int n,
+                float diag_shift, float* buf, void* hip_stream) {
+  if (!l_packed || !eps || !logp || !grad_z || !buf) return fail(GL_EINVAL, "null argument");
+  if (d <= 0 || n <= 0) return fail(GL_EINVAL, "d and n must be positive");
+  const int n_out = 1 + d + (full_rank ? d * (d + 1) / 2 : d);
+  hipLaunchKernelGGL(gl_svi_grad_kernel, dim3(n_out), dim3(256), 0, (hipStream_t)hip_stream, l_packed, d, full_rank, eps,
+                     logp, grad_z, n, diag_shift, buf);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
 int gl_profile_basis(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
                      const float* params, float* out, void* hip_stream) {
   if (!comp || !x || !y || !params || !out) return fail(GL_EINVAL, "null argument");

@@ -1068,6 +1068,81 @@ __global__ void __launch_bounds__(256) gl_adam_kernel(float* __restrict__ x, con
   }
 }
 
+// ---- the Gaussian surrogate of the SVI loop (tf/inference.py:64-91; jax/inference.py:98-128) ---------------------------
+// q(z) = N(mu, L L^T) with L = FillScaleTriL(diag_bijector=Exp, diag_shift) over the row-major lower-triangle packing
+// (full rank) or L = diag(exp(p)) (mean field).  Two small launches bracket the native forward+gradient call:
+//   gl_svi_sample_kernel  z_i = mu + L eps_i
+//   gl_svi_grad_kernel    the fused collective buffer  [ELBO, dELBO/dmu (d), dELBO/dp (packed)]  from eps, log p(z_i) and
+//                         G_i = d log p / d z_i:  dELBO/dmu = -mean G,  dELBO/dL_jk = -mean G_ij eps_ik (k <= j), Exp diagonal
+//                         and -log det L of log q in closed form.  One workgroup per output, fixed-order reduction over i.
+__device__ __forceinline__ void tril_jk(int t, int& j, int& k) {
+  j = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+  while ((j + 1) * (j + 2) / 2 <= t) ++j;
+  while (j * (j + 1) / 2 > t) --j;
+  k = t - j * (j + 1) / 2;
+}
+
+__global__ void __launch_bounds__(256) gl_svi_sample_kernel(const float* __restrict__ mu, const float* __restrict__ lp,
+                                                            int d, int full_rank, const float* __restrict__ eps, int n,
+                                                            float diag_shift, float* __restrict__ z) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n * d) return;
+  const int r = (int)(i / d), j = (int)(i - (long long)r * d);
+  const float* e = eps + (size_t)r * d;
+  float v = mu[j];
+  if (full_rank) {
+    const float* row = lp + j * (j + 1) / 2;
+    for (int k = 0; k < j; ++k) v += row[k] * e[k];
+    v += (expf(row[j]) + diag_shift) * e[j];
+  } else {
+    v += expf(lp[j]) * e[j];
+  }
+  z[i] = v;
+}
+
+__global__ void __launch_bounds__(256) gl_svi_grad_kernel(const float* __restrict__ lp, int d, int full_rank,
+                                                          const float* __restrict__ eps, const float* __restrict__ logp,
+                                                          const float* __restrict__ G, int n, float diag_shift,
+                                                          float* __restrict__ buf) {
+  __shared__ float red[4];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  int j = 0, k = 0;
+  const int kind = o == 0 ? 0 : (o <= d ? 1 : 2);  // ELBO, d/dmu_j, d/dp_t
+  if (kind == 1) j = o - 1;
+  if (kind == 2) {
+    if (full_rank) tril_jk(o - 1 - d, j, k);
+    else j = k = o - 1 - d;
+  }
+  float acc = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    if (kind == 0) {
+      const float* e = eps + (size_t)i * d;
+      float q = 0.f;
+      for (int c = 0; c < d; ++c) q += e[c] * e[c];
+      acc += -0.5f * q - logp[i];
+    } else if (kind == 1) {
+      acc -= G[(size_t)i * d + j];
+    } else {
+      acc -= G[(size_t)i * d + j] * eps[(size_t)i * d + k];
+    }
+  }
+  acc = wave_sum63(acc);
+  if ((tid & 63) == 63) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid != 0) return;
+  float v = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+  if (kind == 0) {
+    float log_det = 0.f;
+    for (int c = 0; c < d; ++c) log_det += full_rank ? logf(expf(lp[c * (c + 1) / 2 + c]) + diag_shift) : lp[c];
+    v += -log_det - 0.5f * (float)d * 1.8378770664093453f;  // log 2 pi
+  } else if (kind == 2 && j == k) {
+    const float p = lp[full_rank ? j * (j + 1) / 2 + j : j];
+    const float e = expf(p);
+    v = full_rank ? v * e - e / (e + diag_shift) : v * e - 1.f;
+  }
+  buf[o] = v;
+}
+
 // ---- plugin-level point evaluation (MassProfile.deriv / LightProfile.light on arbitrary points) ----
 __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float* __restrict__ x,
                                                        const float* __restrict__ y, long long n_pts, int B,

@@ -124,6 +124,14 @@ def svi_step(mu: torch.Tensor, l_packed: torch.Tensor, log_prob_fn: Optional[Cal
     diag_mode = l_packed.numel() == d and d > 1
     eps = torch.randn((n_local, d), generator=generator, dtype=mu.dtype,
                       device=generator.device if generator is not None else mu.device).to(mu.device)
+    if value_and_grad_fn is not None and mu.is_cuda and mu.dtype == torch.float32:
+        # on the GPU the surrogate is two native launches around the forward+gradient call (gl_svi_sample / gl_svi_grad)
+        mu_c, lp_c, eps = mu.contiguous(), l_packed.contiguous(), eps.contiguous()
+        z = _native.svi_sample(mu_c, lp_c, eps, not diag_mode)
+        lp, G = value_and_grad_fn(z)
+        buf = _native.svi_grad(lp_c, eps, lp.contiguous(), G.contiguous(), not diag_mode)
+        gdist.allreduce_mean_(buf)
+        return buf[0], buf[1:1 + d], buf[1 + d:]
     if diag_mode:
         sdiag = torch.exp(l_packed)
         z = mu + eps * sdiag
@@ -284,7 +292,8 @@ class ModellingSequence:
         rnd = lambda *s: torch.randn(*s, generator=gen, device=gen.device).to(pm.device)
         z = mean + rnd(n_local, d) @ L.T
         # momentum ~ N(0, Sigma^-1)  <=>  p = L^-T xi ; kinetic energy 1/2 p^T Sigma p = 1/2 |L^T p|^2
-        Linv_T = torch.linalg.inv(L).T
+        # d x d, once per run: inverted on the host (a first rocSOLVER call costs ~0.3 s of library start-up)
+        Linv_T = torch.linalg.inv(L.detach().cpu().double()).T.to(device=pm.device, dtype=L.dtype)
         Sigma = L @ L.T
 
         def value_and_grad(zz):

@@ -271,6 +271,17 @@ int gl_profile_eval(const gl_component* comp, const float* x, const float* y, in
 int gl_adam_update(float* x, const float* grad, float* m, float* v, int64_t n, float grad_scale, float lr, float beta1,
                    float beta2, float eps, int64_t t, double* t_dev_or_null, void* hip_stream);
 
+/* The Gaussian surrogate of the SVI step (tf/inference.py:64-91: MultivariateNormalTriL over FillScaleTriL(Exp,
+ * diag_shift) / MultivariateNormalDiag over Exp; sharded like jax/inference.py:98-128), as the two launches that bracket
+ * the forward+gradient call.  l_packed: the row-major lower triangle (d(d+1)/2, full_rank != 0) or the d log-scales.
+ * gl_svi_sample: z [n,d] = mu + L eps, eps [n,d] standard normal draws.
+ * gl_svi_grad:   buf [1 + d + len(l_packed)] = [ELBO = mean(log q - log p), dELBO/dmu, dELBO/dl_packed] from eps, logp [n]
+ *                and grad_z [n,d] = d log p / d z  -- exactly the buffer the one RCCL all-reduce of the step carries. */
+int gl_svi_sample(const float* mu, const float* l_packed, int d, int full_rank, const float* eps, int n, float diag_shift,
+                  float* z, void* hip_stream);
+int gl_svi_grad(const float* l_packed, int d, int full_rank, const float* eps, const float* logp, const float* grad_z, int n,
+                float diag_shift, float* buf, void* hip_stream);
+
 /* LightProfile.light of a `use_lstsq=True` profile (the unit-amplitude basis images: sersic.py:30-34 `Ie = ones`,
  * `ret[tf.newaxis]`; shapelets.py:61-62,71-72): out [depth][n_pts][B], depth = 1 for the Sersic family and
  * (n_max+1)(n_max+2)/2 for Shapelets.  Other arguments as gl_profile_eval; params keeps the kind's full row width,
