@@ -69,6 +69,10 @@ SYMBOLS = {
                                c_float, c_int64, c_void_p, c_void_p]),
     "gl_svi_sample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "gl_svi_grad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "gl_hmc_kick_drift": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
+    "gl_hmc_accept": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                              c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "gl_profile_basis": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p]),
     "gl_series_precompute_hessian": (c_int, [c_int, c_int, POINTER(c_int32), c_void_p, POINTER(c_float), c_int, c_int,
@@ -323,6 +327,20 @@ def svi_grad(l_packed, eps, logp, grad_z, full_rank, diag_shift=1e-6):
     _check(lib().gl_svi_grad(_ptr(l_packed), d, int(bool(full_rank)), _ptr(eps), _ptr(logp), _ptr(grad_z), n,
                              float(diag_shift), _ptr(buf), _stream()))
     return buf
+
+
+def hmc_kick_drift(p_in, grad, kick, z_in, sigma, eps, p_out, z_out):
+    """gl_hmc_kick_drift on contiguous float32 CUDA tensors ``[n, d]`` (``sigma`` ``[d, d]``)."""
+    n, d = p_in.shape
+    _check(lib().gl_hmc_kick_drift(_ptr(p_in), _ptr(grad), float(kick), _ptr(z_in), _ptr(sigma), float(eps), n, d,
+                                   _ptr(p_out), _ptr(z_out), _stream()))
+
+
+def hmc_accept(z, g, lp, zn, gn, lpn, p0, pn, kick, scale_tril, uniforms, accept_prob):
+    """gl_hmc_accept: Metropolis step of one transition, state updated in place."""
+    n, d = z.shape
+    _check(lib().gl_hmc_accept(_ptr(z), _ptr(g), _ptr(lp), _ptr(zn), _ptr(gn), _ptr(lpn), _ptr(p0), _ptr(pn), float(kick),
+                               _ptr(scale_tril), _ptr(uniforms), n, d, _ptr(accept_prob), _stream()))
 
 
 def profile_basis(profile, x, y, kwargs):

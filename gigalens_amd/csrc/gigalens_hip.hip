@@ -1401,6 +1401,28 @@ int gl_svi_grad(const float* l_packed, int d, int full_rank, const float* eps, c
   return GL_OK;
 }
 
+int gl_hmc_kick_drift(const float* p_in, const float* grad, float kick, const float* z_in, const float* sigma, float eps, int n,
+                      int d, float* p_out, float* z_out, void* hip_stream) {
+  if (!p_in || !grad || !z_in || !sigma || !p_out || !z_out) return fail(GL_EINVAL, "null argument");
+  if (n <= 0 || d <= 0 || d > HMC_MAXD) return fail(GL_EINVAL, "n must be positive and d in [1, %d]", HMC_MAXD);
+  hipLaunchKernelGGL(gl_hmc_kick_drift_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)hip_stream, p_in, grad, kick,
+                     z_in, sigma, eps, n, d, p_out, z_out);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+int gl_hmc_accept(float* z, float* grad, float* logp, const float* z_new, const float* grad_new, const float* logp_new,
+                  const float* p0, const float* p_new, float kick, const float* scale_tril, const float* uniforms, int n, int d,
+                  float* accept_prob, void* hip_stream) {
+  if (!z || !grad || !logp || !z_new || !grad_new || !logp_new || !p0 || !p_new || !scale_tril || !uniforms || !accept_prob)
+    return fail(GL_EINVAL, "null argument");
+  if (n <= 0 || d <= 0 || d > HMC_MAXD) return fail(GL_EINVAL, "n must be positive and d in [1, %d]", HMC_MAXD);
+  hipLaunchKernelGGL(gl_hmc_accept_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)hip_stream, z, grad, logp, z_new,
+                     grad_new, logp_new, p0, p_new, kick, scale_tril, uniforms, n, d, accept_prob);
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
 int gl_profile_basis(const gl_component* comp, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
                      const float* params, float* out, void* hip_stream) {
   if (!comp || !x || !y || !params || !out) return fail(GL_EINVAL, "null argument");

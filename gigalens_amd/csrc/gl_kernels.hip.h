@@ -1143,6 +1143,63 @@ __global__ void __launch_bounds__(256) gl_svi_grad_kernel(const float* __restric
   buf[o] = v;
 }
 
+// ---- the leapfrog of the preconditioned HMC loop (tf/inference.py:95-182) ----------------------------------------------
+// Momentum precision = the surrogate covariance Sigma = L L^T, so a drift is z += eps * (p Sigma).  One launch does the
+// momentum kick that precedes a drift and the drift itself; one launch closes a transition: last half kick, kinetic
+// energies 1/2 |p L|^2, Metropolis test against the supplied uniforms, and the in-place selection of the state.
+constexpr int HMC_MAXD = 64;
+
+__global__ void __launch_bounds__(128) gl_hmc_kick_drift_kernel(const float* __restrict__ p_in, const float* __restrict__ grad,
+                                                                float kick, const float* __restrict__ z_in,
+                                                                const float* __restrict__ sigma, float eps, int n, int d,
+                                                                float* __restrict__ p_out, float* __restrict__ z_out) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  float p[HMC_MAXD];
+  for (int j = 0; j < d; ++j) {
+    p[j] = p_in[(size_t)i * d + j] + kick * grad[(size_t)i * d + j];
+    p_out[(size_t)i * d + j] = p[j];
+  }
+  for (int j = 0; j < d; ++j) {
+    float s = 0.f;
+    for (int k = 0; k < d; ++k) s += p[k] * sigma[k * d + j];
+    z_out[(size_t)i * d + j] = z_in[(size_t)i * d + j] + eps * s;
+  }
+}
+
+__global__ void __launch_bounds__(128) gl_hmc_accept_kernel(float* __restrict__ z, float* __restrict__ g,
+                                                            float* __restrict__ lp, const float* __restrict__ zn,
+                                                            const float* __restrict__ gn, const float* __restrict__ lpn,
+                                                            const float* __restrict__ p0, const float* __restrict__ pn,
+                                                            float kick, const float* __restrict__ L,
+                                                            const float* __restrict__ u, int n, int d,
+                                                            float* __restrict__ acc_prob) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  float a[HMC_MAXD], b[HMC_MAXD];
+  for (int j = 0; j < d; ++j) {
+    a[j] = p0[(size_t)i * d + j];
+    b[j] = pn[(size_t)i * d + j] + kick * gn[(size_t)i * d + j];
+  }
+  float ke0 = 0.f, ke1 = 0.f;
+  for (int k = 0; k < d; ++k) {  // (p L)_k = sum_j p_j L_jk, L lower triangular
+    float s0 = 0.f, s1 = 0.f;
+    for (int j = k; j < d; ++j) { s0 += a[j] * L[j * d + k]; s1 += b[j] * L[j * d + k]; }
+    ke0 += s0 * s0;
+    ke1 += s1 * s1;
+  }
+  float log_acc = (lpn[i] - 0.5f * ke1) - (lp[i] - 0.5f * ke0);
+  if (!(fabsf(log_acc) <= 3.0e38f)) log_acc = -INFINITY;  // NaN / inf proposals are rejected
+  acc_prob[i] = expf(fminf(log_acc, 0.f));
+  if (logf(u[i]) < log_acc) {
+    for (int j = 0; j < d; ++j) {
+      z[(size_t)i * d + j] = zn[(size_t)i * d + j];
+      g[(size_t)i * d + j] = gn[(size_t)i * d + j];
+    }
+    lp[i] = lpn[i];
+  }
+}
+
 // ---- plugin-level point evaluation (MassProfile.deriv / LightProfile.light on arbitrary points) ----
 __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float* __restrict__ x,
                                                        const float* __restrict__ y, long long n_pts, int B,

@@ -304,24 +304,40 @@ class ModellingSequence:
         n_leap = int(min(max(init_l, 1), max_leapfrog_steps))
         log_eps, log_eps_bar, h_bar, mu_da = math.log(init_eps), 0.0, 0.0, math.log(10 * init_eps)
         samples, accept_hist = [], []
+        native = on_gpu and d <= 64 and z.dtype == torch.float32
+        if native:  # one launch per kick+drift, one per Metropolis step (gl_hmc_kick_drift / gl_hmc_accept)
+            z, g, lp = z.contiguous(), g.contiguous().clone(), lp.contiguous().clone()
+            L_c, Sigma_c = L.contiguous(), Sigma.contiguous()
+            zn, pn = torch.empty_like(z), torch.empty_like(z)
+            acc_buf = torch.empty(n_local, dtype=torch.float32, device=z.device)
         for it in range(num_burnin_steps + num_results):
             eps = math.exp(log_eps)
             p0 = rnd(n_local, d) @ Linv_T.T
-            zn, pn, gn, lpn = z, p0, g, lp
-            pn = pn + 0.5 * eps * gn
-            for i in range(n_leap):
-                zn = zn + eps * (pn @ Sigma)
-                lpn, gn = value_and_grad(zn)
-                pn = pn + (eps if i < n_leap - 1 else 0.5 * eps) * gn
-            ke0 = 0.5 * ((p0 @ L) ** 2).sum(-1)
-            ke1 = 0.5 * ((pn @ L) ** 2).sum(-1)
-            log_acc = (lpn - ke1) - (lp - ke0)
-            log_acc = torch.where(torch.isfinite(log_acc), log_acc, torch.full_like(log_acc, -float("inf")))
-            acc = torch.log(torch.rand(n_local, generator=gen, device=gen.device).to(pm.device)) < log_acc
-            z = torch.where(acc[:, None], zn, z)
-            g = torch.where(acc[:, None], gn, g)
-            lp = torch.where(acc, lpn, lp)
-            a_dev = torch.exp(torch.clamp(log_acc, max=0.0)).mean()
+            if native:
+                _native.hmc_kick_drift(p0, g, 0.5 * eps, z, Sigma_c, eps, pn, zn)
+                for i in range(n_leap):
+                    lpn, gn = value_and_grad(zn)
+                    if i < n_leap - 1:
+                        _native.hmc_kick_drift(pn, gn, eps, zn, Sigma_c, eps, pn, zn)
+                u = torch.rand(n_local, generator=gen, device=gen.device)
+                _native.hmc_accept(z, g, lp, zn, gn.contiguous(), lpn.contiguous(), p0, pn, 0.5 * eps, L_c, u, acc_buf)
+                a_dev = acc_buf.mean()
+            else:
+                zn, pn, gn, lpn = z, p0, g, lp
+                pn = pn + 0.5 * eps * gn
+                for i in range(n_leap):
+                    zn = zn + eps * (pn @ Sigma)
+                    lpn, gn = value_and_grad(zn)
+                    pn = pn + (eps if i < n_leap - 1 else 0.5 * eps) * gn
+                ke0 = 0.5 * ((p0 @ L) ** 2).sum(-1)
+                ke1 = 0.5 * ((pn @ L) ** 2).sum(-1)
+                log_acc = (lpn - ke1) - (lp - ke0)
+                log_acc = torch.where(torch.isfinite(log_acc), log_acc, torch.full_like(log_acc, -float("inf")))
+                acc = torch.log(torch.rand(n_local, generator=gen, device=gen.device).to(pm.device)) < log_acc
+                z = torch.where(acc[:, None], zn, z)
+                g = torch.where(acc[:, None], gn, g)
+                lp = torch.where(acc, lpn, lp)
+                a_dev = torch.exp(torch.clamp(log_acc, max=0.0)).mean()
             accept_hist.append(a_dev)  # read back once at the end; only the adaptation below needs it on the host
             a = float(a_dev) if it < num_burnin_steps else 0.0
             if it < num_burnin_steps and adapt_mode == "simple":

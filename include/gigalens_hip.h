@@ -282,6 +282,18 @@ int gl_svi_sample(const float* mu, const float* l_packed, int d, int full_rank, 
 int gl_svi_grad(const float* l_packed, int d, int full_rank, const float* eps, const float* logp, const float* grad_z, int n,
                 float diag_shift, float* buf, void* hip_stream);
 
+/* The leapfrog of the preconditioned HMC loop (tf/inference.py:95-182; momentum precision = the SVI covariance
+ * Sigma = L L^T, d <= 64).  All arrays [n,d] row-major DEVICE float32 unless noted.
+ * gl_hmc_kick_drift: p_out = p_in + kick * grad;  z_out = z_in + eps * (p_out Sigma)   (in place when out == in).
+ * gl_hmc_accept: closes a transition.  p1 = p_new + kick * grad_new; log_acc = (logp_new - |p1 L|^2/2) - (logp - |p0 L|^2/2),
+ *   non-finite -> rejected; chain i moves (z, grad, logp overwritten by the proposal) when log(uniforms[i]) < log_acc;
+ *   accept_prob [n] = exp(min(log_acc, 0)).  scale_tril: L [d,d] lower triangular. */
+int gl_hmc_kick_drift(const float* p_in, const float* grad, float kick, const float* z_in, const float* sigma, float eps, int n,
+                      int d, float* p_out, float* z_out, void* hip_stream);
+int gl_hmc_accept(float* z, float* grad, float* logp, const float* z_new, const float* grad_new, const float* logp_new,
+                  const float* p0, const float* p_new, float kick, const float* scale_tril, const float* uniforms, int n, int d,
+                  float* accept_prob, void* hip_stream);
+
 /* LightProfile.light of a `use_lstsq=True` profile (the unit-amplitude basis images: sersic.py:30-34 `Ie = ones`,
  * `ret[tf.newaxis]`; shapelets.py:61-62,71-72): out [depth][n_pts][B], depth = 1 for the Sersic family and
  * (n_max+1)(n_max+2)/2 for Shapelets.  Other arguments as gl_profile_eval; params keeps the kind's full row width,

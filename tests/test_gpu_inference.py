@@ -155,3 +155,44 @@ def test_native_svi_surrogate_matches_the_torch_path(full_rank):
     assert got[1].shape == (d,) and got[2].shape == lp.shape
     for x, y in zip(got, want):
         assert torch.allclose(x, y, rtol=2e-4, atol=2e-5 * float(y.abs().max() + 1))
+
+
+def test_hmc_kernels_match_the_torch_leapfrog():
+    """gl_hmc_kick_drift / gl_hmc_accept against the torch formulation of the same leapfrog pieces (tf/inference.py:95-182:
+    momentum precision = the surrogate covariance), non-finite proposals rejected."""
+    from gigalens_amd import _native
+    g0 = torch.Generator().manual_seed(4)
+    n, d = 300, 13
+    L = (torch.tril(torch.randn(d, d, generator=g0) * 0.1) + torch.diag(torch.rand(d, generator=g0) + 0.3)).cuda()
+    Sigma = (L @ L.T).contiguous()
+    z, p, gr = (torch.randn(n, d, generator=g0).cuda() for _ in range(3))
+    eps, kick = 0.07, 0.035
+    p_ref = p + kick * gr
+    z_ref = z + eps * (p_ref @ Sigma)
+    p_out, z_out = torch.empty_like(p), torch.empty_like(z)
+    _native.hmc_kick_drift(p, gr, kick, z, Sigma, eps, p_out, z_out)
+    assert torch.allclose(p_out, p_ref, rtol=1e-6, atol=1e-6) and torch.allclose(z_out, z_ref, rtol=1e-5, atol=1e-6)
+    pi, zi = p.clone(), z.clone()  # in place
+    _native.hmc_kick_drift(pi, gr, kick, zi, Sigma, eps, pi, zi)
+    assert torch.equal(pi, p_out) and torch.equal(zi, z_out)
+    # Metropolis step
+    lp = torch.randn(n, generator=g0).cuda()
+    lpn = (lp.cpu() + 0.5 * torch.randn(n, generator=g0)).cuda()
+    lpn[5] = float("nan")
+    lpn[6] = float("-inf")
+    zn, gn, p0, pn = (torch.randn(n, d, generator=g0).cuda() for _ in range(4))
+    u = torch.rand(n, generator=g0).cuda()
+    p1 = pn + kick * gn
+    ke0, ke1 = 0.5 * ((p0 @ L) ** 2).sum(-1), 0.5 * ((p1 @ L) ** 2).sum(-1)
+    log_acc = (lpn - ke1) - (lp - ke0)
+    log_acc = torch.where(torch.isfinite(log_acc), log_acc, torch.full_like(log_acc, -float("inf")))
+    acc = torch.log(u) < log_acc
+    margin = (torch.log(u) - log_acc).abs() > 1e-4  # decisions at rounding distance may differ
+    zs, gs, lps, accp = z.clone(), gr.clone(), lp.clone(), torch.empty(n, device="cuda")
+    _native.hmc_accept(zs, gs, lps, zn, gn, lpn, p0, pn, kick, L.contiguous(), u, accp)
+    moved = (zs == zn).all(-1)
+    assert torch.equal(moved[margin], acc[margin]) and not moved[5] and not moved[6]
+    assert torch.allclose(accp, torch.exp(torch.clamp(log_acc, max=0.0)), rtol=2e-4, atol=1e-6)
+    sel = moved[:, None]
+    assert torch.equal(zs, torch.where(sel, zn, z)) and torch.equal(gs, torch.where(sel, gn, gr))
+    assert torch.equal(lps[~torch.isnan(lpn)], torch.where(moved, lpn, lp)[~torch.isnan(lpn)])
