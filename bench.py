@@ -9,8 +9,9 @@ rank owns its own 1024 samples and a step also carries the one SVI collective of
 the fused [ELBO, grad] buffer (1 + d + d(d+1)/2 floats; jax/inference.py:126-128).
 
 Defaults: 1000 timed steps after 100 warm-up steps (0.14 s of GPU time).  The chip needs a few tens of milliseconds of
-sustained load to settle at its working clock: a 50-step burst (7 ms) reads 0.140 ms per step, the same binary in a
-400+ step run 0.123 ms -- what a 350-step MAP or a 500-step SVI run of the reference's pipeline sees.
+sustained load to settle at its working clock: a cold 50-step burst (7 ms) reads 0.140 ms per step, the same binary in
+a 400+ step run 0.120 ms -- what a 350-step MAP or a 500-step SVI run of the reference's pipeline sees.  Therefore an
+untimed pre-roll of 0.15 s of steps precedes the W warm-up steps whatever W and K are (``--preroll-seconds``).
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) with two extra objects:
   roofline     -- dominant kernel (gl_main_kernel, fused fwd+grad), HIP-event timed on its launch stream
@@ -95,6 +96,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
     ap.add_argument("--num-pix", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll-seconds", type=float, default=0.15,
+                    help="untimed sustained load before the warm-up steps (clock settling); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -132,6 +135,15 @@ def main():
             gdist.allreduce_mean_(coll)
         return lp, g
 
+    # untimed pre-roll: sustained load until the chip has settled at its working clock (see the module docstring), so
+    # that the timed region reads the same whatever W and K the caller picks; then the W warm-up steps of the contract
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while time.perf_counter() - t_pre < args.preroll_seconds:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        n_pre += 50
     for _ in range(args.warmup):
         step()
     gdist.barrier()
@@ -194,6 +206,7 @@ def main():
             "config": {"workload": f"{wl.name}: {wl.description}, {wl.sim_config.num_pix}x{wl.sim_config.num_pix} px, "
                                    f"batch {B} per GPU, fp32 (BASELINE.json configs[1])",
                        "samples_per_gpu": B, "pixels": N, "params_per_sample": P, "z_dim": d,
+                       "untimed_preroll_steps": n_pre,
                        "parallelism": f"dp{world} (sample shards, one {coll.numel()}-float all-reduce per step)"
                                       if world > 1 else "single GPU",
                        "step": "ForwardProbModel.log_prob_and_grad: log_prob forward + gradient w.r.t. z (bijector, "
