@@ -318,7 +318,9 @@ GL_HD int pinv_solve(C& cx, float* A, float* Z, int n, int ld, const float* rhs,
   GL_STAMP(2);
   if (allow_shortcut) {
     const float lmax = largest_eigenvalue(cx, d, e, n);
-    if (lmax > 0.f && sturm_count(cx, d, e, n, rcond * lmax) == 0) {
+    // 4x margin: a spectrum that comes within a factor 4 of the cutoff is left to the eigenvalue path, whose cut
+    // decision is taken on converged eigenvalues (the Sturm count uses an approximate reciprocal and a bound of lmax)
+    if (lmax > 0.f && sturm_count(cx, d, e, n, 4.0f * rcond * lmax) == 0) {
       for (int k = lane; k < n; k += NL) y[k] = rhs[k];
       cx.sync();
       apply_reflectors(cx, A, n, ld, bet, y, true);

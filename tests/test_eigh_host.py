@@ -112,3 +112,18 @@ def test_short_cut_is_refused_when_the_cutoff_bites(hostmath, case):
     assert took == 0
     want = np.linalg.pinv(A32.astype(np.float64), rcond=1e-6, hermitian=True) @ r32.astype(np.float64)
     assert np.abs(co - want).max() <= 5e-3 * np.abs(want).max()
+
+
+def test_spectrum_near_the_cutoff_is_left_to_the_eigenvalue_path(hostmath):
+    """lambda_min = 2.5e-6 lambda_max: nothing is cut, but the spectrum comes within the 4x safety margin of the
+    cutoff, so the cut decision is taken on converged eigenvalues, not on a Sturm count."""
+    n = 12
+    r = np.random.default_rng(11)
+    Q, _ = np.linalg.qr(r.normal(size=(n, n)))
+    lam = np.geomspace(1.0, 2.5e-6, n)
+    A = (Q * lam) @ Q.T
+    rhs = A @ r.normal(size=n)
+    co, took, A32, r32 = _solve(hostmath, A, rhs, shortcut=True, want_path=True)
+    assert took == 0 and np.isfinite(co).all()
+    res = A32.astype(np.float64) @ co.astype(np.float64) - r32
+    assert np.abs(res).max() <= 1e-4 * np.abs(r32).max()
