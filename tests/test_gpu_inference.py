@@ -126,16 +126,16 @@ def test_fused_adam_matches_the_formula():
         assert torch.allclose(xd.cpu().double(), x, rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("full_rank", [True, False])
-def test_native_svi_surrogate_matches_the_torch_path(full_rank):
+@pytest.mark.parametrize("full_rank,d", [(True, 13), (False, 13), (True, 1), (True, 40)])
+def test_native_svi_surrogate_matches_the_torch_path(full_rank, d):
     """gl_svi_sample / gl_svi_grad (the two launches around the forward+gradient call) against the torch formulation of
     the same step on identical draws: ELBO, d/dmu and d/d(packed scale), Exp diagonal and diag_shift included."""
     from gigalens_amd import inference as inf
     dev = "cuda"
-    d, n = 13, 777
+    n = 777
     g = torch.Generator().manual_seed(1)
     mu = (torch.randn(d, generator=g) * 0.3).to(dev)
-    scale = torch.tril(torch.randn(d, d, generator=g) * 0.05) + torch.diag(torch.rand(d, generator=g) * 0.2 + 0.05)
+    scale = torch.tril(torch.randn(d, d, generator=g) * 0.05, diagonal=-1) + torch.diag(torch.rand(d, generator=g) * 0.2 + 0.05)
     lp = (inf.tril_pack(scale) if full_rank else torch.log(torch.diagonal(scale))).to(dev)
     a = torch.linspace(0.5, 2.0, d, device=dev)
 
