@@ -35,7 +35,7 @@ def _model(kind, num_pix, batch, psf=False, ss=1):
         prior = J(dict(lens_mass=S([epl, shear]), lens_light=S([sere]), source_light=S([ser(0.25), ser(0.12)])))
     else:                  # shapelets n_max=3 (10) + lens light (1): the register-tiled normal-matrix kernel
         shp = J(dict(beta=tfd.LogNormal(math.log(0.15), 0.1), center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05)))
-        n_max = 6 if kind == "shapelets6" else 3
+        n_max = int(kind[len("shapelets"):]) if kind[len("shapelets"):].isdigit() else 3
         phys = PhysicalModel([EPL(), Shear()], [SersicEllipse(use_lstsq=True)],
                              [Shapelets(n_max, use_lstsq=True, interpolate=(kind != "shapelets_direct"))])
         prior = J(dict(lens_mass=S([epl, shear]), lens_light=S([sere]), source_light=S([shp])))
@@ -59,7 +59,9 @@ def _observation(wl, seed=3):
                                                        ("shapelets", 36, 4, False, 1), ("shapelets_direct", 32, 3, True, 1),
                                                        ("shapelets6", 40, 2, False, 1),
                                                        ("shapelets6", 37, 2, False, 1),    # 1369 pixels: no 16-byte pitch
-                                                       ("shapelets", 35, 70, False, 1)])  # one 64-pixel-multiple chunk / sample
+                                                       ("shapelets", 35, 70, False, 1),    # one 64-pixel-multiple chunk / sample
+                                                       ("shapelets7", 40, 2, False, 1),    # 38 channels: 3 MFMA blocks
+                                                       ("shapelets9", 44, 2, False, 1)])   # 57 channels: 4 MFMA blocks
 def test_lstsq_simulate_vs_oracle(gl, kind, num_pix, batch, psf, ss):
     from oracle import ref_torch as ref
     wl = _model(kind, num_pix, batch, psf, ss)
