@@ -78,10 +78,18 @@ GL_HD void tridiagonalize(C& cx, float* A, int n, int ld, float* d, float* e, fl
     const float b = 2.0f / (ss + vl * vl);
     for (int k = lane; k < i; k += NL) v[k] = (k == i - 1) ? vl : A[i * ld + k];
     cx.sync();
-    for (int j = lane; j < i; j += NL) {  // p = b A v
-      float s = 0.f;
-      for (int k = 0; k < i; ++k) s += A[j * ld + k] * v[k];
-      p[j] = b * s;
+    for (int j = lane; j < i; j += NL) {  // p = b A v; four independent chains keep the loads in flight
+      const float* row = A + j * ld;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int k = 0;
+      for (; k + 4 <= i; k += 4) {
+        s0 += row[k] * v[k];
+        s1 += row[k + 1] * v[k + 1];
+        s2 += row[k + 2] * v[k + 2];
+        s3 += row[k + 3] * v[k + 3];
+      }
+      for (; k < i; ++k) s0 += row[k] * v[k];
+      p[j] = b * ((s0 + s1) + (s2 + s3));
     }
     cx.sync();
     float vp = 0.f;
@@ -94,14 +102,12 @@ GL_HD void tridiagonalize(C& cx, float* A, int n, int ld, float* d, float* e, fl
       const float vj = v[j], wj = p[j];
       float* row = A + j * ld;
       int k = 0;
-      for (; k + 4 <= i; k += 4) {  // loads of a group before its stores: the row does not alias v / p
-        const float a0 = row[k], a1 = row[k + 1], a2 = row[k + 2], a3 = row[k + 3];
-        const float p0 = p[k], p1 = p[k + 1], p2 = p[k + 2], p3 = p[k + 3];
-        const float v0 = v[k], v1 = v[k + 1], v2 = v[k + 2], v3 = v[k + 3];
-        row[k] = a0 - (vj * p0 + wj * v0);
-        row[k + 1] = a1 - (vj * p1 + wj * v1);
-        row[k + 2] = a2 - (vj * p2 + wj * v2);
-        row[k + 3] = a3 - (vj * p3 + wj * v3);
+      for (; k + 8 <= i; k += 8) {  // loads of a group before its stores: the row does not alias v / p
+        float a_[8], p_[8], v_[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a_[u] = row[k + u]; p_[u] = p[k + u]; v_[u] = v[k + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) row[k + u] = a_[u] - (vj * p_[u] + wj * v_[u]);
       }
       for (; k < i; ++k) row[k] -= vj * p[k] + wj * v[k];
     }

@@ -111,7 +111,9 @@ def test_short_cut_is_refused_when_the_cutoff_bites(hostmath, case):
     co, took, A32, r32 = _solve(hostmath, A, rhs, shortcut=True, want_path=True)
     assert took == 0
     want = np.linalg.pinv(A32.astype(np.float64), rcond=1e-6, hermitian=True) @ r32.astype(np.float64)
-    assert np.abs(co - want).max() <= 5e-3 * np.abs(want).max()
+    # a float32 eigenvalue just above the cutoff (1e-6 lambda_max) is known to eps / rcond ~ 6 %: that is the accuracy of
+    # the component of the solution along its direction, here and in any float32 pinv
+    assert np.abs(co - want).max() <= (3e-2 if case == "cond_1e8" else 5e-3) * np.abs(want).max()
 
 
 def test_spectrum_near_the_cutoff_is_left_to_the_eigenvalue_path(hostmath):
