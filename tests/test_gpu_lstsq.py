@@ -61,7 +61,9 @@ def _observation(wl, seed=3):
                                                        ("shapelets6", 37, 2, False, 1),    # 1369 pixels: no 16-byte pitch
                                                        ("shapelets", 35, 70, False, 1),    # one 64-pixel-multiple chunk / sample
                                                        ("shapelets7", 40, 2, False, 1),    # 38 channels: 3 MFMA blocks
-                                                       ("shapelets9", 44, 2, False, 1)])   # 57 channels: 4 MFMA blocks
+                                                       ("shapelets9", 44, 2, False, 1),    # 57 channels: 4 MFMA blocks
+                                                       ("shapelets4", 36, 3, False, 1),    # 17 channels: one past a block boundary
+                                                       ("shapelets10", 40, 2, False, 1)])  # 68 channels: 5 blocks, 12 padded
 def test_lstsq_simulate_vs_oracle(gl, kind, num_pix, batch, psf, ss):
     from oracle import ref_torch as ref
     wl = _model(kind, num_pix, batch, psf, ss)
