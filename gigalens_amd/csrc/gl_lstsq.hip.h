@@ -76,8 +76,8 @@ __global__ void __launch_bounds__(256) gl_normal_small_kernel(NormalArgs a) {
 // register per 16-channel block serves as the A operand of its tile row and the B operand of its tile column.  A lane
 // fetches 4 consecutive pixels of its channel with one 16-byte load straight from the stack (16 lanes x 64 B per
 // channel block; no LDS staging), weighs them by 1/err and feeds them as 4 k-steps.  Only the NT (NT+1) / 2 lower
-// tiles are accumulated (4 accumulator registers each).  Exact fp32: every product is rounded once, sums are k-ordered
-// fma chains.  The 4 waves of a workgroup take interleaved 16-pixel groups of the chunk and are summed through LDS.
+// tiles are accumulated (4 accumulator registers each).  fp32 MFMA: every product is rounded once, sums are k-ordered
+// fma chains (the weights 1/err come from v_rcp_f32).  The 4 waves of a workgroup take interleaved 16-pixel groups of the chunk and are summed through LDS.
 // (Round-1 history: the packed-fp32 VALU version of this kernel, 4x4 register tiles fed from LDS, ran 2.9 ms on C3L.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -137,18 +137,21 @@ __global__ void __launch_bounds__(256) gl_normal_mfma_kernel(NormalArgs a) {
     const int nxt = pg + 64;
     if (nxt < p1) load_group(nxt, xn, ern);  // in flight while this group multiplies
     const int pb = pg + 4 * q;
+    // weights 1/err by v_rcp_f32 (1 ulp; the same w multiplies X and Y): the IEEE division sequence costs ~10 VALU
+    // issue slots per pixel beside the MFMAs (1.27 -> 1.21 ms).  Only the last block can contain padding channels.
     float w[4];
-    w[0] = pb < p1 ? 1.0f / er.x : 0.f;
-    w[1] = pb + 1 < p1 ? 1.0f / er.y : 0.f;
-    w[2] = pb + 2 < p1 ? 1.0f / er.z : 0.f;
-    w[3] = pb + 3 < p1 ? 1.0f / er.w : 0.f;
+    w[0] = pb < p1 ? __builtin_amdgcn_rcpf(er.x) : 0.f;
+    w[1] = pb + 1 < p1 ? __builtin_amdgcn_rcpf(er.y) : 0.f;
+    w[2] = pb + 2 < p1 ? __builtin_amdgcn_rcpf(er.z) : 0.f;
+    w[3] = pb + 3 < p1 ? __builtin_amdgcn_rcpf(er.w) : 0.f;
     float xv[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      xv[t][0] = x[t].x * (w[0] * keep[t]);
-      xv[t][1] = x[t].y * (w[1] * keep[t]);
-      xv[t][2] = x[t].z * (w[2] * keep[t]);
-      xv[t][3] = x[t].w * (w[3] * keep[t]);
+      const float k_ = t == NT - 1 ? keep[t] : 1.f;
+      xv[t][0] = x[t].x * (t == NT - 1 ? w[0] * k_ : w[0]);
+      xv[t][1] = x[t].y * (t == NT - 1 ? w[1] * k_ : w[1]);
+      xv[t][2] = x[t].z * (t == NT - 1 ? w[2] * k_ : w[2]);
+      xv[t][3] = x[t].w * (t == NT - 1 ? w[3] * k_ : w[3]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
