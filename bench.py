@@ -2,25 +2,39 @@
 """bench.py -- forward+grad lens simulations per second on BASELINE.json's configs[1]:
 EPL+shear lens, Sersic source, 128x128 px, batch 1024, fp32, per MI355X (weak scaling over GPUs).
 
-One "step" = one pass of the hot path over one batch: ``ForwardProbModel.log_prob(simulator, z)`` forward
-AND its gradient w.r.t. ``z`` (bijector -> fused HIP prep/main/finalize kernels -> prior), i.e. exactly what
-one MAP / SVI / HMC-leapfrog step of the reference evaluates (tf/inference.py:33-39).  With N > 1 ranks each
-rank owns its own 1024 samples and a step also carries the one SVI collective of the path: an all-reduce of
-the fused [ELBO, grad] buffer (1 + d + d(d+1)/2 floats; jax/inference.py:126-128).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C5|...] [--mode auto|fwdgrad|svi]
 
-Defaults: 1000 timed steps after 100 warm-up steps (0.14 s of GPU time).  The chip needs a few tens of milliseconds of
-sustained load to settle at its working clock: a cold 50-step burst (7 ms) reads 0.140 ms per step, the same binary in
-a 400+ step run 0.120 ms -- what a 350-step MAP or a 500-step SVI run of the reference's pipeline sees.  Therefore an
-untimed pre-roll of 0.15 s of steps precedes the W warm-up steps whatever W and K are (``--preroll-seconds``).
+One "step" = one pass of the hot path over one batch.
+  * mode fwdgrad (N = 1 default): ``ForwardProbModel.log_prob_and_grad(simulator, z)`` -- ``log_prob`` forward AND its
+    gradient w.r.t. ``z`` (bijector -> fused HIP prep/main/finalize kernels -> prior), exactly what one MAP /
+    HMC-leapfrog step of the reference evaluates (tf/inference.py:33-39).
+  * mode svi (N > 1 default): one iteration of the sharded SVI loop (jax/inference.py:91-144) on this rank's particle
+    shard: draw eps, ``z = mu + L eps`` (gl_svi_sample), the same forward+gradient call, the fused
+    ``[ELBO, dELBO/dmu, dELBO/dL_packed]`` buffer (gl_svi_grad), the path's ONE collective -- an RCCL all-reduce of that
+    buffer (1 + d + d(d+1)/2 floats: 105 at C2, 8 911 at C5) -- and the fused Adam launch on the surrogate's parameters
+    with learning rate 0, so that every step of the measurement sees the same state.  ``inference.svi_step_buffer``
+    is the product function the SVI driver itself calls.
+
+``--gpus N`` with no launcher environment starts the N ranks itself: the parent never touches a GPU, it spawns
+``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a child process and exits with its code; it refuses
+(exit 2) when fewer than N devices are visible.  Under a launcher (WORLD_SIZE set) it runs as one rank.
+
+Defaults: 1000 timed steps after 100 warm-up steps.  The chip needs a few tens of milliseconds of sustained load to settle
+at its working clock, so an untimed pre-roll of 0.15 s of steps precedes the W warm-up steps whatever W and K are.
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) with two extra objects:
-  roofline     -- dominant kernel (gl_main_kernel, fused fwd+grad), HIP-event timed on its launch stream
-  cpu_baseline -- the oracle (reference algorithm restated op-for-op on torch-CPU, float32 + autograd) timed on
-                  a bounded sample of the same workload on this box's host cores
+  roofline     -- the dominant kernel, timed INSIDE the timed loop by a ring of HIP-event pairs the library records on the
+                  launch stream around every main-kernel launch (no host sync; read back after the loop), plus the
+                  ISA-counted fp32 flop rate of the dispatched instantiation against the 157.3 TFLOP/s vector peak
+                  (tools/isa_flops.py disassembles the shipped code object; the binding bound of this path)
+  cpu_baseline -- the oracle (reference algorithm restated op-for-op on torch-CPU, float32 + autograd) timed on 256 of
+                  the workload's samples on this box's host cores: median and p10 / p90 over the timed passes
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,7 +45,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_TFLOPS = 157.3
+VALU_PEAK_TFLOPS = 157.3  # packed fp32 FMA: 256 CU x 4 SIMD x 16 lanes x 2 (packed) x 2 (FMA) x 2.4 GHz
 
 
 def host_cores():
@@ -53,18 +67,24 @@ def host_cores():
     return min(n, 16)
 
 
-def cpu_baseline(wl, obs, seconds=12.0, sample_batch=16):
-    """Time the oracle (float32, torch autograd) on `sample_batch` samples of the same workload."""
-    import numpy as np
+def _pct(sorted_vals, q):
+    if not sorted_vals:
+        return None
+    k = min(len(sorted_vals) - 1, max(0, int(round(q * (len(sorted_vals) - 1)))))
+    return sorted_vals[k]
+
+
+def cpu_baseline(wl, obs, seconds=20.0, sample_batch=256, min_passes=10, max_passes=200):
+    """Time the oracle (float32, torch autograd) on `sample_batch` samples of the same workload: per-pass
+    forward+backward wall time; median and p10 / p90 of sims/s over the timed passes (3 warm-up passes)."""
     from oracle import ref_torch as ref
     from tests.helpers import struct_from_packed
-    from gigalens_amd import workloads
+    from gigalens_amd.model import _Packing
 
     cores = host_cores()
     torch.set_num_threads(cores)
     rs = ref.RefSimulator(wl.phys_model, wl.sim_config, sample_batch, dtype=torch.float32)
     x = wl.prior.sample(sample_batch, seed=11)
-    from gigalens_amd.model import _Packing
     packed = _Packing(wl.phys_model).pack(x, sample_batch, "cpu")
     obs_np = obs.cpu().numpy()
 
@@ -74,17 +94,102 @@ def cpu_baseline(wl, obs, seconds=12.0, sample_batch=16):
         ll.sum().backward()
         return p.grad
 
-    one()  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
+    t_w = time.perf_counter()
+    one()
+    first = time.perf_counter() - t_w
+    n_warm = 1
+    while n_warm < 3 and first * (n_warm + min_passes) < 4 * seconds:
         one()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 200:
+        n_warm += 1
+    ts, t0 = [], time.perf_counter()
+    while len(ts) < max_passes:
+        t1 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t1)
+        if time.perf_counter() - t0 >= seconds and len(ts) >= min_passes:
             break
-    return {"value": round(sample_batch * n / dt, 3), "unit": "sims/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fwd+grad passes over {sample_batch} of the {wl.batch} samples "
-                      f"({wl.sim_config.num_pix}x{wl.sim_config.num_pix} px, float32 torch-CPU restatement of the TF graph)"}
+        if time.perf_counter() - t0 >= 4 * seconds:  # a very slow host: stop with what there is
+            break
+    rates = sorted(sample_batch / t for t in ts)
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": round(_pct(rates, 0.5), 3), "unit": "sims/s", "cores": cores, "kind": "port",
+            "p10": round(_pct(rates, 0.1), 3), "p90": round(_pct(rates, 0.9), 3), "passes": len(ts),
+            "warmup_passes": n_warm, "cpu_model": cpu_model,
+            "sample": f"{len(ts)} timed fwd+grad passes over {sample_batch} of the {wl.batch} samples "
+                      f"({wl.sim_config.num_pix}x{wl.sim_config.num_pix} px; value = median, p10 / p90 beside it; float32 "
+                      f"torch-CPU restatement of the TF graph with torch.autograd, (N_pix, B) tensors as in the reference)"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start the N ranks as a CHILD process tree (the parent never initialises a GPU and
+    never replaces itself); exit with the child's code."""
+    n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
+    if n_dev < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible; refusing to run fewer ranks "
+                         "than asked for\n")
+        sys.exit(2)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def epl_series_stats(wl, x_struct):
+    """Mean trips of the two-term EPL series loop and the share of odd series lengths over the batch: the per-sample
+    term count K = ceil(log(1e-12) / log f + 2) - 1 (capped at niter) with f = (1-q)/(1+q) = min(|e|, 1), restated from
+    csrc/gl_profiles.h epl_prep (epl.py:22,37,47-54).  None for models without EPL."""
+    import math
+    pairs, odd, ks, n = 0.0, 0.0, 0.0, 0
+    for prof, p in zip(wl.phys_model.lenses, x_struct.get("lens_mass", [])):
+        if getattr(prof, "_kind", 0) != 1:
+            continue
+        e = torch.sqrt(torch.as_tensor(p["e1"], dtype=torch.float64) ** 2 + torch.as_tensor(p["e2"], dtype=torch.float64) ** 2)
+        f = e.clamp(1e-30, 1.0).reshape(-1)
+        cap = int(getattr(prof, "niter", 50) or 50)
+        niter = math.log(1e-12) / torch.log(f) + 2.0
+        K = torch.where(niter > 1, torch.ceil(niter) - 1, torch.zeros_like(niter)).clamp(max=cap)
+        K = torch.where(f >= 1.0, torch.full_like(K, float(cap)), K)
+        pairs += float(torch.floor(K / 2).mean())
+        odd += float((K % 2).mean())
+        ks += float(K.mean())
+        n += 1
+    if not n:
+        return None
+    return {"mean_terms": ks / n, "mean_pair_trips": pairs / n, "frac_odd": odd / n}
+
+
+def isa_account(kernel_symbol, series):
+    """ISA-counted fp32 flops and VALU wave-instructions per pixel of the dispatched kernel (tools/isa_flops.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_flops as isa
+    co = isa.code_object()
+    meta = isa.kernel_metadata(co)
+    name = next((k for k, v in meta.items() if v["symbol"] == kernel_symbol), None)
+    if name is None:
+        return None
+    md = meta[name]
+    out = {"kernel": name, "vgpr_count": md["vgpr_count"], "vgpr_spill_count": md["vgpr_spill_count"],
+           "sgpr_spill_count": md["sgpr_spill_count"], "scratch_bytes": md["scratch_bytes"]}
+    model = isa.execution_model(co, name, md, series)
+    if model is not None:
+        out.update(model)
+    return out
 
 
 def main():
@@ -93,47 +198,96 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="C2")
+    ap.add_argument("--mode", default="auto", choices=["auto", "fwdgrad", "svi"],
+                    help="auto: fwdgrad on one GPU, svi (sharded particles + the all-reduce) on several")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
     ap.add_argument("--num-pix", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not record the per-launch event pairs inside the timed loop (roofline is then null)")
+    ap.add_argument("--kernel-event-stride", type=int, default=8,
+                    help="bracket every k-th main-kernel launch of the timed loop with a HIP-event pair (an event record "
+                         "costs ~2.5 us of stream time: k = 1 slows a 0.12 ms step by 4.6 %%, k = 8 by 0.6 %%)")
     ap.add_argument("--preroll-seconds", type=float, default=0.15,
                     help="untimed sustained load before the warm-up steps (clock settling); 0 disables")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-samples", type=int, default=None)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)  # does not return
 
     from gigalens_amd import dist as gdist
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} rank(s)\n")
+        sys.exit(2)
+    if torch.cuda.device_count() < 1:
+        sys.stderr.write("bench.py: no GPU visible (gigalens_amd has no CPU path)\n")
+        sys.exit(2)
     rank, local_rank, world = gdist.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
     import __graft_entry__ as ge
     from gigalens_amd import _native, workloads
+    from gigalens_amd import inference as ginf
     from gigalens_amd.model import ForwardProbModel
     from gigalens_amd.simulator import LensSimulator
     if not os.path.exists(_native.lib_path()):
         ge.build()
 
+    mode = args.mode if args.mode != "auto" else ("svi" if world > 1 else "fwdgrad")
     wl = workloads.make(args.workload, num_pix=args.num_pix, batch=args.batch)
     obs, err, _ = workloads.synthetic_observation(wl, LensSimulator)
     pm = ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time,
                           error_map=None if err is None else err.cpu().numpy(), include_positions=False)
     sim = LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
-    B, N, P = wl.batch, sim._model.N, sim._model.P
+    model = sim._model
+    B, N, P = wl.batch, model.N, model.P
     x = wl.prior.sample(B, generator=gdist.rank_generator(0, rank))
+    series = epl_series_stats(wl, x)
     z = pm.bij.inverse(x).to(dev).contiguous()
     d = z.shape[1]
-    coll = torch.zeros(1 + d + d * (d + 1) // 2, dtype=torch.float32, device=dev)
+    n_coll = 1 + d + d * (d + 1) // 2
 
-    def step():
-        lp, red, g = pm.log_prob_and_grad(sim, z)
-        if world > 1:  # the path's one collective: fused [ELBO, grad] buffer, mean over ranks
-            torch.mean(lp, 0, keepdim=True, out=coll[0:1])
-            torch.mean(g, 0, out=coll[1:1 + d])
-            gdist.allreduce_mean_(coll)
-        return lp, g
+    if mode == "svi":
+        # surrogate state: the reference's SVI start (tf/inference.py:47-72: mean = a MAP-like point, scale 1e-3 I).  The mean
+        # is the prior draw whose EPL series length is closest to the batch mean, so a particle costs what an average
+        # sample of the fwdgrad batch costs (identical on every rank: drawn with rank 0's stream).
+        x0 = wl.prior.sample(B, generator=gdist.rank_generator(0, 0))
+        z0 = pm.bij.inverse(x0)
+        pick = 0
+        s0 = epl_series_stats(wl, x0)
+        if s0 is not None:
+            import math
+            e = None
+            for prof, p in zip(wl.phys_model.lenses, x0["lens_mass"]):
+                if getattr(prof, "_kind", 0) == 1:
+                    e = torch.sqrt(torch.as_tensor(p["e1"], dtype=torch.float64) ** 2 + torch.as_tensor(p["e2"], dtype=torch.float64) ** 2)
+                    break
+            K = torch.ceil(math.log(1e-12) / torch.log(e.clamp(1e-30, 1 - 1e-12)) + 2.0) - 1
+            pick = int(torch.argmin((K - round(s0["mean_terms"])).abs()))
+            series = {"mean_terms": float(K[pick]), "mean_pair_trips": float(K[pick] // 2), "frac_odd": float(K[pick] % 2)}
+        mu = z0[pick].to(dev).contiguous().clone()
+        lpk = ginf.tril_pack(torch.eye(d, device=dev) * 1e-3)
+        sv_params = torch.cat([mu, lpk]).contiguous()
+        opt = ginf.Adam(lr=0.0)
+        gen = gdist.rank_generator(2, rank, device=dev)
+
+        def vg(zz):
+            lp_, _, g_ = pm.log_prob_and_grad(sim, zz)
+            return lp_, g_
+
+        def step():
+            buf = ginf.svi_step_buffer(sv_params[:d], sv_params[d:], None, B, gen, value_and_grad_fn=vg, full_rank=True)
+            opt.step(sv_params, buf[1:])
+            return buf
+    else:
+        def step():
+            return pm.log_prob_and_grad(sim, z)
 
     # untimed pre-roll: sustained load until the chip has settled at its working clock (see the module docstring), so
     # that the timed region reads the same whatever W and K the caller picks; then the W warm-up steps of the contract
@@ -144,8 +298,15 @@ def main():
             step()
         torch.cuda.synchronize()
         n_pre += 50
+    events = not args.no_kernel_events
+    stride = max(1, min(args.kernel_event_stride, args.steps))
+    n_ev = (args.steps + stride - 1) // stride
     for _ in range(args.warmup):
         step()
+    if events:
+        # ring of ceil(K / stride) event pairs around every stride-th main launch, armed after the warm-up: what it holds
+        # after the loop are launches of the timed region only (allocating the events is host work, no GPU call)
+        model.set_timing(n_ev, stride)
     gdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -157,72 +318,77 @@ def main():
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     gdist.allreduce_max_(tmax)
     elapsed = float(tmax.item())
-
-    # ---- dominant kernel: HIP events around gl_main_kernel on its own launch stream ----
-    packed = sim.pack(pm.bij.forward(z)).contiguous()
-    sim._model.set_timing(True)
-    ms = []
-    for i in range(args.warmup + args.steps):
-        sim._model.loglike(packed, pm.observed_image, pm.error_map, None, pm.background_rms or 0.0,
-                           pm.exp_time or 1.0, True)
-        if i >= args.warmup:
-            ms.append(sim._model.last_main_ms())
-    sim._model.set_timing(False)
-    main_ms = sum(ms) / len(ms)
-    # native call alone (prep + main + finalize), event-timed on the current stream
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(args.steps):
-        sim._model.loglike(packed, pm.observed_image, pm.error_map, None, pm.background_rms or 0.0,
-                           pm.exp_time or 1.0, True)
-    e1.record()
-    torch.cuda.synchronize()
-    native_ms = e0.elapsed_time(e1) / args.steps
+    kernel_ms = sorted(model.timing_drain()) if events else []  # the most recent n_ev recorded launches
+    if events:
+        model.set_timing(0)
+    kernel_symbol = model.last_main_kernel()
 
     if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
         sims = B * world * args.steps / elapsed
         # algorithmic bytes per sim: B1 = simulate() boundary (image out + cotangent in + params/grads),
         # B2 = fused log_prob boundary (what this kernel actually has to move)
         n_planes = 1 + (1 if err is not None else 0)
         bytes_b1 = 2 * 4 * N + 2 * 4 * P
         bytes_b2 = 4 * (2 * P + 2) + 4 * N * n_planes / B
-        achieved = bytes_b1 * B / (main_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), profiles/<tag>_summary.json
-        valu_busy = None  # the binding bound (BASELINE.md section 4 `valu_fraction`): measured VALU-pipe busy fraction
-        try:
-            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
-            if prof and args.workload.upper() == "C2" and B == 1024:
-                summ = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
-                traffic = summ.get("traffic_bytes_per_launch")
-                valu_busy = summ.get("valu_busy_frac")
-        except Exception:
-            traffic = None
+        roofline = None
+        if kernel_ms:
+            k_mean = sum(kernel_ms) / len(kernel_ms)
+            achieved = bytes_b1 * B / (k_mean * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 6),
+                        "traffic": None,  # HBM bytes are a PMC figure; the profiled value lives in profiles/ (see traffic_profiled)
+                        "kernel_ms": round(k_mean, 5), "kernel_ms_p10": round(_pct(kernel_ms, 0.1), 5),
+                        "kernel_ms_p50": round(_pct(kernel_ms, 0.5), 5), "kernel_ms_p90": round(_pct(kernel_ms, 0.9), 5),
+                        "kernel_launches_timed": len(kernel_ms), "kernel_event_stride": stride,
+                        "kernel_share_of_step": round(k_mean / ms_per_step, 4),
+                        "algorithmic_bytes_per_sim_B1": bytes_b1, "algorithmic_bytes_per_sim_B2": round(bytes_b2, 1),
+                        "kernel_sims_per_s": round(B / (k_mean * 1e-3), 1),
+                        "note": "path is VALU/transcendental-bound (SURVEY 8d): the HBM fraction is priced with the "
+                                "simulate()-boundary bytes B1 as the metric asks; the binding bound is the fp32 vector rate "
+                                "(valu_flop_frac)"}
+            try:
+                acct = isa_account(kernel_symbol, series)
+            except Exception as exc:  # the accounting is evidence, never a reason to lose the line
+                acct = {"error": repr(exc)}
+            if acct:
+                roofline["isa"] = acct
+                fpp = acct.get("flops_per_pixel")
+                if fpp:
+                    tflops = fpp * N * B / (k_mean * 1e-3) / 1e12
+                    roofline["valu_flop_frac"] = round(tflops / VALU_PEAK_TFLOPS, 4)
+                    roofline["valu_tflops"] = round(tflops, 2)
+                    roofline["valu_peak_tflops"] = VALU_PEAK_TFLOPS
+            try:  # PMC traffic of an earlier profiled run of the same kernel, named as such (not a measurement of this run)
+                prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
+                if prof and args.workload.upper() == "C2" and B == 1024:
+                    summ = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+                    roofline["traffic_profiled"] = {"file": f"profiles/{prof[-1]}",
+                                                    "hbm_bytes_per_launch": summ.get("traffic_bytes_per_launch")}
+            except Exception:
+                pass
         out = {
             "metric": "forward+grad lens sims/sec, 128x128 px batch 1024; achieved HBM GB/s vs peak",
             "value": round(sims, 1), "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl.name}: {wl.description}, {wl.sim_config.num_pix}x{wl.sim_config.num_pix} px, "
-                                   f"batch {B} per GPU, fp32 (BASELINE.json configs[1])",
-                       "samples_per_gpu": B, "pixels": N, "params_per_sample": P, "z_dim": d,
-                       "untimed_preroll_steps": n_pre,
-                       "parallelism": f"dp{world} (sample shards, one {coll.numel()}-float all-reduce per step)"
-                                      if world > 1 else "single GPU",
-                       "step": "ForwardProbModel.log_prob_and_grad: log_prob forward + gradient w.r.t. z (bijector, "
-                               "kernels, prior) in one native launch sequence"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "gl_pair_kernel<LL_GRAD> (fused ray-shoot + render + chi2 + VJP, EPL+Shear|Sersic, packed fp32)",
-                         "kernel_ms": round(main_ms, 4), "native_call_ms": round(native_ms, 4),
-                         "algorithmic_bytes_per_sim_B1": bytes_b1, "algorithmic_bytes_per_sim_B2": round(bytes_b2, 1),
-                         "kernel_sims_per_s": round(B / (main_ms * 1e-3), 1),
-                         "valu_busy_frac": None if valu_busy is None else round(valu_busy, 4),
-                         "note": "path is VALU/transcendental-bound (SURVEY 8d): HBM fraction is reported as the "
-                                 "metric asks, the binding bound is fp32 VALU issue"},
+                                   f"batch {B} per GPU, fp32" + (" (BASELINE.json configs[1])" if wl.name == "C2" else "")
+                                   + (" (BASELINE.json configs[4]: per-rank shard of the 2048-particle SVI)" if wl.name == "C5" else ""),
+                       "samples_per_gpu": B, "pixels": N, "params_per_sample": P, "z_dim": d, "mode": mode,
+                       "untimed_preroll_steps": n_pre, "kernel_events_in_timed_loop": events,
+                       "epl_series": series,
+                       "parallelism": (f"dp{world}: particle shards, one {n_coll}-float RCCL all-reduce per step"
+                                       if world > 1 else "single GPU"),
+                       "step": ("inference.svi_step_buffer (eps draw, gl_svi_sample, log_prob forward+gradient, gl_svi_grad, all-reduce of "
+                                f"the fused {n_coll}-float [ELBO, grad] buffer) + fused Adam launch (lr 0)" if mode == "svi" else
+                                "ForwardProbModel.log_prob_and_grad: log_prob forward + gradient w.r.t. z (bijector, "
+                                "kernels, prior) in one native launch sequence")},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(wl, obs, seconds=args.cpu_seconds)
+            n_cpu = args.cpu_samples or (256 if N <= 16384 else 32)
+            out["cpu_baseline"] = cpu_baseline(wl, obs, seconds=args.cpu_seconds, sample_batch=min(n_cpu, B))
         print(json.dumps(out), flush=True)
     gdist.barrier()
     if world > 1:

@@ -97,6 +97,9 @@ SYMBOLS = {
     "gl_kind_num_params": (c_int, [POINTER(gl_component)]),
     "gl_model_set_timing": (c_int, [c_void_p, c_int]),
     "gl_model_last_main_ms": (c_int, [c_void_p, POINTER(c_float)]),
+    "gl_model_set_timing_stride": (c_int, [c_void_p, c_int]),
+    "gl_model_timing_drain": (c_int, [c_void_p, POINTER(c_float), c_int, POINTER(c_int)]),
+    "gl_model_last_main_kernel": (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
     "gl_last_error": (c_char_p, []),
     "gl_version": (c_char_p, []),
 }
@@ -521,8 +524,25 @@ class Model:
                                         float(chi2_divisor), int(terms), _ptr(ws), ws.numel(), _stream()))
         return lp, ll, chi2, grad
 
-    def set_timing(self, enabled=True):
-        _check(lib().gl_model_set_timing(self._h, int(enabled)))
+    def set_timing(self, slots=1, stride=1):
+        """Ring of ``slots`` HIP-event pairs around every ``stride``-th main-kernel launch (0 / False: off)."""
+        _check(lib().gl_model_set_timing(self._h, int(slots)))
+        _check(lib().gl_model_set_timing_stride(self._h, max(int(stride), 1)))
+        self._timing_slots = int(slots)
+
+    def timing_drain(self):
+        """Durations [ms] of the main launches recorded since the last drain (oldest first)."""
+        cap = max(int(getattr(self, "_timing_slots", 0)), 1)
+        buf = (c_float * cap)()
+        n = c_int()
+        _check(lib().gl_model_timing_drain(self._h, buf, cap, ctypes.byref(n)))
+        return list(buf[:n.value])
+
+    def last_main_kernel(self):
+        """Mangled symbol of the kernel the most recent main launch dispatched."""
+        buf = ctypes.create_string_buffer(1024)
+        _check(lib().gl_model_last_main_kernel(self._h, buf, len(buf)))
+        return buf.value.decode()
 
     def last_main_ms(self):
         ms = c_float()

@@ -84,8 +84,12 @@ struct gl_model {
   int epl_comp = -1;     // the model's only EPL component, or -1 (none / several)
   int fam = 0;  // family level of the interpreter variant (gl_main_kernel FAM): 1 dPIE family / catalogues / series, 2 gl_extra.h
   bool use_order = true;
-  bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // measurement hooks (gl_model_set_timing): a ring of event pairs around the main-kernel launches, and the host
+  // function of the most recent main launch (gl_model_last_main_kernel)
+  int timing_slots = 0, timing_stride = 1;
+  mutable long long timing_count = 0, timing_calls = 0;
+  std::vector<hipEvent_t> evs;  // 2 * timing_slots
+  mutable const void* last_main_fn = nullptr;
   // galaxy catalogues of the GL_SCALED components (gl_model_set_catalogue)
   struct Cat { CatDev dev; std::vector<float> table; };
   std::vector<Cat> cats;
@@ -210,8 +214,11 @@ int match_static(const gl_model* m) {
 template <int MODE>
 bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
   const int T = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
-#define GL_PAIR(WW, LK, CK, SK) \
-  hipLaunchKernelGGL((gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>), grid, block, shmem, stream, a)
+#define GL_PAIR(WW, LK, CK, SK)                                                           \
+  do {                                                                                    \
+    m->last_main_fn = (const void*)&gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>;            \
+    hipLaunchKernelGGL((gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>), grid, block, shmem, stream, a); \
+  } while (0)
   if (m->pair) {
     // waves/SIMD the register budget is declared for: gradient modes keep the EPL / Sersic state of a pixel
     // pair live between the forward and VJP halves (no spills at 3 resp. 2 waves per SIMD), forward modes fit 4+
@@ -228,8 +235,11 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     }
   }
 #undef GL_PAIR
-#define GL_LAUNCH(TT, WW, LK, CK, SK) \
-  hipLaunchKernelGGL((gl_static_kernel<MODE, TT, WW, LK, CK, SK>), grid, block, shmem, stream, a)
+#define GL_LAUNCH(TT, WW, LK, CK, SK)                                                        \
+  do {                                                                                       \
+    m->last_main_fn = (const void*)&gl_static_kernel<MODE, TT, WW, LK, CK, SK>;              \
+    hipLaunchKernelGGL((gl_static_kernel<MODE, TT, WW, LK, CK, SK>), grid, block, shmem, stream, a); \
+  } while (0)
   switch (m->static_id) {
     case ST_EPLSHEAR_SERSIC:
       if (T == 4) { if (m->static_variant == 2) GL_LAUNCH(4, 2, L_EplShear, C_None, C_Sersic); else GL_LAUNCH(4, 3, L_EplShear, C_None, C_Sersic); }
@@ -262,8 +272,15 @@ template <int MODE>
 int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream) {
   dim3 grid(n_chunks, B), block(WG);
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
-  if (m->timing) GL_HIP(hipEventRecord(m->ev0, stream));
-#define GL_MAIN(TT, S_, F_) hipLaunchKernelGGL((gl_main_kernel<MODE, TT, S_, F_>), grid, block, shmem, stream, a)
+  // every timing_stride-th main launch is bracketed by an event pair (an event record costs ~2.5 us of stream time)
+  const bool timed = m->timing_slots && (m->timing_calls++ % m->timing_stride) == 0;
+  const int slot = timed ? (int)(m->timing_count % m->timing_slots) : 0;
+  if (timed) GL_HIP(hipEventRecord(m->evs[2 * slot], stream));
+#define GL_MAIN(TT, S_, F_)                                                              \
+  do {                                                                                   \
+    m->last_main_fn = (const void*)&gl_main_kernel<MODE, TT, S_, F_>;                    \
+    hipLaunchKernelGGL((gl_main_kernel<MODE, TT, S_, F_>), grid, block, shmem, stream, a); \
+  } while (0)
 #define GL_MAIN_FAM(TT, S_) \
   do { if (m->fam == 2) GL_MAIN(TT, S_, 2); else if (m->fam == 1) GL_MAIN(TT, S_, 1); else GL_MAIN(TT, S_, 0); } while (0)
   if constexpr (MODE == IMG_BASIS) {  // basis stack of lstsq_simulate: interpreter kernel, one tile shape
@@ -277,7 +294,10 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
   }
 #undef GL_MAIN_FAM
 #undef GL_MAIN
-  if (m->timing) GL_HIP(hipEventRecord(m->ev1, stream));
+  if (timed) {
+    GL_HIP(hipEventRecord(m->evs[2 * slot + 1], stream));
+    ++m->timing_count;
+  }
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -713,28 +733,69 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   return GL_OK;
 }
 
-int gl_model_set_timing(gl_model* m, int enabled) {
+int gl_model_set_timing(gl_model* m, int slots) {
   if (!m) return fail(GL_EINVAL, "model is null");
-  if (enabled && !m->ev0) {
-    GL_HIP(hipEventCreate(&m->ev0));
-    GL_HIP(hipEventCreate(&m->ev1));
+  if (slots < 0 || slots > 65536) return fail(GL_EINVAL, "timing slots %d outside [0, 65536]", slots);
+  for (hipEvent_t e : m->evs) (void)hipEventDestroy(e);
+  m->evs.clear();
+  m->timing_slots = 0;
+  m->timing_count = m->timing_calls = 0;
+  m->evs.reserve((size_t)2 * slots);
+  for (int i = 0; i < 2 * slots; ++i) {
+    hipEvent_t e;
+    GL_HIP(hipEventCreate(&e));
+    m->evs.push_back(e);
   }
-  m->timing = enabled != 0;
+  m->timing_slots = slots;
+  return GL_OK;
+}
+
+int gl_model_set_timing_stride(gl_model* m, int stride) {
+  if (!m) return fail(GL_EINVAL, "model is null");
+  if (stride < 1) return fail(GL_EINVAL, "stride must be >= 1");
+  m->timing_stride = stride;
+  m->timing_calls = 0;
   return GL_OK;
 }
 
 int gl_model_last_main_ms(gl_model* m, float* ms) {
   if (!m || !ms) return fail(GL_EINVAL, "null argument");
-  if (!m->ev0) return fail(GL_EINVAL, "timing was never enabled on this model");
-  GL_HIP(hipEventSynchronize(m->ev1));
-  GL_HIP(hipEventElapsedTime(ms, m->ev0, m->ev1));
+  if (!m->timing_slots || !m->timing_count) return fail(GL_EINVAL, "no timed main launch on this model");
+  const int slot = (int)((m->timing_count - 1) % m->timing_slots);
+  GL_HIP(hipEventSynchronize(m->evs[2 * slot + 1]));
+  GL_HIP(hipEventElapsedTime(ms, m->evs[2 * slot], m->evs[2 * slot + 1]));
+  return GL_OK;
+}
+
+int gl_model_timing_drain(gl_model* m, float* ms, int cap, int* n_out) {
+  if (!m || !ms || !n_out || cap < 0) return fail(GL_EINVAL, "bad argument");
+  *n_out = 0;
+  if (!m->timing_slots) return fail(GL_EINVAL, "timing is not enabled on this model");
+  const long long have = std::min<long long>(m->timing_count, m->timing_slots);
+  const long long first = m->timing_count - have;  // oldest launch still in the ring
+  int n = 0;
+  for (long long k = first; k < m->timing_count && n < cap; ++k, ++n) {
+    const int slot = (int)(k % m->timing_slots);
+    GL_HIP(hipEventSynchronize(m->evs[2 * slot + 1]));
+    GL_HIP(hipEventElapsedTime(&ms[n], m->evs[2 * slot], m->evs[2 * slot + 1]));
+  }
+  *n_out = n;
+  m->timing_count = m->timing_calls = 0;
+  return GL_OK;
+}
+
+int gl_model_last_main_kernel(const gl_model* m, char* buf, size_t cap) {
+  if (!m || !buf || cap == 0) return fail(GL_EINVAL, "bad argument");
+  if (!m->last_main_fn) return fail(GL_EINVAL, "no main kernel has been launched on this model yet");
+  const char* name = hipKernelNameRefByPtr(m->last_main_fn, nullptr);
+  if (!name) return fail(GL_ELAUNCH, "hipKernelNameRefByPtr returned no name");
+  snprintf(buf, cap, "%s", name);
   return GL_OK;
 }
 
 void gl_model_destroy(gl_model* m) {
   if (!m) return;
-  if (m->ev0) (void)hipEventDestroy(m->ev0);
-  if (m->ev1) (void)hipEventDestroy(m->ev1);
+  for (hipEvent_t e : m->evs) (void)hipEventDestroy(e);
   if (m->d_comps) (void)hipFree(m->d_comps);
   if (m->d_gx) (void)hipFree(m->d_gx);
   if (m->d_gy) (void)hipFree(m->d_gy);
@@ -1404,9 +1465,9 @@ int gl_svi_grad(const float* l_packed, int d, int full_rank, const float* eps, c
 int gl_hmc_kick_drift(const float* p_in, const float* grad, float kick, const float* z_in, const float* sigma, float eps, int n,
                       int d, float* p_out, float* z_out, void* hip_stream) {
   if (!p_in || !grad || !z_in || !sigma || !p_out || !z_out) return fail(GL_EINVAL, "null argument");
-  if (n <= 0 || d <= 0 || d > HMC_MAXD) return fail(GL_EINVAL, "n must be positive and d in [1, %d]", HMC_MAXD);
-  hipLaunchKernelGGL(gl_hmc_kick_drift_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)hip_stream, p_in, grad, kick,
-                     z_in, sigma, eps, n, d, p_out, z_out);
+  if (n <= 0 || d <= 0 || d > 4096) return fail(GL_EINVAL, "n must be positive and d in [1, 4096]");
+  hipLaunchKernelGGL(gl_hmc_kick_drift_kernel, dim3(n), dim3(HMC_WG), sizeof(float) * d, (hipStream_t)hip_stream, p_in, grad,
+                     kick, z_in, sigma, eps, n, d, p_out, z_out);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }
@@ -1416,9 +1477,9 @@ int gl_hmc_accept(float* z, float* grad, float* logp, const float* z_new, const 
                   float* accept_prob, void* hip_stream) {
   if (!z || !grad || !logp || !z_new || !grad_new || !logp_new || !p0 || !p_new || !scale_tril || !uniforms || !accept_prob)
     return fail(GL_EINVAL, "null argument");
-  if (n <= 0 || d <= 0 || d > HMC_MAXD) return fail(GL_EINVAL, "n must be positive and d in [1, %d]", HMC_MAXD);
-  hipLaunchKernelGGL(gl_hmc_accept_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)hip_stream, z, grad, logp, z_new,
-                     grad_new, logp_new, p0, p_new, kick, scale_tril, uniforms, n, d, accept_prob);
+  if (n <= 0 || d <= 0 || d > 4096) return fail(GL_EINVAL, "n must be positive and d in [1, 4096]");
+  hipLaunchKernelGGL(gl_hmc_accept_kernel, dim3(n), dim3(HMC_WG), sizeof(float) * 2 * d, (hipStream_t)hip_stream, z, grad, logp,
+                     z_new, grad_new, logp_new, p0, p_new, kick, scale_tril, uniforms, n, d, accept_prob);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

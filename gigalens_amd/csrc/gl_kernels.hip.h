@@ -1147,57 +1147,80 @@ __global__ void __launch_bounds__(256) gl_svi_grad_kernel(const float* __restric
 // Momentum precision = the surrogate covariance Sigma = L L^T, so a drift is z += eps * (p Sigma).  One launch does the
 // momentum kick that precedes a drift and the drift itself; one launch closes a transition: last half kick, kinetic
 // energies 1/2 |p L|^2, Metropolis test against the supplied uniforms, and the in-place selection of the state.
-constexpr int HMC_MAXD = 64;
+// One workgroup per chain, any d (cluster models: d = 132): the chain's momentum row is staged in LDS, thread j owns
+// column j, so the rows of Sigma / L are read coalesced and every output element is read and written by the same
+// thread (the calls may run in place: p_out == p_in, z_out == z_in).
+constexpr int HMC_WG = 128;
 
-__global__ void __launch_bounds__(128) gl_hmc_kick_drift_kernel(const float* __restrict__ p_in, const float* __restrict__ grad,
-                                                                float kick, const float* __restrict__ z_in,
-                                                                const float* __restrict__ sigma, float eps, int n, int d,
-                                                                float* __restrict__ p_out, float* __restrict__ z_out) {
-  const int i = blockIdx.x * 128 + threadIdx.x;
-  if (i >= n) return;
-  float p[HMC_MAXD];
-  for (int j = 0; j < d; ++j) {
-    p[j] = p_in[(size_t)i * d + j] + kick * grad[(size_t)i * d + j];
-    p_out[(size_t)i * d + j] = p[j];
+__global__ void __launch_bounds__(HMC_WG) gl_hmc_kick_drift_kernel(const float* p_in, const float* __restrict__ grad,
+                                                                   float kick, const float* z_in,
+                                                                   const float* __restrict__ sigma, float eps, int n, int d,
+                                                                   float* p_out, float* z_out) {
+  extern __shared__ float s_p[];  // [d]
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const size_t row = (size_t)i * d;
+  for (int j = tid; j < d; j += HMC_WG) {
+    const float v = p_in[row + j] + kick * grad[row + j];
+    s_p[j] = v;
+    p_out[row + j] = v;
   }
-  for (int j = 0; j < d; ++j) {
+  __syncthreads();
+  for (int j = tid; j < d; j += HMC_WG) {
     float s = 0.f;
-    for (int k = 0; k < d; ++k) s += p[k] * sigma[k * d + j];
-    z_out[(size_t)i * d + j] = z_in[(size_t)i * d + j] + eps * s;
+    for (int k = 0; k < d; ++k) s += s_p[k] * sigma[(size_t)k * d + j];
+    z_out[row + j] = z_in[row + j] + eps * s;
   }
 }
 
-__global__ void __launch_bounds__(128) gl_hmc_accept_kernel(float* __restrict__ z, float* __restrict__ g,
-                                                            float* __restrict__ lp, const float* __restrict__ zn,
-                                                            const float* __restrict__ gn, const float* __restrict__ lpn,
-                                                            const float* __restrict__ p0, const float* __restrict__ pn,
-                                                            float kick, const float* __restrict__ L,
-                                                            const float* __restrict__ u, int n, int d,
-                                                            float* __restrict__ acc_prob) {
-  const int i = blockIdx.x * 128 + threadIdx.x;
-  if (i >= n) return;
-  float a[HMC_MAXD], b[HMC_MAXD];
-  for (int j = 0; j < d; ++j) {
-    a[j] = p0[(size_t)i * d + j];
-    b[j] = pn[(size_t)i * d + j] + kick * gn[(size_t)i * d + j];
+__global__ void __launch_bounds__(HMC_WG) gl_hmc_accept_kernel(float* z, float* g, float* lp, const float* __restrict__ zn,
+                                                               const float* __restrict__ gn, const float* __restrict__ lpn,
+                                                               const float* __restrict__ p0, const float* __restrict__ pn,
+                                                               float kick, const float* __restrict__ L,
+                                                               const float* __restrict__ u, int n, int d,
+                                                               float* __restrict__ acc_prob) {
+  extern __shared__ float s_ab[];  // [2][d] momenta at both ends, then [4] reduction slots
+  float* s_a = s_ab;
+  float* s_b = s_ab + d;
+  __shared__ float red[2][HMC_WG / 64];
+  __shared__ int s_take;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const size_t row = (size_t)i * d;
+  for (int j = tid; j < d; j += HMC_WG) {
+    s_a[j] = p0[row + j];
+    s_b[j] = pn[row + j] + kick * gn[row + j];
   }
+  __syncthreads();
   float ke0 = 0.f, ke1 = 0.f;
-  for (int k = 0; k < d; ++k) {  // (p L)_k = sum_j p_j L_jk, L lower triangular
+  for (int k = tid; k < d; k += HMC_WG) {  // (p L)_k = sum_{j >= k} p_j L_jk, L lower triangular
     float s0 = 0.f, s1 = 0.f;
-    for (int j = k; j < d; ++j) { s0 += a[j] * L[j * d + k]; s1 += b[j] * L[j * d + k]; }
+    for (int j = k; j < d; ++j) {
+      const float l = L[(size_t)j * d + k];
+      s0 += s_a[j] * l;
+      s1 += s_b[j] * l;
+    }
     ke0 += s0 * s0;
     ke1 += s1 * s1;
   }
-  float log_acc = (lpn[i] - 0.5f * ke1) - (lp[i] - 0.5f * ke0);
-  if (!(fabsf(log_acc) <= 3.0e38f)) log_acc = -INFINITY;  // NaN / inf proposals are rejected
-  acc_prob[i] = expf(fminf(log_acc, 0.f));
-  if (logf(u[i]) < log_acc) {
-    for (int j = 0; j < d; ++j) {
-      z[(size_t)i * d + j] = zn[(size_t)i * d + j];
-      g[(size_t)i * d + j] = gn[(size_t)i * d + j];
-    }
-    lp[i] = lpn[i];
+  ke0 = wave_sum63(ke0);
+  ke1 = wave_sum63(ke1);
+  if ((tid & 63) == 63) { red[0][tid >> 6] = ke0; red[1][tid >> 6] = ke1; }
+  __syncthreads();
+  if (tid == 0) {
+    float k0 = 0.f, k1 = 0.f;
+    for (int w = 0; w < HMC_WG / 64; ++w) { k0 += red[0][w]; k1 += red[1][w]; }
+    float log_acc = (lpn[i] - 0.5f * k1) - (lp[i] - 0.5f * k0);
+    if (!(fabsf(log_acc) <= 3.0e38f)) log_acc = -INFINITY;  // NaN / inf proposals are rejected
+    acc_prob[i] = expf(fminf(log_acc, 0.f));
+    const int take = logf(u[i]) < log_acc;
+    s_take = take;
+    if (take) lp[i] = lpn[i];
   }
+  __syncthreads();
+  if (s_take)
+    for (int j = tid; j < d; j += HMC_WG) {
+      z[row + j] = zn[row + j];
+      g[row + j] = gn[row + j];
+    }
 }
 
 // ---- plugin-level point evaluation (MassProfile.deriv / LightProfile.light on arbitrary points) ----

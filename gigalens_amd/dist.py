@@ -52,8 +52,11 @@ def rank_generator(seed: int, rank: int, device="cpu") -> torch.Generator:
 def allreduce_mean_(buf: torch.Tensor) -> torch.Tensor:
     """In-place mean over ranks (== lax.pmean). One collective for the whole fused buffer."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        buf.div_(dist.get_world_size())
+        if buf.is_cuda and dist.get_backend() == "nccl":
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG)  # RCCL averages inside the collective kernel: no second launch
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            buf.div_(dist.get_world_size())
     return buf
 
 

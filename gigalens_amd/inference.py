@@ -103,13 +103,23 @@ def _tril_idx(d, device):
     return _TRIL_IDX[key]
 
 
-def svi_step(mu: torch.Tensor, l_packed: torch.Tensor, log_prob_fn: Optional[Callable[[torch.Tensor], torch.Tensor]],
-             n_local: int, generator: Optional[torch.Generator] = None,
-             value_and_grad_fn: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None
+def svi_step(mu, l_packed, log_prob_fn, n_local, generator=None, value_and_grad_fn=None, full_rank=None, eps=None
              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """One ELBO evaluation on this rank's particle shard, all-reduced over ranks.
+    """:func:`svi_step_buffer` split into ``(loss, grad_mu, grad_l_packed)`` (views of the one fused buffer)."""
+    buf = svi_step_buffer(mu, l_packed, log_prob_fn, n_local, generator, value_and_grad_fn, full_rank, eps)
+    d = mu.numel()
+    return buf[0], buf[1:1 + d], buf[1 + d:]
 
-    Returns ``(loss, grad_mu, grad_l_packed)`` identical on every rank: the mean over ranks of the per-rank
+
+def svi_step_buffer(mu: torch.Tensor, l_packed: torch.Tensor,
+                    log_prob_fn: Optional[Callable[[torch.Tensor], torch.Tensor]],
+                    n_local: int, generator: Optional[torch.Generator] = None,
+                    value_and_grad_fn: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None,
+                    full_rank: Optional[bool] = None, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One ELBO evaluation on this rank's particle shard, all-reduced over ranks: the fused buffer
+    ``[loss, grad_mu (d), grad_l_packed]`` -- ``buf[1:]`` is the gradient of ``cat([mu, l_packed])`` as it stands.
+
+    The buffer is identical on every rank: the mean over ranks of the per-rank
     means (== the mean over all particles, shards being equal-sized).  ``l_packed`` of length ``d`` is the mean-field
     surrogate (``MultivariateNormalDiag`` with ``Exp`` on the scales, tf/inference.py:75-83), of length
     ``d (d + 1) / 2`` the full-rank one.
@@ -118,20 +128,29 @@ def svi_step(mu: torch.Tensor, l_packed: torch.Tensor, log_prob_fn: Optional[Cal
     ``G = d log p / d z`` (one native forward+gradient call through ``value_and_grad_fn``; ``log_prob_fn`` is
     differentiated with autograd when only that is given),
     ``d ELBO / d mu = -mean G``,  ``d ELBO / d L = -mean G eps^T`` on the lower triangle, and the ``Exp`` diagonal
-    contributes ``dL_ii / dp_ii = exp(p_ii)`` plus ``-exp(p_ii) / L_ii`` from ``-log det L`` in ``log q``."""
+    contributes ``dL_ii / dp_ii = exp(p_ii)`` plus ``-exp(p_ii) / L_ii`` from ``-log det L`` in ``log q``.
+
+    ``full_rank`` says which surrogate ``l_packed`` parameterises; ``None`` infers it from the length, which is
+    ambiguous only at ``d == 1`` (read as mean field there, like ``SVI`` stores it).  ``eps``: the standard-normal draws
+    ``(n_local, d)`` to use instead of drawing them (tests)."""
     d = mu.numel()
     mu, l_packed = mu.detach(), l_packed.detach()
-    diag_mode = l_packed.numel() == d and d > 1
-    eps = torch.randn((n_local, d), generator=generator, dtype=mu.dtype,
-                      device=generator.device if generator is not None else mu.device).to(mu.device)
+    if full_rank is None:
+        full_rank = l_packed.numel() != d
+    if l_packed.numel() != (d * (d + 1) // 2 if full_rank else d):
+        raise ValueError(f"l_packed has {l_packed.numel()} entries, a {'full-rank' if full_rank else 'mean-field'} "
+                         f"surrogate of dimension {d} needs {d * (d + 1) // 2 if full_rank else d}")
+    diag_mode = not full_rank
+    if eps is None:
+        eps = torch.randn((n_local, d), generator=generator, dtype=mu.dtype,
+                          device=generator.device if generator is not None else mu.device).to(mu.device)
     if value_and_grad_fn is not None and mu.is_cuda and mu.dtype == torch.float32:
         # on the GPU the surrogate is two native launches around the forward+gradient call (gl_svi_sample / gl_svi_grad)
         mu_c, lp_c, eps = mu.contiguous(), l_packed.contiguous(), eps.contiguous()
         z = _native.svi_sample(mu_c, lp_c, eps, not diag_mode)
         lp, G = value_and_grad_fn(z)
         buf = _native.svi_grad(lp_c, eps, lp.contiguous(), G.contiguous(), not diag_mode)
-        gdist.allreduce_mean_(buf)
-        return buf[0], buf[1:1 + d], buf[1 + d:]
+        return gdist.allreduce_mean_(buf)
     if diag_mode:
         sdiag = torch.exp(l_packed)
         z = mu + eps * sdiag
@@ -161,8 +180,7 @@ def svi_step(mu: torch.Tensor, l_packed: torch.Tensor, log_prob_fn: Optional[Cal
         e = torch.exp(l_packed)  # only its diagonal entries are used: L_ii = exp(p_ii) + shift
         g_lp = torch.where(on_diag, gl * e - e / ldiag[idx[0]], gl)
     buf = torch.cat([elbo.reshape(1), g_mu, g_lp])  # ONE fused buffer -> ONE collective
-    gdist.allreduce_mean_(buf)
-    return buf[0], buf[1:1 + d], buf[1 + d:]
+    return gdist.allreduce_mean_(buf)
 
 
 class ModellingSequence:
@@ -262,8 +280,10 @@ class ModellingSequence:
             return lp_, g_
 
         for step in range(num_steps):
-            loss, g_mu, g_lp = svi_step(params[:d], params[d:], None, n_local, gen, value_and_grad_fn=value_and_grad)
-            optimizer.step(params, torch.cat([g_mu, g_lp]))
+            buf = svi_step_buffer(params[:d], params[d:], None, n_local, gen, value_and_grad_fn=value_and_grad,
+                                  full_rank=full_rank)
+            loss = buf[0]
+            optimizer.step(params, buf[1:])  # the fused buffer's tail IS the gradient of cat([mu, l_packed])
             losses.append(loss)  # stays on the device: no host round trip per step
             if progress is not None:
                 progress(step, loss)
@@ -304,7 +324,7 @@ class ModellingSequence:
         n_leap = int(min(max(init_l, 1), max_leapfrog_steps))
         log_eps, log_eps_bar, h_bar, mu_da = math.log(init_eps), 0.0, 0.0, math.log(10 * init_eps)
         samples, accept_hist = [], []
-        native = on_gpu and d <= 64 and z.dtype == torch.float32
+        native = on_gpu and z.dtype == torch.float32
         if native:  # one launch per kick+drift, one per Metropolis step (gl_hmc_kick_drift / gl_hmc_accept)
             z, g, lp = z.contiguous(), g.contiguous().clone(), lp.contiguous().clone()
             L_c, Sigma_c = L.contiguous(), Sigma.contiguous()

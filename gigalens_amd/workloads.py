@@ -89,6 +89,11 @@ def make(name: str, num_pix: Optional[int] = None, batch: Optional[int] = None, 
         return Workload("C3", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix or 128), batch or 1024,
                         use_error_map=True, description=f"EPL+shear lens, Shapelets n_max={n_max} source "
                         f"({'table' if interpolate else 'direct'} mode)")
+    if name == "C5":  # BASELINE configs[4]: the C4 model, 2048 SVI particles over 8 GPUs = 256 per rank, full-rank q, d = 132
+        wl = make("C4", num_pix=num_pix, batch=batch or 256, n_halos=n_halos, n_sources=n_sources)
+        wl.name = "C5"
+        wl.description += " (per-rank shard of the 2048-particle full-rank SVI)"
+        return wl
     if name == "C4":  # cluster: 8 NFW + 20 Sersic sources, 256x256, B=512
         phys = PhysicalModel([NFW() for _ in range(n_halos)], [], [Sersic() for _ in range(n_sources)])
         halo = lambda: tfd.JointDistributionNamed(dict(

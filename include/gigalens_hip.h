@@ -283,8 +283,10 @@ int gl_svi_grad(const float* l_packed, int d, int full_rank, const float* eps, c
                 float diag_shift, float* buf, void* hip_stream);
 
 /* The leapfrog of the preconditioned HMC loop (tf/inference.py:95-182; momentum precision = the SVI covariance
- * Sigma = L L^T, d <= 64).  All arrays [n,d] row-major DEVICE float32 unless noted.
- * gl_hmc_kick_drift: p_out = p_in + kick * grad;  z_out = z_in + eps * (p_out Sigma)   (in place when out == in).
+ * Sigma = L L^T; any d up to 4096 -- cluster models run at d = 132).  All arrays [n,d] row-major DEVICE float32 unless
+ * noted.
+ * gl_hmc_kick_drift: p_out = p_in + kick * grad;  z_out = z_in + eps * (p_out Sigma)   (may run in place: p_out == p_in,
+ *   z_out == z_in).
  * gl_hmc_accept: closes a transition.  p1 = p_new + kick * grad_new; log_acc = (logp_new - |p1 L|^2/2) - (logp - |p0 L|^2/2),
  *   non-finite -> rejected; chain i moves (z, grad, logp overwritten by the proposal) when log(uniforms[i]) < log_acc;
  *   accept_prob [n] = exp(min(log_acc, 0)).  scale_tril: L [d,d] lower triangular. */
@@ -309,11 +311,20 @@ int gl_profile_hessian(const gl_component* comp, const float* x, const float* y,
 
 int gl_kind_num_params(const gl_component* comp); /* length of the reference's params list for this profile */
 
-/* Measurement hooks (bench.py / rocprof cross-check): when enabled, every subsequent call records a pair of
- * HIP events on the CALLER'S stream around its dominant ("main") kernel launch; gl_model_last_main_ms
- * synchronises on the second event and returns the elapsed milliseconds of the most recent main launch. */
-int gl_model_set_timing(gl_model* m, int enabled);
+/* Measurement hooks (bench.py / rocprof cross-check).  gl_model_set_timing(m, slots): slots > 0 allocates a ring of
+ * `slots` HIP-event pairs; every subsequent call records one pair on the CALLER'S stream around its dominant ("main")
+ * kernel launch -- no host synchronisation, so a sustained loop can be timed launch by launch; slots == 0 turns the
+ * hooks off.  gl_model_set_timing_stride(m, k): only every k-th main launch is bracketed (default 1; an event record costs
+ * ~2.5 us of stream time, so a sustained loop is sampled rather than slowed).  gl_model_last_main_ms synchronises on the most recent pair and returns its elapsed milliseconds.
+ * gl_model_timing_drain synchronises on every pair recorded since the last drain (at most `slots`, oldest first), writes
+ * up to `cap` durations to ms[] and their number to *n, and restarts the ring.
+ * gl_model_last_main_kernel: the (mangled) symbol of the kernel the most recent main launch dispatched -- the name
+ * rocprofv3 lists and tools/isa_flops.py disassembles. */
+int gl_model_set_timing(gl_model* m, int slots);
+int gl_model_set_timing_stride(gl_model* m, int stride);
 int gl_model_last_main_ms(gl_model* m, float* ms);
+int gl_model_timing_drain(gl_model* m, float* ms, int cap, int* n);
+int gl_model_last_main_kernel(const gl_model* m, char* buf, size_t cap);
 
 const char* gl_last_error(void);
 const char* gl_version(void);

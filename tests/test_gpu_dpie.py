@@ -469,3 +469,83 @@ def test_full_size_cluster_properties(gl):
     g, gs = p.grad[:, keep], ps.grad
     sc = g.abs().max(dim=1, keepdim=True).values
     assert torch.all((g - gs).abs() <= 5e-3 * torch.maximum(g.abs(), 1e-2 * sc) + 1e-5), ((g - gs).abs() / sc).max()
+
+
+# ---- vectors the reference itself produced (tests/golden/ref_dpie_series.npz, made by tests/golden/make_dpie_golden.py from
+# gigalens.series_codegen.profiles.dpie.DPIE + sympy_codegen.sympy_series; CPU half: tests/test_dpie_golden.py) ----------------
+def _ref_fixture():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_dpie_series.npz"))
+    return {k: g[k] for k in g.files}
+
+
+def test_reference_fixture_dpie_deriv_and_hessian(gl):
+    """gl_profile_eval / gl_profile_hessian (fp32 HIP) of a free-standing dPIE against the reference's deriv_0 / hessian_0,
+    case by case, in a rotated and shifted frame (piemd.py:105-138), with the reference's own plugin tolerance
+    (tests/test_profiles.py:50-58: rtol 1e-5, atol 1e-4) -- also at the points within 1e-2 / 1e-3 of the foci of the
+    Kassiola-Kovner form, where the product's cancellation-free imaginary parts (csrc/gl_dpie.h) matter."""
+    from gigalens_amd.profiles.mass import piemd
+    fx = _ref_fixture()
+    prof = piemd.DPIE()
+    r = np.random.default_rng(5)
+    for case in np.unique(fx["case"]):
+        m = fx["case"] == case
+        x, y = fx["x"][m], fx["y"][m]
+        e, rc, rt = float(fx["e"][m][0]), float(fx["r_core"][m][0]), float(fx["r_cut"][m][0])
+        phi, te, cx, cy = r.uniform(-1.5, 1.5), r.uniform(0.5, 3.0), r.normal(), r.normal()
+        c, s = math.cos(phi), math.sin(phi)
+        xs, ys = (c * x - s * y + cx).astype(np.float32), (s * x + c * y + cy).astype(np.float32)
+        # the float32 sky coordinates are the inputs; the halo-frame point they stand for (float64) is what the fixture saw only
+        # up to that rounding, so compare at the 1e-5 / 1e-4 plugin tolerance, not tighter
+        kw = dict(theta_E=te, r_core=rc, r_cut=rt, center_x=cx, center_y=cy, e1=e * math.cos(2 * phi), e2=e * math.sin(2 * phi))
+        ax, ay = prof.deriv(x=xs, y=ys, **kw)
+        d0 = fx["deriv"][m][:, 0, :]
+        wx, wy = te * (c * d0[:, 0] - s * d0[:, 1]), te * (s * d0[:, 0] + c * d0[:, 1])
+        assert np.allclose(ax.cpu().numpy(), wx, rtol=1e-5, atol=1e-4), case
+        assert np.allclose(ay.cpu().numpy(), wy, rtol=1e-5, atol=1e-4), case
+        far = fx["focus_distance"][m] > 0.05  # second derivatives: one more power of 1 / distance to a focus in fp32 inputs
+        fxx, fxy, fyx, fyy = prof.hessian(x=xs, y=ys, **kw)
+        h = fx["hessian"][m][:, 0, :]
+        hxx, hxy, hyy = h[:, 0], h[:, 1], h[:, 3]
+        wxx = te * (c * c * hxx - 2 * c * s * hxy + s * s * hyy)
+        wxy = te * (c * s * (hxx - hyy) + (c * c - s * s) * hxy)
+        wyy = te * (s * s * hxx + 2 * c * s * hxy + c * c * hyy)
+        sc = max(np.abs(wxx).max(), np.abs(wyy).max())
+        for got, want in ((fxx, wxx), (fxy, wxy), (fyx, wxy), (fyy, wyy)):
+            err = np.abs(got.cpu().numpy() - want)
+            assert err[far].max() <= 2e-5 * sc + 1e-4, case
+            assert err.max() <= 2e-3 * sc + 1e-4, case
+
+
+@pytest.mark.parametrize("order", [3, 5])
+def test_reference_fixture_series_precompute(gl, order):
+    """gl_series_precompute / gl_series_precompute_hessian (fp64 jets on the GPU, field stored as fp32) for one dPIE halo
+    (DPIESeries, tf/profiles/mass/dpie_series.py:19-49) against the reference's own deriv_n / hessian_n: C_n n! = f_n.
+    Tolerance model of tests/test_dpie_golden.py plus the fp32 storage rounding of the field."""
+    from gigalens_amd.profiles.mass.dpie_series import DPIESeries
+    from tests.test_dpie_golden import check
+    fx = _ref_fixture()
+    fact = np.array([math.factorial(k) for k in range(6)], dtype=np.float64)
+    for case in np.unique(fx["case"]):
+        m = fx["case"] == case
+        x, y, fd = fx["x"][m].astype(np.float32), fx["y"][m].astype(np.float32), fx["focus_distance"][m]
+        assert np.array_equal(x.astype(np.float64), fx["x"][m])  # the fixture's points are float32-exact
+        s = DPIESeries(order=order)
+        s.set_constants(dict(theta_E=1.0, r_core=float(fx["r_core"][m][0]), r_cut=float(fx["r_cut"][m][0]), center_x=0.0,
+                             center_y=0.0, e1=float(fx["e"][m][0]), e2=0.0))
+        s.set_grid(torch.as_tensor(x), torch.as_tensor(y))
+        s.set_deriv()
+        s.set_hessian()
+        co, hc = s._coefs.cpu().numpy().astype(np.float64), s._hcoefs.cpu().numpy().astype(np.float64)
+        assert co.shape == (2, order + 1, x.size) and hc.shape == (3, order + 1, x.size)
+        for k in range(order + 1):
+            for j in range(2):
+                check(co[j, k] * fact[k], fx["deriv"][m][:, k, j], fd, k, f"case {case} f{j}", floor=2e-7, min_checked=0.4)
+            for j, col in ((0, 0), (1, 1), (2, 3)):
+                check(hc[j, k] * fact[k], fx["hessian"][m][:, k, col], fd, k + 1, f"case {case} h{j}", floor=2e-7,
+                      min_checked=0.3)
+        # MassSeries.deriv (series_profile.py:76-95) near the expansion point against the reference's exact deflection of the
+        # moved cut radius is covered by test_series_precompute_and_deriv; here: the polynomial itself at r_cut0 is deriv_0
+        ax, ay = s.deriv(x, y, theta_E=np.array([2.0], np.float32), r_cut=np.array([float(fx["r_cut"][m][0])], np.float32))
+        assert np.allclose(ax.cpu().numpy()[:, 0], 2.0 * fx["deriv"][m][:, 0, 0], rtol=1e-5, atol=1e-5)
+        assert np.allclose(ay.cpu().numpy()[:, 0], 2.0 * fx["deriv"][m][:, 0, 1], rtol=1e-5, atol=1e-5)

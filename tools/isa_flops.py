@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""ISA-level accounting of one kernel instantiation of lib/libgigalens_hip.so (gfx950 code object).
+
+What it does (no GPU needed; the same binaries run on the GPU box, so bench.py calls it live):
+  1. pulls the gfx950 code object out of the shared library (.hip_fatbin -> clang-offload-bundler),
+  2. reads the kernel's metadata (VGPRs, spills, scratch) from the AMDGPU notes,
+  3. disassembles the kernel, splits it into basic blocks, finds the loops (backward branches) and their nesting,
+  4. counts per block the VALU wave-instructions and the fp32 flops they perform per lane:
+       v_pk_fma_f32 4 | v_pk_mul_f32 / v_pk_add_f32 2 | v_fma / v_fmac / v_mad 2 | v_mul / v_add / v_sub 1 |
+       v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos 1 (quarter-rate transcendental, counted as one flop) |
+       moves, selects, compares, min/max, conversions, integer and bit ops 0,
+  5. turns the static counts into DYNAMIC counts per pixel with an execution model of the kernel's loop nest:
+       flops per tile = (tile-loop body outside its inner loops) + sum_inner (body x trips) + (conditional tails x probability)
+     The trip counts come from the caller (mean EPL series trip count of the batch, see `pair_model`).
+
+The model is validated against hardware: the dynamic VALU wave-instruction count it predicts per launch is compared with the
+PMC counter SQ_INSTS_VALU of the same launch (profiles/r2_isa_flops.md).
+
+    python3 tools/isa_flops.py --kernel 'gl_pair_kernel<3, float __vector(2), 3, glk::KindList<1, 4>, glk::KindList<>, glk::KindList<16> >'
+    python3 tools/isa_flops.py --list            # every kernel: VGPRs, spills, scratch
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+LIB = os.path.join(ROOT, "gigalens_amd", "lib", "libgigalens_hip.so")
+
+FLOPS = [  # (regex on the mnemonic, flops per lane)
+    (r"^v_pk_fma_f32", 4), (r"^v_pk_(mul|add)_f32", 2),
+    (r"^v_(fma|fmac|mad|mac)_f32", 2), (r"^v_fma_mix", 2),
+    (r"^v_(mul|add|sub|subrev)_f32", 1), (r"^v_mul_legacy_f32", 1),
+    (r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_f32", 1), (r"^v_rcp_iflag_f32", 1), (r"^v_ldexp_f32", 1),
+    (r"^v_(fma|mul|add)_f64", 0),  # fp64 is not on this path's hot kernels; kept out of the fp32 tally
+]
+TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_f32|^v_rcp_iflag_f32")
+PACKED = re.compile(r"^v_pk_(fma|mul|add)_f32")
+
+
+def code_object(lib=LIB, workdir=None):
+    """Path of the gfx950 code object extracted from `lib` (cached next to the temp dir)."""
+    workdir = workdir or tempfile.mkdtemp(prefix="gl_isa_")
+    fat, co = os.path.join(workdir, "fatbin"), os.path.join(workdir, "gfx950.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+    return co
+
+
+def demangle(names):
+    out = subprocess.run(["c++filt"] + list(names), capture_output=True, text=True, check=True).stdout
+    return out.strip().split("\n")
+
+
+def kernel_metadata(co):
+    """{demangled name: dict(symbol, vgpr_count, vgpr_spill_count, sgpr_spill_count, scratch_bytes, lds_bytes)}"""
+    txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True,
+                         check=True).stdout
+    pat = re.compile(r"\.group_segment_fixed_size:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?"
+                     r"\.sgpr_count:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?"
+                     r"\.vgpr_spill_count:\s+(\d+)", re.S)
+    rows = pat.findall(txt)
+    names = demangle([r[1] for r in rows])
+    return {d: dict(symbol=r[1], lds_bytes=int(r[0]), scratch_bytes=int(r[2]), sgpr_count=int(r[3]),
+                    sgpr_spill_count=int(r[4]), vgpr_count=int(r[5]), vgpr_spill_count=int(r[6]))
+            for d, r in zip(names, rows)}
+
+
+def disassemble(co, symbol):
+    """[(addr, mnemonic, operands)] of one kernel."""
+    txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", f"--disassemble-symbols={symbol}", co],
+                         capture_output=True, text=True, check=True).stdout
+    ins = []
+    for line in txt.split("\n"):
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+        if not m:
+            continue
+        mnem, ops, addr = m.group(1), m.group(2), int(m.group(3), 16)
+        tgt = None
+        if mnem.startswith("s_cbranch") or mnem == "s_branch":
+            t = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>", line)
+            base = ins[0][0] if ins else addr
+            tgt = (base + int(t.group(1), 16)) if t else None
+        ins.append((addr, mnem, ops, tgt))
+    return ins
+
+
+def weight(mnem):
+    if not mnem.startswith("v_"):
+        return 0
+    for pat, f in FLOPS:
+        if re.match(pat, mnem):
+            return f
+    return 0
+
+
+class Loop:
+    def __init__(self, header, blocks):
+        self.header, self.blocks, self.children, self.parent = header, set(blocks), [], None
+
+    @property
+    def lo(self):
+        return self.header
+
+
+class CFG:
+    """Basic blocks (split at branch targets and after branches), edges, dominators, natural loops."""
+
+    def __init__(self, ins):
+        self.ins = ins
+        addrs = [i[0] for i in ins]
+        leaders = {addrs[0]}
+        for k, (addr, mnem, ops, tgt) in enumerate(ins):
+            is_br = mnem.startswith("s_cbranch") or mnem == "s_branch"
+            if is_br or mnem in ("s_endpgm", "s_setpc_b64"):
+                if tgt is not None:
+                    leaders.add(tgt)
+                if k + 1 < len(ins):
+                    leaders.add(addrs[k + 1])
+        leaders = sorted(a for a in leaders if a in set(addrs))
+        self.block_of = {}
+        self.blocks = {}  # leader -> [instruction indices]
+        cur = None
+        lead = set(leaders)
+        for k, a in enumerate(addrs):
+            if a in lead:
+                cur = a
+                self.blocks[cur] = []
+            self.blocks[cur].append(k)
+            self.block_of[a] = cur
+        self.succ = {b: [] for b in self.blocks}
+        for b, idx in self.blocks.items():
+            addr, mnem, ops, tgt = ins[idx[-1]]
+            nxt = addrs[idx[-1] + 1] if idx[-1] + 1 < len(ins) else None
+            if mnem == "s_branch":
+                if tgt in self.block_of:
+                    self.succ[b].append(self.block_of[tgt])
+            elif mnem.startswith("s_cbranch"):
+                if tgt in self.block_of:
+                    self.succ[b].append(self.block_of[tgt])
+                if nxt is not None:
+                    self.succ[b].append(nxt)
+            elif mnem in ("s_endpgm", "s_setpc_b64"):
+                pass
+            elif nxt is not None:
+                self.succ[b].append(nxt)
+        self.pred = {b: [] for b in self.blocks}
+        for b, ss in self.succ.items():
+            for s in ss:
+                self.pred[s].append(b)
+        self._dominators(addrs[0])
+        self._loops()
+
+    def _dominators(self, entry):
+        nodes = list(self.blocks)
+        dom = {n: set(nodes) for n in nodes}
+        dom[entry] = {entry}
+        changed = True
+        while changed:
+            changed = False
+            for n in nodes:
+                if n == entry:
+                    continue
+                ps = [dom[p] for p in self.pred[n]]
+                new = (set.intersection(*ps) if ps else set()) | {n}
+                if new != dom[n]:
+                    dom[n], changed = new, True
+        self.dom = dom
+
+    def _loops(self):
+        by_header = {}
+        for u, ss in self.succ.items():
+            for h in ss:
+                if h in self.dom[u]:  # back edge u -> h
+                    body, stack = {h, u}, [u]
+                    while stack:
+                        n = stack.pop()
+                        if n == h:
+                            continue
+                        for p in self.pred[n]:
+                            if p not in body:
+                                body.add(p)
+                                stack.append(p)
+                    by_header.setdefault(h, set()).update(body)
+        loops = [Loop(h, b) for h, b in sorted(by_header.items())]
+        for l in loops:
+            outer = [c for c in loops if c is not l and l.blocks < c.blocks]
+            if outer:
+                l.parent = min(outer, key=lambda c: len(c.blocks))
+                l.parent.children.append(l)
+        self.loops = loops
+
+    def tally(self, blocks):
+        t = dict(valu=0, flops=0, trans=0, packed=0, salu=0, smem=0, vmem=0, lds=0, mfma=0, scratch=0)
+        for b in blocks:
+            for k in self.blocks[b]:
+                addr, mnem, ops, tgt = self.ins[k]
+                if mnem.startswith("v_mfma"):
+                    t["mfma"] += 1
+                elif mnem.startswith("v_"):
+                    t["valu"] += 1
+                    t["flops"] += weight(mnem)
+                    t["trans"] += bool(TRANS.match(mnem))
+                    t["packed"] += bool(PACKED.match(mnem))
+                elif mnem.startswith("s_load") or mnem.startswith("s_buffer_load"):
+                    t["smem"] += 1
+                elif mnem.startswith("s_"):
+                    t["salu"] += 1
+                elif mnem.startswith("ds_"):
+                    t["lds"] += 1
+                elif mnem.startswith("scratch_"):
+                    t["scratch"] += 1
+                    t["vmem"] += 1
+                elif mnem.startswith(("global_", "buffer_", "flat_")):
+                    t["vmem"] += 1
+        return t
+
+    def depth(self, l):
+        d = 0
+        while l.parent is not None:
+            d, l = d + 1, l.parent
+        return d
+
+
+def pair_model(cfg, mean_series_pairs, frac_odd, W=2, frac_short=0.0):
+    """Execution model of gl_pair_kernel / gl_static_kernel in a likelihood / gradient mode, steady state.
+
+    The pixel loop of the CHECK=false instantiation is the FIRST outermost loop that contains an inner loop (the EPL
+    series loop) -- for models without EPL, the outermost loop with the most flops; every trip processes W pixels per
+    lane.  Its blocks are weighted as follows:
+      * blocks that dominate the loop's latch run once per trip,
+      * the inner loop (two series terms per trip) runs `mean_series_pairs` times on average,
+      * a conditional block holding >= 4 packed FMAs is the odd remainder term of the series: probability `frac_odd`,
+      * the inner loop's preheader runs with probability 1 - `frac_short` (series of fewer than two terms skip the loop),
+        the blocks of that bypass with probability `frac_short`,
+      * other conditional blocks (optional loads of the mask / error planes: <= 3 VALU, no flops) are counted as executed.
+    Returns per-lane flops and VALU wave-instructions per PIXEL, and the decomposition."""
+    tops = [l for l in cfg.loops if l.parent is None]
+    cands = [l for l in tops if l.children]
+    tile = cands[0] if cands else max(tops, key=lambda l: cfg.tally(l.blocks)["flops"])
+    inner = sorted(tile.children, key=lambda l: l.header)
+    inner_blocks = set().union(*[c.blocks for c in inner]) if inner else set()
+    own = tile.blocks - inner_blocks
+    latches = [b for b in tile.blocks if tile.header in cfg.succ[b]]
+    mandatory = set(own)
+    for lt in latches:
+        mandatory &= cfg.dom[lt]
+    mandatory |= {tile.header} & own
+    inner_headers = {c.header for c in inner}
+    out = {k: float(v) for k, v in cfg.tally(mandatory).items()}
+    detail = dict(tile_loop_header=hex(tile.header), n_blocks=len(tile.blocks), pixels_per_lane_per_trip=W,
+                  mandatory=cfg.tally(mandatory), inner=[], conditional=[])
+    for c in inner:
+        t = cfg.tally(c.blocks)
+        for k in out:
+            out[k] += t[k] * mean_series_pairs
+        detail["inner"].append(dict(header=hex(c.header), per_trip=t, trips=mean_series_pairs))
+    for b in sorted(own - mandatory):
+        t = cfg.tally([b])
+        if t["packed"] >= 4:
+            prob, why = frac_odd, "odd series term"
+        elif any(h in cfg.succ[b] for h in inner_headers):
+            prob, why = 1.0 - frac_short, "series-loop preheader"
+        elif t["flops"] == 0 and t["valu"] <= 3:
+            prob, why = 1.0, "optional plane load (counted as executed)"
+        else:
+            prob, why = frac_short, "short-series bypass"
+        for k in out:
+            out[k] += t[k] * prob
+        detail["conditional"].append(dict(block=hex(b), per_trip={k: v for k, v in t.items() if v}, probability=prob, what=why))
+    per_pixel = {k: v / W for k, v in out.items()}
+    detail["per_pixel"] = per_pixel
+    return per_pixel, detail
+
+
+def execution_model(co, name, md, series):
+    """Dynamic per-pixel counts of a kernel this tool has an execution model for (the specialised pair / static kernels in a
+    likelihood or gradient mode), else None.  `series`: dict(mean_pair_trips, frac_odd[, frac_short]) of the batch, or None
+    for models without EPL."""
+    m = re.search(r"gl_pair_kernel<(\d+), (float __vector\(2\)|float),", name)
+    W = None
+    if m:
+        W = 2 if "vector" in m.group(2) else 1
+    else:
+        m = re.search(r"gl_static_kernel<(\d+), (\d+),", name)
+        if m:
+            W = int(m.group(2))
+    if W is None or int(m.group(1)) == 0:  # interpreter kernel / image-only mode: no model here
+        return None
+    ins = disassemble(co, md["symbol"])
+    cfg = CFG(ins)
+    s = series or {}
+    per_pixel, detail = pair_model(cfg, float(s.get("mean_pair_trips", 0.0)), float(s.get("frac_odd", 0.0)), W,
+                                   float(s.get("frac_short", 0.0)))
+    return dict(flops_per_pixel=round(per_pixel["flops"], 2), valu_insts_per_pixel=round(per_pixel["valu"], 2),
+                trans_per_pixel=round(per_pixel["trans"], 2), packed_insts_per_pixel=round(per_pixel["packed"], 2),
+                flop_weights="v_pk_fma 4, v_pk_mul/add 2, v_fma 2, v_mul/add/sub 1, transcendental 1, other 0 (per lane)",
+                model=dict(tile_loop_header=detail["tile_loop_header"], mandatory=detail["mandatory"],
+                           inner=detail["inner"], conditional=detail["conditional"]))
+
+
+def find_kernel(meta, pattern):
+    hits = [k for k in meta if pattern in k]
+    if not hits:
+        hits = [k for k in meta if re.search(pattern, k)]
+    if len(hits) != 1:
+        raise SystemExit(f"{len(hits)} kernels match {pattern!r}: {hits[:6]}")
+    return hits[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=LIB)
+    ap.add_argument("--list", action="store_true")
+    ap.add_argument("--kernel", help="substring (or regex) of the demangled kernel name")
+    ap.add_argument("--series-pairs", type=float, default=0.0, help="mean trips of the two-term EPL series loop")
+    ap.add_argument("--frac-odd", type=float, default=0.5, help="fraction of samples with an odd series length")
+    ap.add_argument("--json", action="store_true")
+    args = ap.parse_args()
+    co = code_object(args.lib)
+    meta = kernel_metadata(co)
+    if args.list:
+        for name, m in sorted(meta.items(), key=lambda kv: -kv[1]["vgpr_spill_count"]):
+            print(f"{m['vgpr_count']:4d} vgpr {m['vgpr_spill_count']:4d} vspill {m['sgpr_spill_count']:4d} sspill "
+                  f"{m['scratch_bytes']:5d} B scratch  {name}")
+        return
+    name = find_kernel(meta, args.kernel)
+    ins = disassemble(co, meta[name]["symbol"])
+    cfg = CFG(ins)
+    wm = re.search(r"gl_pair_kernel<\d+, float __vector\(2\)", name)
+    tm = re.search(r"gl_static_kernel<\d+, (\d+),", name)
+    W = 2 if wm else (int(tm.group(1)) if tm else 1)
+    per_pixel, detail = pair_model(cfg, args.series_pairs, args.frac_odd, W)
+    rep = dict(kernel=name, metadata=meta[name], n_instructions=len(ins), whole_kernel_static=cfg.tally(cfg.blocks),
+               loops=[dict(header=hex(l.header), depth=cfg.depth(l), n_blocks=len(l.blocks),
+                           own=cfg.tally(l.blocks - set().union(*[c.blocks for c in l.children]) if l.children else l.blocks))
+                      for l in cfg.loops],
+               model=detail)
+    if args.json:
+        print(json.dumps(rep))
+    else:
+        print(json.dumps(rep, indent=1))
+
+
+if __name__ == "__main__":
+    main()

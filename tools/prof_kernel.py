@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--num-pix", type=int, default=None)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--mode", default="grad", choices=["grad", "fwd", "img", "lstsq"])
+    ap.add_argument("--mode", default="grad", choices=["grad", "fwd", "img", "simpair", "lstsq"])
     ap.add_argument("--direct", action="store_true", help="C3: direct (non-table) shapelets")
     args = ap.parse_args()
     from gigalens_amd import workloads
@@ -52,7 +52,24 @@ def main():
     sim = LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
     packed = sim.pack(wl.prior.sample(wl.batch, seed=0)).contiguous()
     m = sim._model
-    m.set_timing(True)
+    if args.mode == "simpair":
+        # the simulate() boundary itself: gl_simulate_fwd writes the [B,H,W] image, gl_simulate_bwd reads its cotangent --
+        # the pair that really moves the B1 bytes (8N + 8P per sample) through HBM
+        gimg = torch.randn((wl.batch, m.out_h, m.out_w), device=packed.device)
+        m.set_timing(2 * args.iters)
+        for i in range(args.iters):
+            m.simulate_fwd(packed)
+            m.simulate_bwd(packed, gimg)
+        torch.cuda.synchronize()
+        ts = m.timing_drain()
+        fwd, bwd = sorted(ts[0::2][2:]), sorted(ts[1::2][2:])
+        b1 = (8 * m.N + 8 * m.P) * wl.batch
+        mf, mb = fwd[len(fwd) // 2], bwd[len(bwd) // 2]
+        print(f"{wl.name} B={wl.batch} N={m.N} P={m.P} simulate pair: fwd {mf:.4f} ms + bwd {mb:.4f} ms; B1 = {b1 / 1e6:.1f} MB per "
+              f"pair -> {b1 / ((mf + mb) * 1e-3) / 1e9:.1f} GB/s; fwd alone writes {4 * m.N * wl.batch / 1e6:.1f} MB -> "
+              f"{4 * m.N * wl.batch / (mf * 1e-3) / 1e9:.1f} GB/s")
+        return
+    m.set_timing(1)
     ts = []
     for i in range(args.iters):
         if args.mode == "img":
