@@ -13,10 +13,10 @@
 #include <new>
 #include <vector>
 
+#define GL_AUX_KERNELS 1
 #include "gl_host_tables.h"
-#include "gl_kernels.hip.h"
+#include "gl_model.h"
 #include "gl_static.hip.h"
-#include "gl_pair.hip.h"
 #include "gl_post.hip.h"
 #include "gl_positions.hip.h"
 #include "gl_lstsq.hip.h"
@@ -24,9 +24,10 @@
 using namespace glk;
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
+namespace glk {
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -34,12 +35,9 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+}  // namespace glk
 
-#define GL_HIP(call)                                                                              \
-  do {                                                                                            \
-    hipError_t e_ = (call);                                                                       \
-    if (e_ != hipSuccess) return fail(GL_ELAUNCH, "%s failed: %s", #call, hipGetErrorString(e_)); \
-  } while (0)
+namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -50,66 +48,6 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
-struct gl_model {
-  std::vector<CompDesc> comps;
-  int n_lens = 0, n_ll = 0, n_src = 0;
-  int P = 0, D = 0, A = 0, Apad = 0, ncols = 64;
-  bool has_shapelets = false, has_table = false;
-  int height = 0, width = 0, supersample = 1, N = 0;
-  float conversion_factor = 1.f;
-  // device-resident, immutable
-  CompDesc* d_comps = nullptr;
-  float* d_gx = nullptr;
-  float* d_gy = nullptr;
-  int* d_pix = nullptr;
-  float* d_shp_tab = nullptr;
-  int shp_stride = 0;
-  float* d_psf = nullptr;  // effective kernel flip(psf) (*) box(ss)/ss^2, see gl_post.hip.h
-  int psf_h = 0, psf_w = 0;
-  int KH = 1, KW = 1, pad_t = 0, pad_l = 0;
-  bool has_post = false;
-  // unconstrained-space front end (gl_model_set_prior)
-  int d_z = 0;
-  ZCol* d_zcols = nullptr;
-  int* d_src = nullptr;
-  float* d_const = nullptr;
-  int static_id = 0;   // 0 = generic interpreter kernel, >0 = compile-time-specialised composition
-  int static_variant = 0;
-  int pair = 1;        // pixel-pair (packed fp32) form of the specialised kernels
-  // image-position likelihood (gl_model_set_positions)
-  int pos_J = 0, pos_F = 0, lens_params = 0;
-  float* d_pos = nullptr;  // [4][J]: x, y, err_x, err_y
-  int* d_fam = nullptr;    // [F+1]
-  bool has_epl = false;
-  int epl_comp = -1;     // the model's only EPL component, or -1 (none / several)
-  int fam = 0;  // family level of the interpreter variant (gl_main_kernel FAM): 1 dPIE family / catalogues / series, 2 gl_extra.h
-  bool use_order = true;
-  // measurement hooks (gl_model_set_timing): a ring of event pairs around the main-kernel launches, and the host
-  // function of the most recent main launch (gl_model_last_main_kernel)
-  int timing_slots = 0, timing_stride = 1;
-  mutable long long timing_count = 0, timing_calls = 0;
-  std::vector<hipEvent_t> evs;  // 2 * timing_slots
-  mutable const void* last_main_fn = nullptr;
-  // galaxy catalogues of the GL_SCALED components (gl_model_set_catalogue)
-  struct Cat { CatDev dev; std::vector<float> table; };
-  std::vector<Cat> cats;
-  int G = 0;           // galaxies over all catalogues
-  int n_scaled = 0;    // GL_SCALED components
-  CatDev* d_cats = nullptr;
-  float* d_gal_table = nullptr;   // [G][7]
-  float* d_gal_static = nullptr;  // [G][DP_NS]
-  // series-expansion lenses (gl_model_set_series): one coefficient field per GL_SERIES component
-  std::vector<SeriesDev> series;      // device pointers owned by the model
-  std::vector<int> series_comp;       // component of each slot
-  int n_series = 0, n_series_set = 0;
-  SeriesDev* d_series = nullptr;
-  // linear amplitudes (lstsq_simulate): channel k of the basis stack <-> packed parameter column
-  std::vector<int> lin_cols;
-  int* d_lin_cols = nullptr;
-  int tile = 2;          // pixels per thread per tile (template T) for forward-only launches
-  int tile_grad = 2;     // ... and for launches that also produce gradients
-  int target_wgs = 2048;  // work decomposition target (>= 8 workgroups per CU)
-};
 
 namespace {
 
@@ -180,127 +118,6 @@ Workspace carve(const gl_model* m, int B, void* base) {
   return w;
 }
 
-
-// ---- compile-time-specialised compositions (gl_static.hip.h) ------------------------------------------
-// SERSIC and SERSIC_ELLIPSE share one device code path (the spherical profile is the e = 0 member), so
-// signatures are matched after folding SERSIC_ELLIPSE -> SERSIC.
-using L_EplShear = KindList<K_EPL, K_SHEAR>;
-using L_Sie = KindList<K_SIE>;
-using L_SieShear = KindList<K_SIE, K_SHEAR>;
-using C_None = KindList<>;
-using C_Sersic = KindList<K_SERSIC>;
-using C_Shapelets = KindList<K_SHAPELETS>;
-
-enum StaticId { ST_NONE = 0, ST_EPLSHEAR_SERSIC, ST_EPLSHEAR_SERSIC_SERSIC, ST_SIE_SERSIC, ST_EPLSHEAR_SHAPELETS,
-                ST_SIESHEAR_SERSIC_SERSIC, ST_EPLSHEAR_SERSIC_SHAPELETS /* shapelets-demo.ipynb: lens light + shapelet source */ };
-
-int match_static(const gl_model* m) {
-  auto fold = [](int k) { return k == K_SERSIC_ELLIPSE ? (int)K_SERSIC : k; };
-  std::vector<int> L, C, S;
-  for (int i = 0; i < m->n_lens; ++i) L.push_back(m->comps[i].kind);
-  for (int i = 0; i < m->n_ll; ++i) C.push_back(fold(m->comps[m->n_lens + i].kind));
-  for (int i = 0; i < m->n_src; ++i) S.push_back(fold(m->comps[m->n_lens + m->n_ll + i].kind));
-  const std::vector<int> eplshear{K_EPL, K_SHEAR}, sie{K_SIE}, sieshear{K_SIE, K_SHEAR}, none{}, sersic{K_SERSIC},
-      shp{K_SHAPELETS};
-  if (L == eplshear && C == none && S == sersic) return ST_EPLSHEAR_SERSIC;
-  if (L == eplshear && C == sersic && S == sersic) return ST_EPLSHEAR_SERSIC_SERSIC;
-  if (L == sie && C == none && S == sersic) return ST_SIE_SERSIC;
-  if (L == eplshear && C == none && S == shp) return ST_EPLSHEAR_SHAPELETS;
-  if (L == eplshear && C == sersic && S == shp) return ST_EPLSHEAR_SERSIC_SHAPELETS;
-  if (L == sieshear && C == sersic && S == sersic) return ST_SIESHEAR_SERSIC_SERSIC;
-  return ST_NONE;
-}
-
-template <int MODE>
-bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
-  const int T = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
-#define GL_PAIR(WW, LK, CK, SK)                                                           \
-  do {                                                                                    \
-    m->last_main_fn = (const void*)&gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>;            \
-    hipLaunchKernelGGL((gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>), grid, block, shmem, stream, a); \
-  } while (0)
-  if (m->pair) {
-    // waves/SIMD the register budget is declared for: gradient modes keep the EPL / Sersic state of a pixel
-    // pair live between the forward and VJP halves (no spills at 3 resp. 2 waves per SIMD), forward modes fit 4+
-    constexpr bool G = (MODE == IMG_BWD || MODE == LL_GRAD);
-    constexpr int W1 = G ? 3 : 4, W2 = G ? 2 : 4;
-    switch (m->static_id) {
-      case ST_EPLSHEAR_SERSIC:
-        if (m->pair == 4) GL_PAIR(4, L_EplShear, C_None, C_Sersic); else GL_PAIR(W1, L_EplShear, C_None, C_Sersic);
-        return true;
-      case ST_EPLSHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_EplShear, C_Sersic, C_Sersic); return true;
-      case ST_SIE_SERSIC: GL_PAIR(4, L_Sie, C_None, C_Sersic); return true;
-      case ST_SIESHEAR_SERSIC_SERSIC: GL_PAIR(W1, L_SieShear, C_Sersic, C_Sersic); return true;
-      default: break;
-    }
-  }
-#undef GL_PAIR
-#define GL_LAUNCH(TT, WW, LK, CK, SK)                                                        \
-  do {                                                                                       \
-    m->last_main_fn = (const void*)&gl_static_kernel<MODE, TT, WW, LK, CK, SK>;              \
-    hipLaunchKernelGGL((gl_static_kernel<MODE, TT, WW, LK, CK, SK>), grid, block, shmem, stream, a); \
-  } while (0)
-  switch (m->static_id) {
-    case ST_EPLSHEAR_SERSIC:
-      if (T == 4) { if (m->static_variant == 2) GL_LAUNCH(4, 2, L_EplShear, C_None, C_Sersic); else GL_LAUNCH(4, 3, L_EplShear, C_None, C_Sersic); }
-      else if (T == 1) GL_LAUNCH(1, 4, L_EplShear, C_None, C_Sersic);
-      else { if (m->static_variant == 3) GL_LAUNCH(2, 3, L_EplShear, C_None, C_Sersic); else GL_LAUNCH(2, 4, L_EplShear, C_None, C_Sersic); }
-      return true;
-    case ST_EPLSHEAR_SERSIC_SERSIC:
-      if (T == 4) GL_LAUNCH(4, 2, L_EplShear, C_Sersic, C_Sersic); else GL_LAUNCH(2, 4, L_EplShear, C_Sersic, C_Sersic);
-      return true;
-    case ST_SIE_SERSIC:
-      if (T == 4) GL_LAUNCH(4, 4, L_Sie, C_None, C_Sersic); else GL_LAUNCH(2, 4, L_Sie, C_None, C_Sersic);
-      return true;
-    case ST_SIESHEAR_SERSIC_SERSIC:
-      if (T == 4) GL_LAUNCH(4, 4, L_SieShear, C_Sersic, C_Sersic); else GL_LAUNCH(2, 4, L_SieShear, C_Sersic, C_Sersic);
-      return true;
-    case ST_EPLSHEAR_SHAPELETS:
-      if (T == 2) GL_LAUNCH(2, 2, L_EplShear, C_None, C_Shapelets); else if (T == 1) GL_LAUNCH(1, 2, L_EplShear, C_None, C_Shapelets);
-      else return false;
-      return true;
-    case ST_EPLSHEAR_SERSIC_SHAPELETS:
-      if (T == 2) GL_LAUNCH(2, 2, L_EplShear, C_Sersic, C_Shapelets); else if (T == 1) GL_LAUNCH(1, 2, L_EplShear, C_Sersic, C_Shapelets);
-      else return false;
-      return true;
-  }
-#undef GL_LAUNCH
-  return false;
-}
-
-template <int MODE>
-int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream) {
-  dim3 grid(n_chunks, B), block(WG);
-  size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
-  // every timing_stride-th main launch is bracketed by an event pair (an event record costs ~2.5 us of stream time)
-  const bool timed = m->timing_slots && (m->timing_calls++ % m->timing_stride) == 0;
-  const int slot = timed ? (int)(m->timing_count % m->timing_slots) : 0;
-  if (timed) GL_HIP(hipEventRecord(m->evs[2 * slot], stream));
-#define GL_MAIN(TT, S_, F_)                                                              \
-  do {                                                                                   \
-    m->last_main_fn = (const void*)&gl_main_kernel<MODE, TT, S_, F_>;                    \
-    hipLaunchKernelGGL((gl_main_kernel<MODE, TT, S_, F_>), grid, block, shmem, stream, a); \
-  } while (0)
-#define GL_MAIN_FAM(TT, S_) \
-  do { if (m->fam == 2) GL_MAIN(TT, S_, 2); else if (m->fam == 1) GL_MAIN(TT, S_, 1); else GL_MAIN(TT, S_, 0); } while (0)
-  if constexpr (MODE == IMG_BASIS) {  // basis stack of lstsq_simulate: interpreter kernel, one tile shape
-    if (m->has_shapelets) GL_MAIN_FAM(2, true); else GL_MAIN_FAM(2, false);
-  } else if (m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
-    // specialised kernel launched
-  } else {
-    const int Tg = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
-    if (m->has_shapelets) { if (Tg == 4) GL_MAIN_FAM(4, true); else GL_MAIN_FAM(2, true); }
-    else { if (Tg == 4) GL_MAIN_FAM(4, false); else GL_MAIN_FAM(2, false); }
-  }
-#undef GL_MAIN_FAM
-#undef GL_MAIN
-  if (timed) {
-    GL_HIP(hipEventRecord(m->evs[2 * slot + 1], stream));
-    ++m->timing_count;
-  }
-  GL_HIP(hipGetLastError());
-  return GL_OK;
-}
 
 MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   MainArgs a{};
@@ -675,6 +492,20 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     if (!env_tile && !m->has_epl && !m->has_shapelets && !m->fam) m->tile = m->tile_grad = 4;  // cheap profiles: amortise the per-tile accumulation
     if (m->tile == 1) m->tile = 2;
     if (m->tile_grad == 1) m->tile_grad = 2;
+  }
+  if (env_int("GIGALENS_HIP_CLUSTER", 1) && !m->static_id && n_lens_light == 0 && n_lens >= 1 && n_lens <= 8 && n_src >= 1 &&
+      n_src <= 20 && (size_t)64 * m->Apad * sizeof(float) <= 64 * 1024) {
+    bool ok_c = true, ell = false;
+    for (int i = 0; i < n_lens; ++i) ok_c = ok_c && m->comps[i].kind == K_NFW;
+    for (int i = n_lens; i < n_comp; ++i) {
+      ok_c = ok_c && (m->comps[i].kind == K_SERSIC || m->comps[i].kind == K_SERSIC_ELLIPSE);
+      ell = ell || m->comps[i].kind == K_SERSIC_ELLIPSE;
+    }
+    // the kernel addresses the derived / accumulator blocks in closed form: component-major, fixed block sizes
+    for (int i = 0; i < n_lens && ok_c; ++i) ok_c = m->comps[i].d_off == 4 * i && m->comps[i].a_off == NSTAT + NFW_NACC * i;
+    for (int i = 0; i < n_src && ok_c; ++i)
+      ok_c = m->comps[n_lens + i].d_off == 4 * n_lens + 12 * i && m->comps[n_lens + i].a_off == NSTAT + NFW_NACC * n_lens + SER_NACC * i;
+    if (ok_c) m->cluster = ell ? 2 : 1;
   }
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;

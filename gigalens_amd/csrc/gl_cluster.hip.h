@@ -1,0 +1,336 @@
+// gl_cluster.hip.h -- forward+gradient kernel for "N x same kind" cluster models: up to NH NFW halos lensing up to NS
+// Sersic sources (BASELINE config 4: 8 halos + 20 sources, 256 x 256 px; tf/profiles/mass/nfw.py:15-52,
+// tf/profiles/light/sersic.py:29-80, tf/simulator.py:109-156, tf/model.py:89-101).
+//
+// Why not the interpreter (gl_main_kernel): for such a model it spends its time on (a) every profile's forward pass a
+// second time inside its VJP -- 3 quarter-rate transcendentals per source and pixel, the branchy NFW g(X) per halo and
+// pixel -- (b) the component switch and LDS constant loads per (component, tile), and it spills (81 VGPRs under a
+// 128-register budget).  Here
+//   * one thread owns ONE pixel pair (packed fp32 throughout, like gl_pair_kernel) and keeps the forward state of EVERY
+//     component of that pair in registers until its VJP has consumed it: 3 values per source (E, u, log2(R/Rs)) and 3 per
+//     halo (h = g/X^2 and the two factors its VJP needs) -- 6 VGPRs each, 168 for 8 + 20, inside a 256-register budget
+//     (2 waves per SIMD), no spills, nothing evaluated twice;
+//   * the component loops are compile-time loops over the capacity (NH, NS) guarded by wave-uniform counts, so the state is
+//     statically indexed; per-component constants come through scalar loads from the sample's derived row (wave-uniform
+//     address -> SGPR operands): no LDS reads, no descriptor loads in the pixel loop;
+//   * the 4..8 gradient values per component (152 for 8 + 20) cannot each own a register, and summing them into LDS every
+//     tile is what sinks this design: ds_add_f32 by the quad leaders (measured: 3.3 ms, SQ_WAIT_INST_LDS = 31 % of the wave
+//     cycles, VALU busy 39 %; the same kernel without the atomics 1.6 ms) or read-modify-write chains at two waves per SIMD.
+//     Instead FOUR different values share one register: a 4 x 4 transpose-reduction inside every quad (6 selects + 3 DPP
+//     adds per four values) leaves in lane q of each quad the quad's sum of value q, and that register is added to a
+//     per-lane running sum -- 38 VGPRs for all 152 accumulators, no LDS instruction in the pixel loop, one store per
+//     running sum at the end of the chunk; spherical Sersic sources skip the two ellipticity accumulators altogether and
+//     are packed in pairs (2 x 6 values = 3 registers).  Summation order is fixed: bitwise reproducible.
+// Same derived-constant layout, accumulator layout, partial rows and finalize as the other kernels.
+#pragma once
+#include "gl_pair.hip.h"
+
+namespace glk {
+
+#ifdef GL_CLUSTER_FENCE
+#define GL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GL_SCHED_FENCE() ((void)0)
+#endif
+
+template <class V> struct NfwStateC { V h, w, uu; };
+template <class V> struct SerStateC { V E, u; };  // log2(R/Rs) is recomputed in the VJP (1 transcendental): 40 VGPRs for 20 sources
+
+// NFW forward on a pixel pair, leaving what the VJP needs (nfw_vjp_v written once, split at the state):
+//   a = K0 h;  cot(K0) = ga h;  gX0 = ga p, p = [X0 > 1e-6] K0 h';  t = gR0 / R0 = ga w, w = [R0 > 1e-7] p / (Rs R0);
+//   cot(Rs) = -gX0 X0 / Rs = -ga uu, uu = p X0 / Rs        (ga = g . (dx, dy))
+template <class V>
+__device__ __forceinline__ void nfw_fwd_c(const float* __restrict__ d, V x, V y, V& bx, V& by, NfwStateC<V>& st) {
+  const float invrs = d[NFW_INVRS], K0 = d[NFW_K0];
+  V dx = x - d[NFW_CX], dy = y - d[NFW_CY];
+  V r2 = dx * dx + dy * dy;
+  V R0 = sqrt_(r2);
+  V X0 = vmax(R0, V(1e-7f)) * invrs;  // nfw.py:26
+  V X = vmax(X0, V(1e-6f));           // nfw.py:37
+  V g, gp;
+  nfw_gw_v(X, g, gp);
+  V iX = rcp(X);
+  V iX2 = iX * iX;
+  st.h = g * iX2;
+  V hp = gp * iX2 - (st.h + st.h) * iX;
+  V p = (X0 > V(1e-6f)) ? hp * K0 : V(0.f);
+  V iR0 = (r2 > V(0.f)) ? rsq_(r2) : V(0.f);
+  st.w = (R0 > V(1e-7f)) ? p * invrs * iR0 : V(0.f);
+  st.uu = p * X0 * invrs;
+  V a = st.h * K0;
+  bx -= a * dx;
+  by -= a * dy;
+}
+template <class V>
+__device__ __forceinline__ void nfw_vjp_c(const float* __restrict__ d, V x, V y, V gx, V gy, const NfwStateC<V>& st,
+                                          V (&va)[NFW_NACC]) {
+  V dx = x - d[NFW_CX], dy = y - d[NFW_CY];
+  V ga = gx * dx + gy * dy;
+  V a = st.h * d[NFW_K0];
+  V t = ga * st.w;
+  va[NFWA_CX] = -(gx * a + t * dx);
+  va[NFWA_CY] = -(gy * a + t * dy);
+  va[NFWA_RS] = -(ga * st.uu);
+  va[NFWA_K0] = ga * st.h;
+}
+
+// Sersic forward / VJP with the state split (sersic_fwd_v / sersic_vjp_v of gl_vec.hip.h); ELL = false is the spherical
+// profile (sersic.py:23-66 passes e1 = e2 = 0: no rotation, no axis-ratio stretch, no ellipticity gradients)
+template <class V, bool ELL>
+__device__ __forceinline__ V sersic_fwd_c(const float* __restrict__ d, V x, V y, SerStateC<V>& st) {
+  V dx = x - d[SER_CX], dy = y - d[SER_CY];
+  V r2;
+  if constexpr (ELL) {
+    const float c = d[SER_C], s = d[SER_S];
+    V xt1 = (dx * c + dy * s) * d[SER_SQ], xt2 = (dy * c - dx * s) * d[SER_ISQ];
+    r2 = xt1 * xt1 + xt2 * xt2;
+  } else {
+    r2 = dx * dx + dy * dy;
+  }
+  V L2 = log2_(r2) * 0.5f + d[SER_L2IRS];  // log2(R / R_sersic) without the square root
+  st.u = exp2_(L2 * d[SER_INVN]);
+  st.E = vexp<V>((st.u - 1.f) * -d[SER_BN]);
+  return st.E * d[SER_IE];
+}
+template <class V, bool ELL>
+__device__ __forceinline__ void sersic_vjp_c(const float* __restrict__ d, V x, V y, const SerStateC<V>& st, V gI,
+                                             V (&va)[SER_NACC], V& gpx, V& gpy) {
+  V dx = x - d[SER_CX], dy = y - d[SER_CY];
+  V gE = gI * st.E;
+  V tI = gE * d[SER_IE];
+  V guu = -(tI * st.u) * d[SER_BN];
+  V gL = guu * d[SER_INVN];
+  V gdx, gdy;
+  if constexpr (ELL) {
+    const float c = d[SER_C], s = d[SER_S], sq = d[SER_SQ], isq = d[SER_ISQ];
+    V a1 = dx * c + dy * s, a2 = dy * c - dx * s;
+    V xt1 = a1 * sq, xt2 = a2 * isq;
+    V r2 = xt1 * xt1 + xt2 * xt2;
+    auto pos = r2 > V(0.f);
+    V k = pos ? gL * rcp(r2) : V(0.f);
+    V gxt1 = k * xt1, gxt2 = k * xt2;
+    V ga1 = gxt1 * sq, ga2 = gxt2 * isq;
+    gdx = ga1 * c - ga2 * s;
+    gdy = ga1 * s + ga2 * c;
+    va[SERA_PHI] = ga1 * a2 - ga2 * a1;
+    va[SERA_SQ] = gxt1 * a1 - gxt2 * a2 * (isq * isq);
+    V L2 = log2_(r2) * 0.5f + d[SER_L2IRS];
+    va[SERA_INVN] = pos ? guu * L2 : V(0.f);  // x ln2 when it is summed
+  } else {
+    V r2 = dx * dx + dy * dy;
+    auto pos = r2 > V(0.f);
+    V k = pos ? gL * rcp(r2) : V(0.f);
+    gdx = k * dx;
+    gdy = k * dy;
+    va[SERA_PHI] = V(0.f);
+    va[SERA_SQ] = V(0.f);
+    V L2 = log2_(r2) * 0.5f + d[SER_L2IRS];
+    va[SERA_INVN] = pos ? guu * L2 : V(0.f);
+  }
+  va[SERA_CX] = -gdx;
+  va[SERA_CY] = -gdy;
+  va[SERA_L] = gL;
+  va[SERA_BN] = -(tI * (st.u - 1.f));
+  va[SERA_IE] = gE;
+  gpx += gdx;
+  gpy += gdy;
+}
+
+// 4 x 4 transpose-reduction inside a quad: lane q of every quad receives  sum over the quad's lanes of v_q.
+// Step 1 exchanges with lane ^ 1 (even lanes keep v0 / v2, odd lanes v1 / v3), step 2 with lane ^ 2.
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
+}
+__device__ __forceinline__ float quad_transpose_sum(float v0, float v1, float v2, float v3, bool odd, bool hi) {
+  const float r01 = (odd ? v1 : v0) + dpp_xor1(odd ? v0 : v1);
+  const float r23 = (odd ? v3 : v2) + dpp_xor1(odd ? v2 : v3);
+  return (hi ? r23 : r01) + dpp_xor2(hi ? r01 : r23);
+}
+
+// accumulator slot (inside the sample's accumulator row) of lane q of running sum g -- the inverse of the packing in the loop
+template <int NH, bool ELL> __device__ __forceinline__ int cluster_slot(int g, int q, int n_h, int n_s) {
+  if (g < NH) return g < n_h ? NSTAT + NFW_NACC * g + q : -1;
+  const int aS = NSTAT + NFW_NACC * n_h;
+  g -= NH;
+  if (ELL) {
+    const int s = g >> 1;
+    return s < n_s ? aS + SER_NACC * s + 4 * (g & 1) + q : -1;
+  }
+  const int flat = 4 * (g % 3) + q;  // 0..11 inside a pair of spherical sources: 6 values each
+  const int s = 2 * (g / 3) + flat / 6, k = flat % 6;
+  const int map[6] = {SERA_CX, SERA_CY, SERA_L, SERA_INVN, SERA_BN, SERA_IE};
+  return s < n_s ? aS + SER_NACC * s + map[k] : -1;
+}
+
+template <int MODE, int NH, int NS, bool ELL, int WAVES>
+__global__ void __launch_bounds__(WG, WAVES) gl_cluster_kernel(MainArgs a, int n_h, int n_s) {
+  static_assert(MODE == IMG_BWD || MODE == LL_GRAD, "gradient modes only (forward modes: gl_main_kernel)");
+  using V = v2f;
+  constexpr int W = 2;
+  constexpr int SERP = (SER_ND + 2 + 3) & ~3, NFWP = (NFW_ND + 3) & ~3;
+  extern __shared__ float smem[];
+  float* s_acc = smem;  // [64][Apad]
+  const int tid = threadIdx.x;
+  const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
+  for (int i = tid; i < 64 * a.Apad; i += WG) s_acc[i] = 0.f;
+  __syncthreads();
+  // this sample's derived constants: wave-uniform address -> scalar loads
+  const float* __restrict__ gder = a.derived + (size_t)b * a.D;
+  const float* __restrict__ dH = gder;
+  const float* __restrict__ dS = gder + NFWP * n_h;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool odd = lane & 1, hi = lane & 2;
+  float* col = s_acc + (wave * 16 + (lane >> 2)) * a.Apad;
+  // running sums: lane q of every quad owns value q of four accumulators per register (see quad_transpose_sum)
+  constexpr int NR = NH + (ELL ? 2 * NS : 3 * ((NS + 1) / 2));
+  float racc[NR];
+#pragma unroll
+  for (int g = 0; g < NR; ++g) racc[g] = 0.f;
+  const bool has_err = a.err != nullptr, has_mask = a.mask != nullptr, has_pix = a.pix != nullptr;
+  V st0 = V(0.f), st1 = V(0.f);
+  const int p0 = chunk * a.chunk;
+  const int p1 = min(p0 + a.chunk, a.N);
+
+  auto tile = [&](int base, auto check_tag) {
+    constexpr bool CHECK = decltype(check_tag)::value;
+    unsigned jj[W], pidx[W];
+    bool valid[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      int j = base + w * WG + tid;
+      valid[w] = CHECK ? (j < p1) : true;
+      jj[w] = (unsigned)(valid[w] ? j : p1 - 1);
+      pidx[w] = has_pix ? (unsigned)a.pix[jj[w]] : jj[w];
+    }
+    const V x = V{a.gx[jj[0]], a.gx[jj[1]]}, y = V{a.gy[jj[0]], a.gy[jj[1]]};
+    V vmask = V(1.f);
+    if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
+    V bx = x, by = y, m = V(0.f);
+    NfwStateC<V> hst[NH];
+    SerStateC<V> sst[NS];
+    // ---- ray-shoot: beta = (x, y) - sum_h alpha_h   (tf/simulator.py:72-78) ----
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      if (h < n_h) {
+        nfw_fwd_c<V>(dH + NFWP * h, x, y, bx, by, hst[h]);
+        GL_SCHED_FENCE();
+      }
+    // ---- render the sources at beta (tf/simulator.py:128-138) ----
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (s < n_s) {
+        m += sersic_fwd_c<V, ELL>(dS + SERP * s, bx, by, sst[s]);
+        GL_SCHED_FENCE();
+      }
+    auto nanp = m != m;
+    m = (nanp ? V(0.f) : m) * a.out_scale;  // NaN -> 0 (tf/simulator.py:140), then x det(T) (:156)
+    V gm;
+    if (MODE == IMG_BWD) {
+      const float* row = a.gimg + (size_t)b * a.img_stride;
+      V g = V{row[pidx[0]], row[pidx[1]]};
+      gm = nanp ? V(0.f) : (CHECK ? g * vmask : g) * a.out_scale;
+    } else {
+      V o = V{a.obs[pidx[0]], a.obs[pidx[1]]}, w = vmask, e = V(1.f);
+      if (CHECK && has_mask) w = w * V{a.mask[pidx[0]], a.mask[pidx[1]]};
+      if (has_err) e = V{a.err[pidx[0]], a.err[pidx[1]]};
+      V dmo = m - o;
+      V s2 = has_err ? e * e : m * a.inv_t + a.bg2;  // tf/model.py:92-95
+      V is2 = rcp(s2);
+      V nm = vlog<V>(s2 * (float)(2 * kPi));
+      V c2 = __builtin_elementwise_fma(nm, V(0.f), dmo * dmo * is2);  // + 0 * nm: a NaN sigma reaches chi^2 like in the reference
+      if (CHECK) {
+        auto use = w != V(0.f);
+        st0 += use ? c2 * w : V(0.f);
+        st1 += use ? nm * w : V(0.f);
+      } else {
+        st0 += c2;
+        st1 += nm;
+      }
+      V g = has_err ? -(dmo * is2) : (dmo * dmo * is2 - 1.f) * (is2 * (0.5f * a.inv_t)) - dmo * is2;
+      gm = nanp ? V(0.f) : (CHECK ? g * w : g) * a.out_scale;
+    }
+    // ---- source VJPs: parameter gradients and the cotangent of beta ----
+    V gbx = V(0.f), gby = V(0.f);
+    if constexpr (ELL) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        if (s < n_s) {
+          V va[SER_NACC];
+          sersic_vjp_c<V, true>(dS + SERP * s, bx, by, sst[s], gm, va, gbx, gby);
+          float v[SER_NACC];
+#pragma unroll
+          for (int k = 0; k < SER_NACC; ++k) v[k] = va[k].x + va[k].y;
+          v[SERA_INVN] *= (float)kLn2;
+          racc[NH + 2 * s] += quad_transpose_sum(v[0], v[1], v[2], v[3], odd, hi);
+          racc[NH + 2 * s + 1] += quad_transpose_sum(v[4], v[5], v[6], v[7], odd, hi);
+        }
+    } else {
+#pragma unroll
+      for (int p = 0; p < (NS + 1) / 2; ++p)
+        if (2 * p < n_s) {  // two spherical sources: 2 x (CX, CY, L, INVN, BN, IE) = three registers
+          float v[12];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int s = 2 * p + j;
+            if (s < NS && s < n_s) {
+              V va[SER_NACC];
+              sersic_vjp_c<V, false>(dS + SERP * s, bx, by, sst[s < NS ? s : 0], gm, va, gbx, gby);
+              v[6 * j + 0] = va[SERA_CX].x + va[SERA_CX].y;
+              v[6 * j + 1] = va[SERA_CY].x + va[SERA_CY].y;
+              v[6 * j + 2] = va[SERA_L].x + va[SERA_L].y;
+              v[6 * j + 3] = (va[SERA_INVN].x + va[SERA_INVN].y) * (float)kLn2;
+              v[6 * j + 4] = va[SERA_BN].x + va[SERA_BN].y;
+              v[6 * j + 5] = va[SERA_IE].x + va[SERA_IE].y;
+            } else {
+#pragma unroll
+              for (int k = 0; k < 6; ++k) v[6 * j + k] = 0.f;
+            }
+          }
+          racc[NH + 3 * p] += quad_transpose_sum(v[0], v[1], v[2], v[3], odd, hi);
+          racc[NH + 3 * p + 1] += quad_transpose_sum(v[4], v[5], v[6], v[7], odd, hi);
+          racc[NH + 3 * p + 2] += quad_transpose_sum(v[8], v[9], v[10], v[11], odd, hi);
+          GL_SCHED_FENCE();
+        }
+    }
+    // ---- halo VJPs with the cotangent -g_beta (beta = x - sum alpha) ----
+    gbx = -gbx;
+    gby = -gby;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      if (h < n_h) {
+        V va[NFW_NACC];
+        nfw_vjp_c<V>(dH + NFWP * h, x, y, gbx, gby, hst[h], va);
+        racc[h] += quad_transpose_sum(va[0].x + va[0].y, va[1].x + va[1].y, va[2].x + va[2].y, va[3].x + va[3].y, odd, hi);
+        GL_SCHED_FENCE();
+      }
+  };
+  {
+    const bool plain = !has_mask;
+    int base = p0;
+    if (plain)
+      for (; base + WG * W <= p1; base += WG * W) tile(base, std::false_type{});
+    for (; base < p1; base += WG * W) tile(base, std::true_type{});
+  }
+  // ---- epilogue: every lane stores its running sums into its quad's column, then the 64 columns are summed ----
+#pragma unroll
+  for (int g = 0; g < NR; ++g) {
+    const int slot = cluster_slot<NH, ELL>(g, lane & 3, n_h, n_s);
+    if (slot >= 0) col[slot] = racc[g];
+  }
+  if (MODE == LL_GRAD) {
+    const float c2 = quad_sum(st0.x + st0.y), nm = quad_sum(st1.x + st1.y);
+    if ((lane & 3) == 0) { col[0] = c2; col[1] = nm; }
+  }
+  __syncthreads();
+  float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
+  for (int k = tid; k < a.A; k += WG) {
+    float v = 0.f;
+    for (int j = 0; j < 64; ++j) v += s_acc[j * a.Apad + k];
+    out[k] = v;
+  }
+}
+
+}  // namespace glk

@@ -177,6 +177,7 @@ template <int G> __device__ __forceinline__ void wave_acc(float (&acc)[G], const
   }
 }
 
+#ifdef GL_AUX_KERNELS  // the non-template kernels around the main one: compiled into the main translation unit only
 // ---- per-sample prep: raw parameter rows -> derived constants --------------------------------
 // `cost` (optional): per-sample dispatch cost = the EPL trip count, written by the thread of component `cost_comp`
 // (models with exactly one EPL), so that gl_order_kernel reads one coalesced int array
@@ -351,6 +352,8 @@ __global__ void __launch_bounds__(256) gl_order_kernel(const CompDesc* __restric
   __syncthreads();
   for (int b = threadIdx.x; b < B; b += 256) order[atomicAdd(&offs[cost(b)], 1)] = b;
 }
+
+#endif  // GL_AUX_KERNELS
 
 // ---- T-pixel EPL: series loop outermost so one LDS table read serves T pixels -------------------
 template <int T> __device__ __forceinline__ void epl_fwd_T(const float* d, const float (&x)[T], const float (&y)[T],
@@ -939,6 +942,7 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
   }
 }
 
+#ifdef GL_AUX_KERNELS
 // ---- finalize: sum chunk partials (fixed order), chain rule to raw parameters -------------------
 // With zcols != null the gradient is carried on to the unconstrained vector z and the log-prior
 // + log|J| is added:  log_prob = loglike + sum_k [log p_k(x_k) + fldj_k(z_k)]   (tf/model.py:164-167).
@@ -1395,5 +1399,7 @@ __global__ void __launch_bounds__(256) gl_series_eval_kernel(const float* __rest
   out0[i] = theta_E[b] * ax;
   out1[i] = theta_E[b] * ay;
 }
+
+#endif  // GL_AUX_KERNELS
 
 }  // namespace glk

@@ -1,0 +1,135 @@
+// gl_launch.hip.h -- the launcher of the dominant ("main") kernel of a call: picks the kernel instantiation for the model
+// (specialised pair / static kernels, the cluster kernel, or the interpreter) and launches it.  Included by the
+// gl_launch_mode*.hip translation units, each of which instantiates it for ONE mode so that the kernel families compile
+// in parallel.
+#pragma once
+#include "gl_model.h"
+#include "gl_static.hip.h"
+#include "gl_pair.hip.h"
+#include "gl_cluster.hip.h"
+
+namespace glk {
+
+// ---- compile-time-specialised compositions (gl_static.hip.h) ------------------------------------------
+// SERSIC and SERSIC_ELLIPSE share one device code path (the spherical profile is the e = 0 member), so
+// signatures are matched after folding SERSIC_ELLIPSE -> SERSIC.
+using L_EplShear = KindList<K_EPL, K_SHEAR>;
+using L_Sie = KindList<K_SIE>;
+using L_SieShear = KindList<K_SIE, K_SHEAR>;
+using C_None = KindList<>;
+using C_Sersic = KindList<K_SERSIC>;
+using C_Shapelets = KindList<K_SHAPELETS>;
+
+enum StaticId { ST_NONE = 0, ST_EPLSHEAR_SERSIC, ST_EPLSHEAR_SERSIC_SERSIC, ST_SIE_SERSIC, ST_EPLSHEAR_SHAPELETS,
+                ST_SIESHEAR_SERSIC_SERSIC, ST_EPLSHEAR_SERSIC_SHAPELETS /* shapelets-demo.ipynb: lens light + shapelet source */ };
+
+template <int MODE>
+bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
+  const int T = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
+#define GL_PAIR(WW, LK, CK, SK)                                                           \
+  do {                                                                                    \
+    m->last_main_fn = (const void*)&gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>;            \
+    hipLaunchKernelGGL((gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>), grid, block, shmem, stream, a); \
+  } while (0)
+  if (m->pair) {
+    // waves/SIMD the register budget is declared for: gradient modes keep the EPL / Sersic state of a pixel
+    // pair live between the forward and VJP halves (no spills at 3 resp. 2 waves per SIMD), forward modes fit 4+
+    constexpr bool G = (MODE == IMG_BWD || MODE == LL_GRAD);
+    constexpr int W1 = G ? 3 : 4, W2 = G ? 2 : 4;
+    switch (m->static_id) {
+      case ST_EPLSHEAR_SERSIC:
+        if (m->pair == 4) GL_PAIR(4, L_EplShear, C_None, C_Sersic); else GL_PAIR(W1, L_EplShear, C_None, C_Sersic);
+        return true;
+      case ST_EPLSHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_EplShear, C_Sersic, C_Sersic); return true;
+      case ST_SIE_SERSIC: GL_PAIR(4, L_Sie, C_None, C_Sersic); return true;
+      case ST_SIESHEAR_SERSIC_SERSIC: GL_PAIR(W1, L_SieShear, C_Sersic, C_Sersic); return true;
+      default: break;
+    }
+  }
+#undef GL_PAIR
+#define GL_LAUNCH(TT, WW, LK, CK, SK)                                                        \
+  do {                                                                                       \
+    m->last_main_fn = (const void*)&gl_static_kernel<MODE, TT, WW, LK, CK, SK>;              \
+    hipLaunchKernelGGL((gl_static_kernel<MODE, TT, WW, LK, CK, SK>), grid, block, shmem, stream, a); \
+  } while (0)
+  switch (m->static_id) {
+    case ST_EPLSHEAR_SERSIC:
+      if (T == 4) { if (m->static_variant == 2) GL_LAUNCH(4, 2, L_EplShear, C_None, C_Sersic); else GL_LAUNCH(4, 3, L_EplShear, C_None, C_Sersic); }
+      else if (T == 1) GL_LAUNCH(1, 4, L_EplShear, C_None, C_Sersic);
+      else { if (m->static_variant == 3) GL_LAUNCH(2, 3, L_EplShear, C_None, C_Sersic); else GL_LAUNCH(2, 4, L_EplShear, C_None, C_Sersic); }
+      return true;
+    case ST_EPLSHEAR_SERSIC_SERSIC:
+      if (T == 4) GL_LAUNCH(4, 2, L_EplShear, C_Sersic, C_Sersic); else GL_LAUNCH(2, 4, L_EplShear, C_Sersic, C_Sersic);
+      return true;
+    case ST_SIE_SERSIC:
+      if (T == 4) GL_LAUNCH(4, 4, L_Sie, C_None, C_Sersic); else GL_LAUNCH(2, 4, L_Sie, C_None, C_Sersic);
+      return true;
+    case ST_SIESHEAR_SERSIC_SERSIC:
+      if (T == 4) GL_LAUNCH(4, 4, L_SieShear, C_Sersic, C_Sersic); else GL_LAUNCH(2, 4, L_SieShear, C_Sersic, C_Sersic);
+      return true;
+    case ST_EPLSHEAR_SHAPELETS:
+      if (T == 2) GL_LAUNCH(2, 2, L_EplShear, C_None, C_Shapelets); else if (T == 1) GL_LAUNCH(1, 2, L_EplShear, C_None, C_Shapelets);
+      else return false;
+      return true;
+    case ST_EPLSHEAR_SERSIC_SHAPELETS:
+      if (T == 2) GL_LAUNCH(2, 2, L_EplShear, C_Sersic, C_Shapelets); else if (T == 1) GL_LAUNCH(1, 2, L_EplShear, C_Sersic, C_Shapelets);
+      else return false;
+      return true;
+  }
+#undef GL_LAUNCH
+  return false;
+}
+
+template <int MODE>
+int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream) {
+  dim3 grid(n_chunks, B), block(WG);
+  size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
+  // every timing_stride-th main launch is bracketed by an event pair (an event record costs ~2.5 us of stream time)
+  const bool timed = m->timing_slots && (m->timing_calls++ % m->timing_stride) == 0;
+  const int slot = timed ? (int)(m->timing_count % m->timing_slots) : 0;
+  if (timed) GL_HIP(hipEventRecord(m->evs[2 * slot], stream));
+#define GL_MAIN(TT, S_, F_)                                                              \
+  do {                                                                                   \
+    m->last_main_fn = (const void*)&gl_main_kernel<MODE, TT, S_, F_>;                    \
+    hipLaunchKernelGGL((gl_main_kernel<MODE, TT, S_, F_>), grid, block, shmem, stream, a); \
+  } while (0)
+#define GL_MAIN_FAM(TT, S_) \
+  do { if (m->fam == 2) GL_MAIN(TT, S_, 2); else if (m->fam == 1) GL_MAIN(TT, S_, 1); else GL_MAIN(TT, S_, 0); } while (0)
+  bool done = false;
+  if constexpr (MODE == IMG_BWD || MODE == LL_GRAD) {
+    if (m->cluster && a.parts == 7u) {  // N x same-kind cluster model: forward state of every component kept in registers
+      const size_t sh = (size_t)64 * m->Apad * sizeof(float);
+#define GL_CLUSTER(NH_, NS_, E_, W_)                                                                     \
+  do {                                                                                                 \
+    m->last_main_fn = (const void*)&gl_cluster_kernel<MODE, NH_, NS_, E_, W_>;                          \
+    hipLaunchKernelGGL((gl_cluster_kernel<MODE, NH_, NS_, E_, W_>), grid, block, sh, stream, a, m->n_lens, m->n_src); \
+  } while (0)
+      const bool small = m->n_lens <= 4 && m->n_src <= 8;
+      if (m->cluster == 2) { if (small) GL_CLUSTER(4, 8, true, 3); else GL_CLUSTER(8, 20, true, 2); }
+      else { if (small) GL_CLUSTER(4, 8, false, 3); else GL_CLUSTER(8, 20, false, 2); }
+#undef GL_CLUSTER
+      done = true;
+    }
+  }
+  if (done) {
+  } else if constexpr (MODE == IMG_BASIS) {  // basis stack of lstsq_simulate: interpreter kernel, one tile shape
+    if (m->has_shapelets) GL_MAIN_FAM(2, true); else GL_MAIN_FAM(2, false);
+  } else if (m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
+    // specialised kernel launched
+  } else {
+    const int Tg = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
+    if (m->has_shapelets) { if (Tg == 4) GL_MAIN_FAM(4, true); else GL_MAIN_FAM(2, true); }
+    else { if (Tg == 4) GL_MAIN_FAM(4, false); else GL_MAIN_FAM(2, false); }
+  }
+#undef GL_MAIN_FAM
+#undef GL_MAIN
+  if (timed) {
+    GL_HIP(hipEventRecord(m->evs[2 * slot + 1], stream));
+    ++m->timing_count;
+  }
+  GL_HIP(hipGetLastError());
+  return GL_OK;
+}
+
+
+}  // namespace glk

@@ -1,0 +1,100 @@
+// gl_model.h -- the library-internal model descriptor and error helper shared by the translation units of
+// libgigalens_hip.so (gigalens_hip.hip: C ABI + host logic; gl_launch_mode*.hip: one instantiation of the main-kernel
+// launcher per mode, compiled in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/gigalens_hip.h"
+#include "gl_kernels.hip.h"
+
+namespace glk {
+// sets the thread-local message gl_last_error() returns; returns `code`
+__attribute__((visibility("hidden"))) int fail(int code, const char* fmt, ...);
+}  // namespace glk
+
+#define GL_HIP(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) return glk::fail(GL_ELAUNCH, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+using glk::CompDesc;
+using glk::CatDev;
+using glk::SeriesDev;
+using glk::ZCol;
+
+struct gl_model {
+  std::vector<CompDesc> comps;
+  int n_lens = 0, n_ll = 0, n_src = 0;
+  int P = 0, D = 0, A = 0, Apad = 0, ncols = 64;
+  bool has_shapelets = false, has_table = false;
+  int height = 0, width = 0, supersample = 1, N = 0;
+  float conversion_factor = 1.f;
+  // device-resident, immutable
+  CompDesc* d_comps = nullptr;
+  float* d_gx = nullptr;
+  float* d_gy = nullptr;
+  int* d_pix = nullptr;
+  float* d_shp_tab = nullptr;
+  int shp_stride = 0;
+  float* d_psf = nullptr;  // effective kernel flip(psf) (*) box(ss)/ss^2, see gl_post.hip.h
+  int psf_h = 0, psf_w = 0;
+  int KH = 1, KW = 1, pad_t = 0, pad_l = 0;
+  bool has_post = false;
+  // unconstrained-space front end (gl_model_set_prior)
+  int d_z = 0;
+  ZCol* d_zcols = nullptr;
+  int* d_src = nullptr;
+  float* d_const = nullptr;
+  int static_id = 0;   // 0 = generic interpreter kernel, >0 = compile-time-specialised composition
+  int static_variant = 0;
+  int pair = 1;        // pixel-pair (packed fp32) form of the specialised kernels
+  int cluster = 0;     // gl_cluster_kernel serves the gradient modes: 1 = halos + spherical Sersic sources, 2 = elliptical sources
+  // image-position likelihood (gl_model_set_positions)
+  int pos_J = 0, pos_F = 0, lens_params = 0;
+  float* d_pos = nullptr;  // [4][J]: x, y, err_x, err_y
+  int* d_fam = nullptr;    // [F+1]
+  bool has_epl = false;
+  int epl_comp = -1;     // the model's only EPL component, or -1 (none / several)
+  int fam = 0;  // family level of the interpreter variant (gl_main_kernel FAM): 1 dPIE family / catalogues / series, 2 gl_extra.h
+  bool use_order = true;
+  // measurement hooks (gl_model_set_timing): a ring of event pairs around the main-kernel launches, and the host
+  // function of the most recent main launch (gl_model_last_main_kernel)
+  int timing_slots = 0, timing_stride = 1;
+  mutable long long timing_count = 0, timing_calls = 0;
+  std::vector<hipEvent_t> evs;  // 2 * timing_slots
+  mutable const void* last_main_fn = nullptr;
+  // galaxy catalogues of the GL_SCALED components (gl_model_set_catalogue)
+  struct Cat { CatDev dev; std::vector<float> table; };
+  std::vector<Cat> cats;
+  int G = 0;           // galaxies over all catalogues
+  int n_scaled = 0;    // GL_SCALED components
+  CatDev* d_cats = nullptr;
+  float* d_gal_table = nullptr;   // [G][7]
+  float* d_gal_static = nullptr;  // [G][DP_NS]
+  // series-expansion lenses (gl_model_set_series): one coefficient field per GL_SERIES component
+  std::vector<SeriesDev> series;      // device pointers owned by the model
+  std::vector<int> series_comp;       // component of each slot
+  int n_series = 0, n_series_set = 0;
+  SeriesDev* d_series = nullptr;
+  // linear amplitudes (lstsq_simulate): channel k of the basis stack <-> packed parameter column
+  std::vector<int> lin_cols;
+  int* d_lin_cols = nullptr;
+  int tile = 2;          // pixels per thread per tile (template T) for forward-only launches
+  int tile_grad = 2;     // ... and for launches that also produce gradients
+  int target_wgs = 2048;  // work decomposition target (>= 8 workgroups per CU)
+};
+
+namespace glk {
+// launches the dominant kernel of a call for one mode (gl_launch.hip.h); explicit instantiations live in gl_launch_mode*.hip
+template <int MODE>
+int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream);
+int match_static(const gl_model* m);
+extern template int launch_main<IMG_FWD>(const gl_model*, const MainArgs&, int, int, hipStream_t);
+extern template int launch_main<IMG_BWD>(const gl_model*, const MainArgs&, int, int, hipStream_t);
+extern template int launch_main<LL_FWD>(const gl_model*, const MainArgs&, int, int, hipStream_t);
+extern template int launch_main<LL_GRAD>(const gl_model*, const MainArgs&, int, int, hipStream_t);
+extern template int launch_main<IMG_BASIS>(const gl_model*, const MainArgs&, int, int, hipStream_t);
+}  // namespace glk

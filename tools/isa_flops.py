@@ -43,13 +43,22 @@ PACKED = re.compile(r"^v_pk_(fma|mul|add)_f32")
 
 
 def code_object(lib=LIB, workdir=None):
-    """Path of the gfx950 code object extracted from `lib` (cached next to the temp dir)."""
+    """Paths of the gfx950 code objects extracted from `lib`: the library is several translation units, each contributing one
+    offload bundle to the .hip_fatbin section."""
     workdir = workdir or tempfile.mkdtemp(prefix="gl_isa_")
-    fat, co = os.path.join(workdir, "fatbin"), os.path.join(workdir, "gfx950.co")
+    fat = os.path.join(workdir, "fatbin")
     subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
-    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
-    return co
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(magic, blob)] + [len(blob)]
+    cos = []
+    for i in range(len(starts) - 1):
+        part, co = os.path.join(workdir, f"bundle{i}"), os.path.join(workdir, f"gfx950_{i}.co")
+        open(part, "wb").write(blob[starts[i]:starts[i + 1]])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={part}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+        cos.append(co)
+    return cos
 
 
 def demangle(names):
@@ -57,18 +66,24 @@ def demangle(names):
     return out.strip().split("\n")
 
 
-def kernel_metadata(co):
-    """{demangled name: dict(symbol, vgpr_count, vgpr_spill_count, sgpr_spill_count, scratch_bytes, lds_bytes)}"""
-    txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True,
-                         check=True).stdout
+def kernel_metadata(cos):
+    """{demangled name: dict(symbol, co, vgpr_count, vgpr_spill_count, sgpr_spill_count, scratch_bytes, lds_bytes)}"""
+    if isinstance(cos, str):
+        cos = [cos]
     pat = re.compile(r"\.group_segment_fixed_size:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?"
                      r"\.sgpr_count:\s+(\d+).*?\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?"
                      r"\.vgpr_spill_count:\s+(\d+)", re.S)
-    rows = pat.findall(txt)
-    names = demangle([r[1] for r in rows])
-    return {d: dict(symbol=r[1], lds_bytes=int(r[0]), scratch_bytes=int(r[2]), sgpr_count=int(r[3]),
-                    sgpr_spill_count=int(r[4]), vgpr_count=int(r[5]), vgpr_spill_count=int(r[6]))
-            for d, r in zip(names, rows)}
+    out = {}
+    for co in cos:
+        txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True,
+                             check=True).stdout
+        rows = pat.findall(txt)
+        if not rows:
+            continue
+        for d, r in zip(demangle([r[1] for r in rows]), rows):
+            out[d] = dict(symbol=r[1], co=co, lds_bytes=int(r[0]), scratch_bytes=int(r[2]), sgpr_count=int(r[3]),
+                          sgpr_spill_count=int(r[4]), vgpr_count=int(r[5]), vgpr_spill_count=int(r[6]))
+    return out
 
 
 def disassemble(co, symbol):
@@ -292,7 +307,7 @@ def execution_model(co, name, md, series):
             W = int(m.group(2))
     if W is None or int(m.group(1)) == 0:  # interpreter kernel / image-only mode: no model here
         return None
-    ins = disassemble(co, md["symbol"])
+    ins = disassemble(md["co"], md["symbol"])
     cfg = CFG(ins)
     s = series or {}
     per_pixel, detail = pair_model(cfg, float(s.get("mean_pair_trips", 0.0)), float(s.get("frac_odd", 0.0)), W,
@@ -330,13 +345,13 @@ def main():
                   f"{m['scratch_bytes']:5d} B scratch  {name}")
         return
     name = find_kernel(meta, args.kernel)
-    ins = disassemble(co, meta[name]["symbol"])
+    ins = disassemble(meta[name]["co"], meta[name]["symbol"])
     cfg = CFG(ins)
     wm = re.search(r"gl_pair_kernel<\d+, float __vector\(2\)", name)
     tm = re.search(r"gl_static_kernel<\d+, (\d+),", name)
     W = 2 if wm else (int(tm.group(1)) if tm else 1)
     per_pixel, detail = pair_model(cfg, args.series_pairs, args.frac_odd, W)
-    rep = dict(kernel=name, metadata=meta[name], n_instructions=len(ins), whole_kernel_static=cfg.tally(cfg.blocks),
+    rep = dict(kernel=name, metadata={k: v for k, v in meta[name].items() if k != "co"}, n_instructions=len(ins), whole_kernel_static=cfg.tally(cfg.blocks),
                loops=[dict(header=hex(l.header), depth=cfg.depth(l), n_blocks=len(l.blocks),
                            own=cfg.tally(l.blocks - set().union(*[c.blocks for c in l.children]) if l.children else l.blocks))
                       for l in cfg.loops],

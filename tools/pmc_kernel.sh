@@ -1,0 +1,15 @@
+#!/bin/bash
+# PMC passes on the native call of one workload (run on the GPU box):  bash tools/pmc_kernel.sh <tag> <workload> [extra prof_kernel args]
+# Each counter group is its own rocprofv3 run with --kernel-trace only, as the pool requires.
+set -u
+TAG=$1; WL=$2; shift 2
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $R/tools/prof_kernel.py --workload $WL --iters 6 $EXTRA > $OUT/$n.log 2>&1; }
+EXTRA="$*"
+run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+run mix SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD
+run clk GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU
+python3 $R/tools/pmc_summary.py $OUT
