@@ -41,7 +41,7 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
         if (m->pair == 4) GL_PAIR(4, L_EplShear, C_None, C_Sersic); else GL_PAIR(W1, L_EplShear, C_None, C_Sersic);
         return true;
       case ST_EPLSHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_EplShear, C_Sersic, C_Sersic); return true;
-      case ST_SIE_SERSIC: GL_PAIR(4, L_Sie, C_None, C_Sersic); return true;
+      case ST_SIE_SERSIC: GL_PAIR(W1, L_Sie, C_None, C_Sersic); return true;  // gradient mode: 4 VGPRs spill under the 128-register budget of 4 waves
       case ST_SIESHEAR_SERSIC_SERSIC: GL_PAIR(W1, L_SieShear, C_Sersic, C_Sersic); return true;
       default: break;
     }

@@ -7,9 +7,11 @@ forward+gradient call.  Data parallelism follows the JAX substrate: the sample b
 (one process per GPU); MAP and HMC need no collective, SVI all-reduces ONE fused buffer
 ``[ELBO, dELBO/dmu (d), dELBO/dL_packed (d(d+1)/2)]`` per step (``lax.pmean``, jax/inference.py:123-128).
 
-Differences from the TFP drivers, stated plainly: the HMC here is preconditioned HMC with dual-averaging
-step-size adaptation and a fixed number of leapfrog steps (TFP's gradient-based trajectory-length adaptation
-is not restated); SMC (adaptive tempering + HMC mutations) follows the reference's driver.
+The TFP kernels the reference composes (PreconditionedHamiltonianMonteCarlo, GradientBasedTrajectoryLengthAdaptation,
+Dual-averaging / Simple step-size adaptation, sample_sequential_monte_carlo) are third party and not installed here; their
+published algorithms are restated: ChEES trajectory-length adaptation (Hoffman, Radul & Sountsov 2021) with Halton-jittered
+trajectory lengths, dual averaging (Hoffman & Gelman 2014), adaptive tempered SMC.  Stochastic drivers cannot be pinned
+bit for bit against TFP (different random streams); they are checked on targets with known answers.
 """
 import math
 from typing import Callable, Optional, Tuple
@@ -183,8 +185,52 @@ def svi_step_buffer(mu: torch.Tensor, l_packed: torch.Tensor,
     return gdist.allreduce_mean_(buf)
 
 
+def _halton2(i: int) -> float:
+    """i-th point of the base-2 Halton (van der Corput) sequence in (0, 1): the trajectory-length jitter."""
+    f, r = 0.5, 0.0
+    while i > 0:
+        r += f * (i & 1)
+        i >>= 1
+        f *= 0.5
+    return r
+
+
+class _TrajectoryLength:
+    """State of the ChEES trajectory-length adaptation (see ``ModellingSequence.HMC``): the maximum trajectory length ``T``,
+    the running mean of the squared gradient and the iterate average of ``log T``."""
+
+    def __init__(self, initial, rate=0.025):
+        self.T = float(initial)
+        self.T_avg = float(initial)
+        self.rate = float(rate)
+        self.sq = 0.0
+        self.step = 0
+
+    def current(self, adapting):
+        return self.T if adapting or self.step == 0 else self.T_avg
+
+    def update(self, x, x_new, v_new, accept_prob, jitter, eps, max_leapfrog_steps):
+        """One ascent step on ChEES.  ``x`` / ``x_new``: states before the transition / proposed, ``(n, d)``; ``v_new``: final
+        velocity ``d x_new / d t``; ``accept_prob (n,)``; the jittered length is ``jitter * T`` so ``d / dT = jitter * d / dt``."""
+        a = accept_prob.to(x.dtype)
+        xc = x - x.mean(0, keepdim=True)
+        xn = x_new - (a[:, None] * x_new).sum(0, keepdim=True) / (a.sum() + 1e-20)
+        diff = (xn * xn).sum(-1) - (xc * xc).sum(-1)
+        g = jitter * diff * (xn * v_new).sum(-1)  # d/dT of 1/4 diff^2, per chain
+        g = torch.where((a > 1e-4) & torch.isfinite(g), g, torch.zeros_like(g))
+        grad = float((g * a).sum() / (a.sum() + 1e-20))
+        self.step += 1
+        self.sq = 0.95 * self.sq + 0.05 * grad * grad
+        sq_hat = self.sq / (1.0 - 0.95 ** self.step)
+        log_update = min(max(self.rate * grad / math.sqrt(sq_hat + 1e-20), -0.35), 0.35)
+        T = self.T * math.exp(log_update)
+        self.T = min(T, eps * max_leapfrog_steps)  # never ask for more than max_leapfrog_steps steps
+        w = self.step ** -0.5
+        self.T_avg = math.exp(w * math.log(self.T) + (1.0 - w) * math.log(1e-10 + self.T_avg))
+
+
 class ModellingSequence:
-    """Drop-in for ``gigalens.tf.inference.ModellingSequence`` (MAP / SVI / HMC)."""
+    """Drop-in for ``gigalens.tf.inference.ModellingSequence`` (MAP / SVI / HMC / SMC)."""
 
     def __init__(self, phys_model, prob_model, sim_config):
         self.phys_model = phys_model
@@ -293,10 +339,21 @@ class ModellingSequence:
         return (self.q_mean, self.q_scale_tril), losses
 
     def HMC(self, q_z, init_eps=0.3, init_l=3, n_hmc=50, num_burnin_steps=250, num_results=750,
-            max_leapfrog_steps=30, adapt_rate=0.05, adapt_mode="dual", seed=3, target_accept=0.75):
-        """tf/inference.py:95-182: preconditioned HMC (momentum precision = SVI covariance) with dual-averaging
-        step-size adaptation during burn-in.  Chains are sharded over ranks with no collective
-        (jax/inference.py:157-208); samples are gathered along the chain axis at the end."""
+            max_leapfrog_steps=30, adapt_rate=0.05, adapt_mode="dual", seed=3, target_accept=0.75,
+            trajectory_adaptation_rate=0.025):
+        """tf/inference.py:95-182: preconditioned HMC (momentum precision = SVI covariance) wrapped, like the reference's
+        kernel stack, in gradient-based trajectory-length adaptation and a step-size adaptation, both active for the first
+        ``int(0.8 * num_burnin_steps)`` transitions (:140,150-162).  Chains are sharded over ranks with no collective
+        (jax/inference.py:157-208); samples are gathered along the chain axis at the end.
+
+        Trajectory length (``tfe.mcmc.GradientBasedTrajectoryLengthAdaptation`` with its default ChEES criterion; Hoffman,
+        Radul & Sountsov 2021): every transition integrates for ``h_t * T`` with ``h_t`` the base-2 Halton sequence in (0, 1)
+        and ``T`` the maximum trajectory length, i.e. ``ceil(h_t T / eps)`` leapfrog steps clipped to
+        ``[1, max_leapfrog_steps]``; ``T`` starts at ``init_eps * init_l`` and climbs the gradient of
+        ``ChEES = 1/4 E[(|x' - E x'|^2 - |x - E x|^2)^2]`` estimated over the chains (acceptance-weighted, the final
+        velocity as ``d x' / d T``) with an RMSProp-normalised step on ``log T`` clipped to +-0.35, kept below
+        ``eps * max_leapfrog_steps``; after the adaptation the iterate average of ``log T`` is used.  With several ranks
+        each rank adapts on its own chains (the JAX driver adapts per device too)."""
         if adapt_mode not in ("dual", "simple"):
             raise ValueError(f"Invalid adaptation mode {adapt_mode}, the options are 'simple' and 'dual'")  # :163-164
         rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
@@ -321,9 +378,11 @@ class ModellingSequence:
             return lp, g
 
         lp, g = value_and_grad(z)
-        n_leap = int(min(max(init_l, 1), max_leapfrog_steps))
+        max_leapfrog_steps = max(int(max_leapfrog_steps), 1)
+        num_adaptation_steps = int(num_burnin_steps * 0.8)  # :140
         log_eps, log_eps_bar, h_bar, mu_da = math.log(init_eps), 0.0, 0.0, math.log(10 * init_eps)
-        samples, accept_hist = [], []
+        traj = _TrajectoryLength(init_eps * min(max(int(init_l), 1), max_leapfrog_steps), trajectory_adaptation_rate)
+        samples, accept_hist, leap_hist = [], [], []
         native = on_gpu and z.dtype == torch.float32
         if native:  # one launch per kick+drift, one per Metropolis step (gl_hmc_kick_drift / gl_hmc_accept)
             z, g, lp = z.contiguous(), g.contiguous().clone(), lp.contiguous().clone()
@@ -332,7 +391,12 @@ class ModellingSequence:
             acc_buf = torch.empty(n_local, dtype=torch.float32, device=z.device)
         for it in range(num_burnin_steps + num_results):
             eps = math.exp(log_eps)
+            adapting = it < num_adaptation_steps
+            jitter = _halton2(it + 1)
+            n_leap = int(min(max(math.ceil(jitter * traj.current(adapting) / eps), 1), max_leapfrog_steps))
+            leap_hist.append(n_leap)
             p0 = rnd(n_local, d) @ Linv_T.T
+            z_prev = z.clone() if adapting else None
             if native:
                 _native.hmc_kick_drift(p0, g, 0.5 * eps, z, Sigma_c, eps, pn, zn)
                 for i in range(n_leap):
@@ -340,8 +404,10 @@ class ModellingSequence:
                     if i < n_leap - 1:
                         _native.hmc_kick_drift(pn, gn, eps, zn, Sigma_c, eps, pn, zn)
                 u = torch.rand(n_local, generator=gen, device=gen.device)
+                if adapting:
+                    z_prop, v_prop = zn.clone(), (pn + 0.5 * eps * gn) @ Sigma
                 _native.hmc_accept(z, g, lp, zn, gn.contiguous(), lpn.contiguous(), p0, pn, 0.5 * eps, L_c, u, acc_buf)
-                a_dev = acc_buf.mean()
+                acc_prob = acc_buf
             else:
                 zn, pn, gn, lpn = z, p0, g, lp
                 pn = pn + 0.5 * eps * gn
@@ -354,30 +420,35 @@ class ModellingSequence:
                 log_acc = (lpn - ke1) - (lp - ke0)
                 log_acc = torch.where(torch.isfinite(log_acc), log_acc, torch.full_like(log_acc, -float("inf")))
                 acc = torch.log(torch.rand(n_local, generator=gen, device=gen.device).to(pm.device)) < log_acc
+                z_prop, v_prop = zn, pn @ Sigma
                 z = torch.where(acc[:, None], zn, z)
                 g = torch.where(acc[:, None], gn, g)
                 lp = torch.where(acc, lpn, lp)
-                a_dev = torch.exp(torch.clamp(log_acc, max=0.0)).mean()
+                acc_prob = torch.exp(torch.clamp(log_acc, max=0.0))
+            a_dev = acc_prob.mean()
             accept_hist.append(a_dev)  # read back once at the end; only the adaptation below needs it on the host
-            a = float(a_dev) if it < num_burnin_steps else 0.0
-            if it < num_burnin_steps and adapt_mode == "simple":
-                # tfp.mcmc.SimpleStepSizeAdaptation (tf/inference.py:159-162): multiplicative nudge towards the target
-                log_eps += math.log1p(adapt_rate) if a > target_accept else -math.log1p(adapt_rate)
-            elif it < num_burnin_steps:  # Nesterov dual averaging (Hoffman & Gelman 2014, alg. 5)
-                m = it + 1
-                h_bar = (1 - 1 / (m + 10)) * h_bar + (target_accept - a) / (m + 10)
-                log_eps = mu_da - math.sqrt(m) / adapt_rate * h_bar
-                eta = m ** -0.75
-                log_eps_bar = eta * log_eps + (1 - eta) * log_eps_bar
-                if it == num_burnin_steps - 1:
-                    log_eps = log_eps_bar
-            else:
+            if adapting:
+                traj.update(z_prev, z_prop, v_prop, acc_prob, jitter, eps, max_leapfrog_steps)
+                a = float(a_dev)
+                if adapt_mode == "simple":
+                    # tfp.mcmc.SimpleStepSizeAdaptation (tf/inference.py:159-162): multiplicative nudge towards the target
+                    log_eps += math.log1p(adapt_rate) if a > target_accept else -math.log1p(adapt_rate)
+                else:  # Nesterov dual averaging (Hoffman & Gelman 2014, alg. 5)
+                    m = it + 1
+                    h_bar = (1 - 1 / (m + 10)) * h_bar + (target_accept - a) / (m + 10)
+                    log_eps = mu_da - math.sqrt(m) / adapt_rate * h_bar
+                    eta = m ** -0.75
+                    log_eps_bar = eta * log_eps + (1 - eta) * log_eps_bar
+                    if it == num_adaptation_steps - 1:
+                        log_eps = log_eps_bar
+            if it >= num_burnin_steps:
                 samples.append(z.clone())
         out = torch.stack(samples)  # (num_results, n_local, d)
         if world > 1:
             out = gdist.gather_rows(out.permute(1, 0, 2).contiguous()).permute(1, 0, 2)
         accept_hist = torch.stack(accept_hist).tolist() if accept_hist else []
-        return out, {"accept": accept_hist, "step_size": math.exp(log_eps), "num_leapfrog_steps": n_leap}
+        return out, {"accept": accept_hist, "step_size": math.exp(log_eps), "num_leapfrog_steps": leap_hist,
+                     "max_trajectory_length": traj.current(False)}
 
     def SMC(self, start=None, num_particles=1000, num_ensembles=1, num_leapfrog_steps=10, post_sampling_steps=100,
             ess_threshold_ratio=0.5, max_sampling_per_stage=8, target="pixels", auxiliar="positions", seed=1,

@@ -115,9 +115,10 @@ class LensSimulator(LensSimulatorInterface):
     """
 
     def __init__(self, phys_model, sim_config: SimulatorConfig, bs: int, supersampled_kernel=None):
-        """``supersampled_kernel``: PSF already sampled on the supersampled grid.  The reference derives it from
-        ``sim_config.kernel`` with lenstronomy's ``subgrid_kernel`` (tf/simulator.py:62-65), a third-party routine
-        that is not restated here: with ``supersample > 1`` pass the supersampled PSF explicitly."""
+        """``sim_config.kernel`` with ``supersample > 1`` is brought to the supersampled grid like the reference does
+        (tf/simulator.py:60-70: lenstronomy's ``subgrid_kernel(kernel, supersample, odd=True)``, restated in
+        gigalens_amd/kernel_util.py -- third party, parity unpinned).  ``supersampled_kernel`` overrides it with a PSF
+        already sampled on the supersampled grid."""
         super().__init__(phys_model, sim_config, bs)
         self.device = _native.device()
         self.supersample = int(sim_config.supersample)
@@ -147,11 +148,8 @@ class LensSimulator(LensSimulatorInterface):
         if supersampled_kernel is not None:
             psf = np.asarray(supersampled_kernel, dtype=np.float32)
         elif sim_config.kernel is not None:
-            if ss != 1:
-                raise NotImplementedError(
-                    "supersample > 1 with a PSF needs lenstronomy's subgrid_kernel (third party, not restated); "
-                    "pass LensSimulator(..., supersampled_kernel=<PSF sampled on the supersampled grid>)")
-            psf = np.asarray(sim_config.kernel, dtype=np.float32)
+            from gigalens_amd.kernel_util import subgrid_kernel
+            psf = np.asarray(subgrid_kernel(np.asarray(sim_config.kernel), ss, odd=True), dtype=np.float32)
         self.kernel = psf
         comps = ([_native.component_of(p) for p in phys_model.lenses]
                  + [_native.component_of(p) for p in phys_model.lens_light]

@@ -811,18 +811,86 @@ def light_eval(profile, x, y, **kw):
 
 
 # --------------------------------------------------------------------------
-# PSF helper (third party, "parity unpinned" for supersample>1)
+# PSF helper (third party: lenstronomy; restated from its published source, "parity unpinned" for supersample>1)
 # --------------------------------------------------------------------------
-def subgrid_kernel(kernel, subgrid_res, odd=True, num_iter=100):
-    """lenstronomy ``kernel_util.subgrid_kernel`` (used at tf/simulator.py:62-65).
-    Identity for subgrid_res==1.  For subgrid_res>1 lenstronomy interpolates the
-    PSF onto the finer grid and iteratively corrects it so that re-averaging gives
-    back the input kernel; that third-party routine is NOT restated here (parity
-    unpinned) -- callers must pass an already-supersampled kernel."""
+def _re_size_array(x_in, y_in, values, x_out, y_out):
+    """lenstronomy ``image_util.re_size_array``: ``scipy.interpolate.interp2d(x_in, y_in, values, kind='linear')(x_out, y_out)``
+    -- bilinear on the regular grid, nearest-edge outside it; ``values[j, i]`` sits at ``(x_in[i], y_in[j])``."""
+    tmp = np.stack([np.interp(x_out, x_in, row) for row in values])          # along x for every input row
+    return np.stack([np.interp(y_out, y_in, tmp[:, i]) for i in range(tmp.shape[1])], axis=1)
+
+
+def _averaging_even_kernel(kernel_high_res, subgrid_res):
+    """lenstronomy ``kernel_util.averaging_even_kernel``: an odd-sized fine kernel re-binned at an even factor, centred; fine
+    cells fully inside a coarse pixel add to it, cells on a border are split in halves (quarters at corners)."""
+    n_high_in = len(kernel_high_res)
+    n_low = int(round(n_high_in / subgrid_res + 0.5))
+    if n_low % 2 == 0:
+        n_low += 1
+    n_high = int(n_low * subgrid_res - 1)
+    if n_high == n_high_in:
+        edges = kernel_high_res
+    else:
+        i0 = int((n_high - n_high_in) / 2)
+        edges = np.zeros((n_high, n_high))
+        edges[i0:-i0, i0:-i0] = kernel_high_res
+    low = np.zeros((n_low, n_low))
+    for i in range(subgrid_res - 1):
+        for j in range(subgrid_res - 1):
+            low += edges[i::subgrid_res, j::subgrid_res]
+    i = subgrid_res - 1
+    for j in range(subgrid_res - 1):
+        low[1:, :] += edges[i::subgrid_res, j::subgrid_res] / 2
+        low[:-1, :] += edges[i::subgrid_res, j::subgrid_res] / 2
+    j = subgrid_res - 1
+    for i in range(subgrid_res - 1):
+        low[:, 1:] += edges[i::subgrid_res, j::subgrid_res] / 2
+        low[:, :-1] += edges[i::subgrid_res, j::subgrid_res] / 2
+    corner = edges[subgrid_res - 1::subgrid_res, subgrid_res - 1::subgrid_res]
+    low[1:, 1:] += corner / 4
+    low[:-1, 1:] += corner / 4
+    low[1:, :-1] += corner / 4
+    low[:-1, :-1] += corner / 4
+    return low
+
+
+def subgrid_kernel(kernel, subgrid_res, odd=False, num_iter=100):
+    """lenstronomy ``Util.kernel_util.subgrid_kernel`` (used at tf/simulator.py:62-65 with ``odd=True``), THIRD PARTY: not under
+    /root/reference and not installed here, so this is the published algorithm (lenstronomy 1.9.x) restated step by step --
+    **parity unpinned**.  Interpolate onto the finer grid, normalise, then iterate ``num_iter`` times: re-bin to the input
+    pixel scale, correct the working kernel by the mismatch, re-interpolate, normalise."""
+    subgrid_res = int(subgrid_res)
+    kernel = np.asarray(kernel, dtype=np.float64)
     if subgrid_res == 1:
-        return np.asarray(kernel)
-    raise NotImplementedError("subgrid_kernel for supersample>1 is an unpinned third-party routine; "
-                              "pass a PSF already sampled on the supersampled grid")
+        return kernel
+    nx, ny = kernel.shape
+    x_in = np.linspace(1. / nx / 2, 1 - 1. / nx / 2, nx)
+    y_in = np.linspace(1. / nx / 2, 1 - 1. / nx / 2, ny)  # lenstronomy writes d_y = 1 / nx as well (square kernels)
+    nx_new, ny_new = nx * subgrid_res, ny * subgrid_res
+    if odd:
+        if nx_new % 2 == 0:
+            nx_new -= 1
+        if ny_new % 2 == 0:
+            ny_new -= 1
+    x_out = np.linspace(1. / nx_new / 2., 1 - 1. / nx_new / 2., nx_new)
+    y_out = np.linspace(1. / ny_new / 2., 1 - 1. / ny_new / 2., ny_new)
+    kernel_input = kernel.copy()
+    kernel_subgrid = _re_size_array(x_in, y_in, kernel_input, x_out, y_out)
+    kernel_subgrid = kernel_subgrid / kernel_subgrid.sum()
+    for _ in range(max(num_iter, 1)):
+        if subgrid_res % 2 == 0:
+            kernel_pixel = _averaging_even_kernel(kernel_subgrid, subgrid_res)
+        else:  # util.averaging(grid, numGrid, numPix): block MEANS
+            kernel_pixel = kernel_subgrid.reshape(nx, nx_new // nx, nx, nx_new // nx).mean(3).mean(1)
+        kernel_pixel = kernel_pixel / kernel_pixel.sum()  # kernel_norm: the block MEANS of the odd branch carry 1 / subgrid_res^2
+        delta = kernel - kernel_pixel
+        temp_kernel = kernel_input + delta
+        kernel_subgrid = _re_size_array(x_in, y_in, temp_kernel, x_out, y_out)
+        kernel_subgrid = kernel_subgrid / kernel_subgrid.sum()
+        kernel_input = temp_kernel
+    if subgrid_res % 2 == 0:
+        return kernel_subgrid
+    return kernel_subgrid / kernel_subgrid.sum()
 
 
 # --------------------------------------------------------------------------

@@ -33,15 +33,17 @@ def fx():
     return {k: g[k] for k in g.files}
 
 
-def tolerance(fd, k, floor=0.0):
+def tolerance(fd, k, floor=0.0, amp=1.0):
+    """``amp``: size of the coordinates in units of the focus distance's own scale -- the cancellation is between numbers of
+    the size of the focus ordinate 2 sqrt(e) r_w (10 for the r_cut = 10 cases), so the lost digits scale with it."""
     d = np.minimum(fd, 1.0)
-    return 2e-13 / d * (1.0 + (3.0 / d) ** k) + 1e-11 * 8.0 ** k + floor
+    return 2e-13 * amp / d * (1.0 + (3.0 / d) ** k) + 1e-11 * 8.0 ** k + floor
 
 
-def check(got, want, fd, k, what, floor=0.0, min_checked=0.5):
+def check(got, want, fd, k, what, floor=0.0, min_checked=0.5, amp=1.0):
     """|got - want| <= tol(point, order) * scale(order); returns the share of points that were comparable."""
     sc = np.abs(want).max()
-    tol = tolerance(fd, k, floor)
+    tol = tolerance(fd, k, floor, amp)
     ok = tol <= 3e-2
     err = np.abs(got - want) / sc
     bad = ok & ~(err <= tol)

@@ -1,0 +1,47 @@
+"""Register budgets of the kernels the BASELINE configs dispatch: no VGPR spills, no scratch traffic.
+
+CPU half: the code-object metadata of the shipped library (tools/isa_flops.py reads the AMDGPU notes of every translation
+unit's gfx950 code object) for the instantiations the dispatch tables of csrc/gl_launch.hip.h select for configs C1-C5 --
+the names are the ones rocprofv3 lists in profiles/ and the GPU half re-derives from live launches
+(tests/test_gpu_parity.py::test_dispatched_kernels_do_not_spill asks the library which kernel it launched)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+V2 = "float __vector(2)"
+EPLSHEAR, SIE, NONE, SERSIC, SHAPELETS = "glk::KindList<1, 4>", "glk::KindList<2>", "glk::KindList<>", "glk::KindList<16>", "glk::KindList<18>"
+
+# config -> kernels of simulate() [IMG_FWD=0], its VJP [IMG_BWD=1], log-likelihood [LL_FWD=2] and fused forward+gradient [LL_GRAD=3]
+DISPATCHED = {
+    "C1 SIE | Sersic": [f"gl_pair_kernel<{m}, {V2}, {w}, {SIE}, {NONE}, {SERSIC} >" for m, w in ((0, 4), (1, 3), (2, 4), (3, 3))],
+    "C2 EPL+Shear | Sersic": [f"gl_pair_kernel<{m}, {V2}, {w}, {EPLSHEAR}, {NONE}, {SERSIC} >" for m, w in ((0, 4), (1, 3), (2, 4), (3, 3))],
+    "C3 EPL+Shear | Shapelets": [f"gl_static_kernel<{m}, {t}, 2, {EPLSHEAR}, {NONE}, {SHAPELETS} >" for m, t in ((0, 2), (1, 1), (2, 2), (3, 1))],
+    "C4 / C5 8 NFW | 20 Sersic": ["gl_main_kernel<0, 4, false, 0>", "gl_cluster_kernel<1, 8, 20, false, 2>",
+                                  "gl_main_kernel<2, 4, false, 0>", "gl_cluster_kernel<3, 8, 20, false, 2>"],
+}
+
+
+@pytest.fixture(scope="module")
+def metadata():
+    import isa_flops as isa
+    if not os.path.exists(isa.LIB):
+        pytest.skip("library not built")
+    return isa.kernel_metadata(isa.code_object())
+
+
+@pytest.mark.parametrize("config", sorted(DISPATCHED))
+def test_dispatched_instantiations_do_not_spill(metadata, config):
+    for pat in DISPATCHED[config]:
+        hits = [k for k in metadata if pat in k]
+        assert len(hits) == 1, (pat, hits)
+        md = metadata[hits[0]]
+        assert md["vgpr_spill_count"] == 0, (hits[0], md)
+        assert md["vgpr_count"] <= 256
+        if md["scratch_bytes"]:  # a reserved private segment is tolerated only if no instruction touches it
+            import isa_flops as isa
+            ins = isa.disassemble(md["co"], md["symbol"])
+            assert not [i for i in ins if i[1].startswith("scratch_")], (hits[0], md["scratch_bytes"])

@@ -20,7 +20,7 @@ TRUTH = {  # tf-demo.ipynb cell 5
 }
 
 
-def _setup():
+def _setup(supersample=1):
     from gigalens_amd.model import PhysicalModel
     from gigalens_amd.profiles.light.sersic import SersicEllipse
     from gigalens_amd.profiles.mass.epl import EPL
@@ -29,7 +29,7 @@ def _setup():
     obs = np.load(os.path.join(HERE, "demo.npy"))
     psf = np.load(os.path.join(HERE, "psf.npy")).astype(np.float32)
     phys = PhysicalModel([EPL(50), Shear()], [SersicEllipse()], [SersicEllipse()])
-    cfg = SimulatorConfig(delta_pix=0.065, num_pix=60, supersample=1, kernel=psf)
+    cfg = SimulatorConfig(delta_pix=0.065, num_pix=60, supersample=supersample, kernel=psf)
     return obs, psf, phys, cfg
 
 
@@ -47,19 +47,36 @@ def test_oracle_explains_reference_demo_image():
     assert float(ref.stats_pixels(rs0, tt, obs, 0.2, 100.0)[1]) > 1.4
 
 
+def test_oracle_explains_reference_demo_image_at_supersample_2():
+    """The notebook's own configuration (tf-demo.ipynb cell 6: ``SimulatorConfig(delta_pix=0.065, num_pix=60, supersample=2,
+    kernel=psf)``), which needs lenstronomy's ``subgrid_kernel`` (restated, parity unpinned): the truth parameters still
+    explain the reference's image (measured 0.981; the notebook's cell-9 print of this number was stripped from the
+    committed outputs).  A naive supersampled PSF (each PSF pixel split into 2 x 2) does not: 1.33."""
+    from oracle import ref_torch as ref
+    obs, psf, phys, cfg = _setup(supersample=2)
+    tt = {k: [{n: torch.tensor([v], dtype=torch.float64) for n, v in d.items()} for d in lst] for k, lst in TRUTH.items()}
+    rs = ref.RefSimulator(phys, cfg, 1, dtype=torch.float64)
+    assert rs.flat_kernel.shape == (25, 25)
+    red = float(ref.stats_pixels(rs, tt, obs, 0.2, 100.0)[1])
+    assert 0.95 < red < 1.05, red
+    naive = ref.RefSimulator(phys, cfg, 1, dtype=torch.float64, supersampled_kernel=np.kron(psf, np.ones((2, 2)) / 4))
+    assert float(ref.stats_pixels(naive, tt, obs, 0.2, 100.0)[1]) > 1.2
+
+
 @pytest.mark.gpu
-def test_hip_explains_reference_demo_image():
+@pytest.mark.parametrize("supersample", [1, 2, 3])
+def test_hip_explains_reference_demo_image(supersample):
     from gigalens_amd import prior as tfd
     from gigalens_amd.model import ForwardProbModel
     from gigalens_amd.simulator import LensSimulator
     from oracle import ref_torch as ref
-    obs, psf, phys, cfg = _setup()
+    obs, psf, phys, cfg = _setup(supersample)
     sim = LensSimulator(phys, cfg, bs=1)
     prior = tfd.JointDistributionNamed(dict(lens_mass=tfd.JointDistributionSequential(
         [tfd.JointDistributionNamed(dict(theta_E=tfd.Normal(0, 1)))])))
     pm = ForwardProbModel(prior, obs, 0.2, 100.0, include_positions=False)
     ll, red = pm.stats_pixels(sim, TRUTH)
-    assert 0.95 < float(red) < 1.05, float(red)
+    assert 0.94 < float(red) < 1.06, float(red)  # measured: 0.999 / 0.981 / 1.036 at supersample 1 / 2 / 3
     rs = ref.RefSimulator(phys, cfg, 1, dtype=torch.float64)
     tt = {k: [{n: torch.tensor([np.float32(v)], dtype=torch.float64) for n, v in d.items()} for d in lst] for k, lst in TRUTH.items()}
     ll_o, red_o = ref.stats_pixels(rs, tt, obs, 0.2, 100.0)
