@@ -9,10 +9,16 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
-for W in C2 C3 C4 C6; do
+for W in C2 C3 C4 C5 C6; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_$W -- python3 $R/tools/prof_kernel.py --workload $W --iters 20 > $OUT/kernel_stats_$W.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_C3L -- python3 $R/tools/prof_kernel.py --workload C3L --mode lstsq --iters 8 > $OUT/kernel_stats_C3L.log 2>&1
+# the simulate() boundary itself at C2: gl_simulate_fwd writes the image, gl_simulate_bwd reads its cotangent (the pair that moves B1)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_simpair -- python3 $R/tools/prof_kernel.py --workload C2 --mode simpair --iters 40 > $OUT/kernel_stats_simpair.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_simpair_fetch -- python3 $R/tools/prof_kernel.py --workload C2 --mode simpair --iters 8 > $OUT/pmc_simpair_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_simpair_write -- python3 $R/tools/prof_kernel.py --workload C2 --mode simpair --iters 8 > $OUT/pmc_simpair_write.log 2>&1
+# the cluster kernel (C4): issue and wait counters
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_C4 -- python3 $R/tools/prof_kernel.py --workload C4 --iters 6 > $OUT/pmc_C4.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_C6 -- python3 $R/tools/prof_kernel.py --workload C6 --iters 6 > $OUT/pmc_C6.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_C3L -- python3 $R/tools/prof_kernel.py --workload C3L --mode lstsq --iters 4 > $OUT/pmc_C3L.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_fetch.log 2>&1
@@ -24,4 +30,7 @@ python3 $R/tools/map_step_time.py > $OUT/map_step_time.log 2>&1
 python3 $R/tools/svi_hmc_step_time.py > $OUT/svi_hmc_step_time.log 2>&1
 python3 $R/tools/bench_configs.py > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 $R/bench.py --no-cpu-baseline --mode svi > $OUT/bench_svi.json 2> $OUT/bench_svi.err
+python3 $R/bench.py --no-cpu-baseline --workload C5 --steps 200 --warmup 20 > $OUT/bench_C5.json 2> $OUT/bench_C5.err
+python3 $R/bench.py --no-cpu-baseline --workload C5 --mode svi --steps 200 --warmup 20 > $OUT/bench_C5_svi.json 2> $OUT/bench_C5_svi.err
 tail -1 $OUT/bench.json

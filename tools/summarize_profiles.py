@@ -32,7 +32,7 @@ def stats_table(d, out, top=12):
     return rows
 
 
-def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_kernel<3")):
+def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_kernel<3", "gl_cluster_kernel<3")):
     f = sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     if not f:
         return {}
@@ -49,11 +49,36 @@ def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_ker
 
 summary = {}
 rows = stats_table("bench_stats", f"{tag}_bench_kernel_stats.md")
-for w in ("C2", "C3", "C4", "C6", "C3L"):
+for w in ("C2", "C3", "C4", "C5", "C6", "C3L", "simpair"):
     stats_table(f"kernel_stats_{w}", f"{tag}_{w}_kernel_stats.md", top=6)
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mix", "pmc_clk"):
     summary[d] = pmc(d)
 summary["pmc_C6"] = pmc("pmc_C6", kernel_filter=("gl_main_kernel<3",))
+summary["pmc_C4"] = pmc("pmc_C4", kernel_filter=("gl_cluster_kernel<3", "gl_main_kernel<3"))
+c4 = summary["pmc_C4"]
+if c4.get("SQ_ACTIVE_INST_VALU") and c4.get("GRBM_GUI_ACTIVE"):
+    c4["valu_busy_frac"] = c4["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * c4["GRBM_GUI_ACTIVE"] / 8.0)
+    c4["valu_insts_per_pixel"] = c4["SQ_INSTS_VALU"] * 64 / (512 * 65536)
+# the simulate() pair at C2: the image-materialising kernels, where the HBM roofline is the bound
+sp = {}
+for mode, filt in (("fwd", ("gl_pair_kernel<0",)), ("bwd", ("gl_pair_kernel<1",))):
+    f, w = pmc("pmc_simpair_fetch", kernel_filter=filt), pmc("pmc_simpair_write", kernel_filter=filt)
+    if f.get("FETCH_SIZE") is not None and w.get("WRITE_SIZE") is not None:
+        hbm = (2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024  # same units / gfx950 correction as below
+        us = 0.5 * (f["_kernel_us"] + w["_kernel_us"])
+        sp[mode] = {"kernel_us_under_pmc": us, "hbm_bytes_per_launch": hbm, "hbm_GBps": hbm / (us * 1e-6) / 1e9}
+rows_sp = stats_table("kernel_stats_simpair", f"{tag}_simpair_kernel_stats.md", top=6)
+if rows_sp:
+    for r in rows_sp:
+        for mode, key in (("fwd", "gl_pair_kernel<0"), ("bwd", "gl_pair_kernel<1")):
+            if key in r["Name"] and mode in sp:
+                sp[mode]["kernel_us"] = float(r["AverageNs"]) / 1e3
+    if "fwd" in sp and "bwd" in sp and "kernel_us" in sp["fwd"] and "kernel_us" in sp["bwd"]:
+        b1 = (8 * 16384 + 8 * 13) * 1024  # B1 = 8N + 8P per sample, C2, 1024 samples
+        t = (sp["fwd"]["kernel_us"] + sp["bwd"]["kernel_us"]) * 1e-6
+        sp["pair"] = {"algorithmic_bytes_B1": b1, "achieved_GBps": b1 / t / 1e9, "frac_of_8TBps": b1 / t / 8e12,
+                      "hbm_bytes_measured": sp["fwd"]["hbm_bytes_per_launch"] + sp["bwd"]["hbm_bytes_per_launch"]}
+summary["simulate_pair_C2"] = sp
 c3l = summary["pmc_C3L"] = pmc("pmc_C3L", kernel_filter=("gl_normal_mfma_kernel",))
 if c3l.get("SQ_VALU_MFMA_BUSY_CYCLES") and c3l.get("GRBM_GUI_ACTIVE"):
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles over all SIMDs (MI355X_MICROARCH.md, PMC units); 1024 SIMDs
@@ -75,13 +100,22 @@ if sq.get("SQ_INSTS_VALU") and clk.get("GRBM_GUI_ACTIVE"):
     summary["valu_busy_frac"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * cycles)   # quad-cycles -> cycles, 1024 SIMDs
     summary["cycles_per_valu_inst"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / sq["SQ_INSTS_VALU"]
     summary["eff_clock_ghz"] = cycles / (clk["_kernel_us"] * 1e3)
-bj = os.path.join(src, "bench.json")
-if os.path.exists(bj):
-    line = [l for l in open(bj) if l.startswith("{")]
-    if line:
-        summary["bench"] = json.loads(line[-1])
+for key, name in (("bench", "bench.json"), ("bench_svi", "bench_svi.json"), ("bench_C5", "bench_C5.json"),
+                  ("bench_C5_svi", "bench_C5_svi.json")):
+    bj = os.path.join(src, name)
+    if os.path.exists(bj):
+        line = [l for l in open(bj) if l.startswith("{")]
+        if line:
+            summary[key] = json.loads(line[-1])
+# the ISA execution model of bench.py against the hardware count of the same kernel
+mix, b = summary.get("pmc_sq", {}), summary.get("bench", {})
+isa = (b.get("roofline") or {}).get("isa") or {}
+if mix.get("SQ_INSTS_VALU") and isa.get("valu_insts_per_pixel"):
+    measured = mix["SQ_INSTS_VALU"] * 64 / (1024 * 16384)
+    summary["isa_model_check"] = {"valu_insts_per_pixel_model": isa["valu_insts_per_pixel"], "valu_insts_per_pixel_pmc": measured,
+                                  "ratio": isa["valu_insts_per_pixel"] / measured}
 cfg = os.path.join(src, "bench_configs.jsonl")
 if os.path.exists(cfg):
     summary["configs"] = [json.loads(l) for l in open(cfg) if l.startswith("{")]
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in summary.items() if k not in ("bench", "configs")}, indent=1))
+print(json.dumps({k: v for k, v in summary.items() if not k.startswith("bench") and k != "configs"}, indent=1))
