@@ -149,6 +149,11 @@ def _ptr(t):
 
 def component_of(profile):
     kind, iparam, flags = profile._component()
+    if not kind:
+        raise NativeLibraryError(
+            f"profile {getattr(profile, 'name', type(profile).__name__)!r} has no gl_kind: user-defined deriv / light bodies are "
+            "not supported -- the profile maths lives in the HIP library (adding a profile means adding a kind: "
+            "gigalens_amd/csrc/gl_profiles.h and the dispatch switches of gl_kernels.hip.h; see INTEGRATION.md)")
     return gl_component(kind, iparam, flags, 0)
 
 

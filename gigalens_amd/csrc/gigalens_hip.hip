@@ -767,12 +767,13 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   if (!m) return fail(GL_EINVAL, "model is null");
   const int D = (int)m->lin_cols.size();
   if (D == 0) return fail(GL_EINVAL, "the model has no linear (light amplitude) coefficients");
-  if (D + 1 > LS_MAXD) return fail(GL_EUNSUPPORTED, "%d linear coefficients exceed the %d the in-LDS solve serves", D, LS_MAXD - 1);
   if (!params || !workspace) return fail(GL_EINVAL, "params / workspace is null");
   if (B <= 0 || B > 65535) return fail(GL_EINVAL, "batch size %d outside [1, 65535]", B);
   if ((int)m->cats.size() != m->n_scaled) return fail(GL_EINVAL, "GL_SCALED component without a catalogue");
   if (m->n_series_set != m->n_series) return fail(GL_EINVAL, "GL_SERIES component without a coefficient field");
   const bool solve = coeffs_or_null || image_or_null;
+  if (solve && D + 1 > LS_MAXD)  // the basis stack alone (return_stacked) is served at any depth
+    return fail(GL_EUNSUPPORTED, "%d linear coefficients exceed the %d the in-LDS solve serves", D, LS_MAXD - 1);
   if (solve && (!obs || !err)) return fail(GL_EINVAL, "obs / err_map are required to solve for the coefficients");
   if (!solve && !stacked_or_null) return fail(GL_EINVAL, "nothing to compute");
   if (!(parts & (GL_PART_LENS_LIGHT | GL_PART_SOURCE_LIGHT)) || parts > 7u) return fail(GL_EINVAL, "bad parts");

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2d
-python -m pytest tests -m gpu -q > gpurun_out/r2d/pytest.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/r2d/pytest.log
+python -m pytest tests/test_gpu_limits.py tests/test_gpu_parity.py -m gpu -q -k "limits or cluster_kernel or refused or oversized" 2>&1 | grep -E "^E  |^>|passed|failed|^FAILED" | head -30
