@@ -151,9 +151,10 @@ def launch_ranks(args):
 
 
 def epl_series_stats(wl, x_struct):
-    """Mean trips of the two-term EPL series loop and the share of odd series lengths over the batch: the per-sample
-    term count K = ceil(log(1e-12) / log f + 2) - 1 (capped at niter) with f = (1-q)/(1+q) = min(|e|, 1), restated from
-    csrc/gl_profiles.h epl_prep (epl.py:22,37,47-54).  None for models without EPL."""
+    """Mean trips of the two-term EPL series loop and the share of samples with a left-over term: the per-sample term
+    count K = ceil(log(1e-12) / log f + 2) - 1 (capped at niter) with f = (1-q)/(1+q) = min(|e|, 1), restated from
+    csrc/gl_profiles.h epl_prep (epl.py:22,37,47-54).  The Clenshaw loop of csrc/gl_vec.hip.h sums terms K..0 two per trip:
+    ceil(K / 2) trips, and the n = 0 term is left over when K is even.  None for models without EPL."""
     import math
     pairs, odd, ks, n = 0.0, 0.0, 0.0, 0
     for prof, p in zip(wl.phys_model.lenses, x_struct.get("lens_mass", [])):
@@ -165,8 +166,8 @@ def epl_series_stats(wl, x_struct):
         niter = math.log(1e-12) / torch.log(f) + 2.0
         K = torch.where(niter > 1, torch.ceil(niter) - 1, torch.zeros_like(niter)).clamp(max=cap)
         K = torch.where(f >= 1.0, torch.full_like(K, float(cap)), K)
-        pairs += float(torch.floor(K / 2).mean())
-        odd += float((K % 2).mean())
+        pairs += float(torch.ceil(K / 2).mean())
+        odd += float(1.0 - (K % 2).mean())  # "frac_odd" of the execution model = share of samples with the left-over term
         ks += float(K.mean())
         n += 1
     if not n:
@@ -270,7 +271,7 @@ def main():
                     break
             K = torch.ceil(math.log(1e-12) / torch.log(e.clamp(1e-30, 1 - 1e-12)) + 2.0) - 1
             pick = int(torch.argmin((K - round(s0["mean_terms"])).abs()))
-            series = {"mean_terms": float(K[pick]), "mean_pair_trips": float(K[pick] // 2), "frac_odd": float(K[pick] % 2)}
+            series = {"mean_terms": float(K[pick]), "mean_pair_trips": float(torch.ceil(K[pick] / 2)), "frac_odd": float(1.0 - K[pick] % 2)}
         mu = z0[pick].to(dev).contiguous().clone()
         lpk = ginf.tril_pack(torch.eye(d, device=dev) * 1e-3)
         sv_params = torch.cat([mu, lpk]).contiguous()

@@ -486,6 +486,8 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   m->static_id = env_int("GIGALENS_HIP_STATIC", 1) ? match_static(m) : 0;
   m->static_variant = env_int("GIGALENS_HIP_STATIC_VARIANT", 0);
   m->pair = env_int("GIGALENS_HIP_PAIR", 1);
+  m->light_spherical = n_comp > n_lens;
+  for (int i = n_lens; i < n_comp; ++i) m->light_spherical = m->light_spherical && m->comps[i].kind == K_SERSIC;
   if (!m->tile_grad) m->tile_grad = m->static_id ? 1 : 2;  // measured: T=1 wins once the VJP state lives in registers
   if (!m->static_id) {  // the interpreter kernel is built for T = 2 and 4
     const bool env_tile = env_int("GIGALENS_HIP_TILE", 0) != 0;

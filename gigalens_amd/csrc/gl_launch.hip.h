@@ -17,7 +17,8 @@ using L_EplShear = KindList<K_EPL, K_SHEAR>;
 using L_Sie = KindList<K_SIE>;
 using L_SieShear = KindList<K_SIE, K_SHEAR>;
 using C_None = KindList<>;
-using C_Sersic = KindList<K_SERSIC>;
+using C_Sersic = KindList<K_SERSIC>;           // pair kernels: spherical fast path (every light profile of the model spherical)
+using C_SersicE = KindList<K_SERSIC_ELLIPSE>;  // pair kernels: the general elliptical code, serves spherical members too
 using C_Shapelets = KindList<K_SHAPELETS>;
 
 enum StaticId { ST_NONE = 0, ST_EPLSHEAR_SERSIC, ST_EPLSHEAR_SERSIC_SERSIC, ST_SIE_SERSIC, ST_EPLSHEAR_SHAPELETS,
@@ -36,14 +37,22 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     // pair live between the forward and VJP halves (no spills at 3 resp. 2 waves per SIMD), forward modes fit 4+
     constexpr bool G = (MODE == IMG_BWD || MODE == LL_GRAD);
     constexpr int W1 = G ? 3 : 4, W2 = G ? 2 : 4;
-    switch (m->static_id) {
-      case ST_EPLSHEAR_SERSIC:
-        if (m->pair == 4) GL_PAIR(4, L_EplShear, C_None, C_Sersic); else GL_PAIR(W1, L_EplShear, C_None, C_Sersic);
-        return true;
-      case ST_EPLSHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_EplShear, C_Sersic, C_Sersic); return true;
-      case ST_SIE_SERSIC: GL_PAIR(W1, L_Sie, C_None, C_Sersic); return true;  // gradient mode: 4 VGPRs spill under the 128-register budget of 4 waves
-      case ST_SIESHEAR_SERSIC_SERSIC: GL_PAIR(W1, L_SieShear, C_Sersic, C_Sersic); return true;
-      default: break;
+    if (m->light_spherical) {
+      switch (m->static_id) {
+        case ST_EPLSHEAR_SERSIC: GL_PAIR(W1, L_EplShear, C_None, C_Sersic); return true;
+        case ST_EPLSHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_EplShear, C_Sersic, C_Sersic); return true;
+        case ST_SIE_SERSIC: GL_PAIR(W1, L_Sie, C_None, C_Sersic); return true;  // gradient mode: 4 VGPRs would spill at 4 waves
+        case ST_SIESHEAR_SERSIC_SERSIC: GL_PAIR(W1, L_SieShear, C_Sersic, C_Sersic); return true;
+        default: break;
+      }
+    } else {
+      switch (m->static_id) {
+        case ST_EPLSHEAR_SERSIC: GL_PAIR(W1, L_EplShear, C_None, C_SersicE); return true;
+        case ST_EPLSHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_EplShear, C_SersicE, C_SersicE); return true;
+        case ST_SIE_SERSIC: GL_PAIR(W1, L_Sie, C_None, C_SersicE); return true;
+        case ST_SIESHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_SieShear, C_SersicE, C_SersicE); return true;  // 168 VGPRs at 3 waves would spill 60
+        default: break;
+      }
     }
   }
 #undef GL_PAIR

@@ -8,7 +8,8 @@
 // The per-profile maths is the same as gl_profiles.h (same derived-constant layout, same accumulator
 // layout, same finalize), written once over a value type V in {float, v2f}: comparisons yield lane masks and
 // `m ? a : b` selects per lane.  Transcendentals (v_rcp/sqrt/log/exp) have no packed form and are applied
-// per lane.  Supported components: EPL, SIE, SHEAR, SIS lenses; SERSIC / SERSIC_ELLIPSE lights.
+// per lane.  Supported components: EPL, SIE, SHEAR, SIS lenses; SERSIC / SERSIC_ELLIPSE lights (K_SERSIC in a kind list
+// selects the spherical fast path: only for models whose light profiles are ALL spherical, else K_SERSIC_ELLIPSE serves both).
 #pragma once
 #include "gl_static.hip.h"
 #include "gl_vec.hip.h"
@@ -94,7 +95,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr bool src = i >= NLL;
-      m += sersic_fwd_v<V>(dC[i], src ? bx : x, src ? by : y, sst[i]);
+      constexpr bool ell = (src ? SK::kinds[src ? i - NLL : 0] : LLK::kinds[src ? 0 : i]) != K_SERSIC;  // K_SERSIC in the list = all spherical
+      m += sersic_fwd_v<V, ell>(dC[i], src ? bx : x, src ? by : y, sst[i]);
     }, std::make_integer_sequence<int, NLIGHT>{});
     auto nanp = m != m;
     m = (nanp ? V(0.f) : m) * a.out_scale;  // NaN -> 0 (tf/simulator.py:140), then x det(T) (:156)
@@ -154,7 +156,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
           for (int j = 0; j < i; ++j) n += static_nacc(j < NLL ? LLK::kinds[j < NLL ? j : 0] : SK::kinds[j >= NLL ? j - NLL : 0]);
           return n;
         }();
-        sersic_vjp_v<V, src>(dC[i], sst[i], gm, accC + off, gbx, gby);
+        constexpr bool ell = (src ? SK::kinds[src ? i - NLL : 0] : LLK::kinds[src ? 0 : i]) != K_SERSIC;
+        sersic_vjp_v<V, src, ell>(dC[i], sst[i], gm, accC + off, gbx, gby);
       }, std::make_integer_sequence<int, NLIGHT>{});
       gbx = -gbx;
       gby = -gby;
@@ -203,7 +206,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
 #pragma unroll
       for (int k = 0; k < G; ++k) tmp[k] = hsum(accL[off + k]);
       if constexpr (kind == K_EPL) {
-        tmp[EPLA_B] *= dL[i][EPL_INVB];
+        // sum of gP P: the b-gradient is (t - 1) / b times it, the P0-gradient 1 / P0 times it (epl_vjp_v keeps one sum)
+        tmp[EPLA_B] = tmp[EPLA_P0] * (dL[i][EPL_TM1] * dL[i][EPL_INVB]);
         tmp[EPLA_P0] *= rcp(dL[i][EPL_P0]);
       }
 #pragma unroll

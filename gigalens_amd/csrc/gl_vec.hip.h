@@ -49,8 +49,17 @@ __device__ __forceinline__ float hsum(float a) { return a; }
 __device__ __forceinline__ float hsum(v2f a) { return a.x + a.y; }
 
 // ---- EPL ------------------------------------------------------------------------------------------------
+// The angular series  Omega = sum_n c_n e^{i(2n+1)theta}  (epl.py:39-54; c_n real, per sample) and its derivatives w.r.t.
+// f and t (same form with dc_n/df, dc_n/dt) are summed by CLENSHAW's backward recurrence: cos((2n+1)theta) and
+// sin((2n+1)theta) obey the same three-term recurrence phi_{n+1} = 2 cos(2 theta) phi_n - phi_{n-1}, so ONE real sequence
+//     b_k = c_k + 2 cos(2 theta) b_{k+1} - b_{k+2}        (k = K .. 0,  b_{K+1} = b_{K+2} = 0)
+// serves both components:  sum c_n cos((2n+1)theta) = (b_0 - b_1) cos(theta),  sum c_n sin((2n+1)theta) = (b_0 + b_1) sin(theta)
+// (phi_0 = cos / sin theta, phi_{-1} = cos(-theta) / sin(-theta)).  Two packed instructions per term and series for a pixel
+// pair, against two for advancing E_n plus two per series when the terms e^{i(2n+1)theta} are formed explicitly: 6 instead
+// of 8 per term in gradient mode (three series), 2 instead of 4 forward-only.  The small terms are added first.
 template <class V> struct EplStateV {
-  V xr, yr, inv, invc, L2, P, Ox, Oy, Fx, Fy, Tx, Ty;
+  V xr, yr, inv, invc, L2, P, Cs, Ss, Ox, Oy;
+  V f0, f1, t0, t1;  // Clenshaw tails (b_0, b_1) of the d/df and d/dt series
 };
 
 template <class V, bool GRAD>
@@ -67,44 +76,41 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   V r = rsq_(r2);
   auto pos = r2 > V(0.f);
   st.inv = pos ? r : V(0.f);
-  V Cs = pos ? X * r : V(1.f);
-  V Ss = st.yr * st.inv;
+  st.Cs = pos ? X * r : V(1.f);
+  st.Ss = st.yr * st.inv;
   V iRc = vmin(vmax(r, V(1e-10f)), V(1e10f));
   st.invc = (iRc == r) ? r : V(0.f);  // clip_by_value passes gradient only inside the clamp
-  // E_n = e^{i(2n+1)theta} by the three-term recurrence  E_{n+1} = 2 cos(2 theta) E_n - E_{n-1}  (one FMA per
-  // component and term, against four for the complex product of the reference's  rot(2 theta) * last, epl.py:43-44);
-  // E_{-1} = conj(E_0).  Two terms per trip so that the two registers simply swap roles.
-  V twoc = (Cs * Cs - Ss * Ss) * 2.f;
-  V Ex = Cs, Ey = Ss, Px = Cs, Py = -Ss;
-  st.Ox = Cs; st.Oy = Ss;
-  if (GRAD) {
-    st.Fx = V(0.f); st.Fy = V(0.f); st.Tx = V(0.f); st.Ty = V(0.f);
-  }
+  V twoc = (st.Cs * st.Cs - st.Ss * st.Ss) * 2.f;
   // scalar-loaded trip count and coefficients (wave-uniform address): SGPR operands, scalar loop control
   const int K = reinterpret_cast<const int*>(gd)[EPL_KI];
-  const float4* __restrict__ gtab = reinterpret_cast<const float4*>(gd + EPL_TAB);
-  auto add = [&](const float4 cc, const V& ex, const V& ey) {
-    st.Ox += cc.x * ex; st.Oy += cc.x * ey;
+  const float4* __restrict__ gtab = reinterpret_cast<const float4*>(gd + EPL_TAB);  // rows (c_n, (2n+1) c_n, dc_n/df, dc_n/dt)
+  V o1 = V(0.f), o2 = V(0.f), f1 = V(0.f), f2 = V(0.f), t1 = V(0.f), t2 = V(0.f);  // b_{k+1}, b_{k+2}
+  int n = K;
+  for (; n >= 1; n -= 2) {  // terms n and n - 1; the two registers of a series swap roles, no moves
+    const float4 ca = gtab[n], cb = gtab[n - 1];
+    o2 = __builtin_elementwise_fma(twoc, o1, V(ca.x)) - o2;
+    o1 = __builtin_elementwise_fma(twoc, o2, V(cb.x)) - o1;
     if (GRAD) {
-      st.Fx += cc.z * ex; st.Fy += cc.z * ey;
-      st.Tx += cc.w * ex; st.Ty += cc.w * ey;
+      f2 = __builtin_elementwise_fma(twoc, f1, V(ca.z)) - f2;
+      f1 = __builtin_elementwise_fma(twoc, f2, V(cb.z)) - f1;
+      t2 = __builtin_elementwise_fma(twoc, t1, V(ca.w)) - t2;
+      t1 = __builtin_elementwise_fma(twoc, t2, V(cb.w)) - t1;
     }
-  };
-  int n = 1;
-  for (; n + 1 <= K; n += 2) {
-    const float4 ca = gtab[n], cb = gtab[n + 1];
-    Px = twoc * Ex - Px;  // E_n      (P held E_{n-2})
-    Py = twoc * Ey - Py;
-    add(ca, Px, Py);
-    Ex = twoc * Px - Ex;  // E_{n+1}
-    Ey = twoc * Py - Ey;
-    add(cb, Ex, Ey);
   }
-  if (n <= K) {
-    Px = twoc * Ex - Px;
-    Py = twoc * Ey - Py;
-    add(gtab[n], Px, Py);
+  V o0, ob;  // b_0, b_1 of Omega
+  if (n == 0) {  // K even: the n = 0 term (c_0 = 1, dc_0 = 0) is still to come
+    o0 = __builtin_elementwise_fma(twoc, o1, V(1.f)) - o2;
+    ob = o1;
+    if (GRAD) {
+      st.f0 = twoc * f1 - f2; st.f1 = f1;
+      st.t0 = twoc * t1 - t2; st.t1 = t1;
+    }
+  } else {
+    o0 = o1; ob = o2;
+    if (GRAD) { st.f0 = f1; st.f1 = f2; st.t0 = t1; st.t1 = t2; }
   }
+  st.Ox = (o0 - ob) * st.Cs;
+  st.Oy = (o0 + ob) * st.Ss;
   st.L2 = log2_(iRc * d[EPL_B]);
   st.P = exp2_(st.L2 * d[EPL_TM1]) * d[EPL_P0];  // 2b/(1+q) (b/R)^(t-1), epl.py:55
   V arx = st.P * st.Ox, ary = st.P * st.Oy;
@@ -122,28 +128,29 @@ __device__ __forceinline__ void epl_vjp_v(const float* d, V gx, V gy, const EplS
   V g_phi = gy * ax - gx * ay;
   V gP = grx * st.Ox + gry * st.Oy;
   V gOx = P * grx, gOy = P * gry;
+  // dot and cross products of (gOx, gOy) with a series (Sx, Sy) = ((b0 - b1) Cs, (b0 + b1) Ss) straight from its tails:
+  //   gOx Sx + gOy Sy = b0 (A + B) + b1 (B - A),  gOy Sx - gOx Sy = b0 (C - D) - b1 (C + D)
+  V A = gOx * st.Cs, B = gOy * st.Ss, C = gOy * st.Cs, D = gOx * st.Ss;
+  V dotp = A + B, dotm = B - A, crsm = C - D, crsp = C + D;
   // d Omega/d theta = i S with S = sum (2n+1) c_n E_n = Omega + 2 f dOmega/df  (c_n ~ f^n): no separate S sum
-  V g_ang = (gOy * st.Ox - gOx * st.Oy) + (gOy * st.Fx - gOx * st.Fy) * d[EPL_F2];
-  V g_t = gOx * st.Tx + gOy * st.Ty;
-  V g_f = gOx * st.Fx + gOy * st.Fy;
+  V g_ang = (gOy * st.Ox - gOx * st.Oy) + (st.f0 * crsm - st.f1 * crsp) * d[EPL_F2];
+  V g_t = st.t0 * dotp + st.t1 * dotm;
+  V g_f = st.f0 * dotp + st.f1 * dotm;
   V gW_W = gP * P;
   g_t += gW_W * (st.L2 * (float)kLn2);
-  V gWt = gW_W * tm1;
-  V gR0 = -(gWt * st.invc);
-  V Cs = st.xr * q * st.inv, Ss = st.yr * st.inv;  // (R0 == 0: inv = 0, and g_ang * inv = 0 as in the scalar code)
+  V gR0 = -(gW_W * st.invc) * tm1;
   V gai = g_ang * st.inv;
-  V gX = gR0 * Cs - gai * Ss;
-  V gyr = gR0 * Ss + gai * Cs;
+  V gX = gR0 * st.Cs - gai * st.Ss;
+  V gyr = gR0 * st.Ss + gai * st.Cs;
   V gxr = gX * q;
   g_phi += gxr * st.yr - gyr * st.xr;
   acc[EPLA_CX] -= gxr * c - gyr * s;
   acc[EPLA_CY] -= gxr * s + gyr * c;
   acc[EPLA_PHI] += g_phi;
   acc[EPLA_Q] += gX * st.xr;
-  acc[EPLA_B] += gWt;     // x 1/b in the epilogue
   acc[EPLA_T] += g_t;
   acc[EPLA_F] += g_f;
-  acc[EPLA_P0] += gW_W;   // x 1/P0 in the epilogue (gP * W = gP * P / P0)
+  acc[EPLA_P0] += gW_W;   // x 1/P0 in the epilogue (gP * W = gP * P / P0); EPLA_B = (t - 1) / b times the same sum
 }
 
 // ---- SIE / SHEAR / SIS (stateless: cheap to re-evaluate) ----------------------------------------------
@@ -210,35 +217,50 @@ template <class V> __device__ __forceinline__ void sis_vjp_v(const float* d, V x
 // ---- SERSIC ---------------------------------------------------------------------------------------------
 template <class V> struct SerStateV { V a1, a2, r2, L2, u, E; };
 
-template <class V> __device__ __forceinline__ V sersic_fwd_v(const float* d, V x, V y, SerStateV<V>& st) {
-  const float c = d[SER_C], s = d[SER_S];
+// ELL = false: the spherical profile (sersic.py:23-66 passes e1 = e2 = 0): no rotation, no axis-ratio stretch and no
+// ellipticity gradients -- 21 packed instructions per pixel pair less over forward + VJP
+template <class V, bool ELL = true> __device__ __forceinline__ V sersic_fwd_v(const float* d, V x, V y, SerStateV<V>& st) {
   V dx = x - d[SER_CX], dy = y - d[SER_CY];
-  st.a1 = dx * c + dy * s;
-  st.a2 = dy * c - dx * s;
-  V xt1 = st.a1 * d[SER_SQ], xt2 = st.a2 * d[SER_ISQ];
-  st.r2 = xt1 * xt1 + xt2 * xt2;
+  if constexpr (ELL) {
+    const float c = d[SER_C], s = d[SER_S];
+    st.a1 = dx * c + dy * s;
+    st.a2 = dy * c - dx * s;
+    V xt1 = st.a1 * d[SER_SQ], xt2 = st.a2 * d[SER_ISQ];
+    st.r2 = xt1 * xt1 + xt2 * xt2;
+  } else {
+    st.a1 = dx;
+    st.a2 = dy;
+    st.r2 = dx * dx + dy * dy;
+  }
   st.L2 = log2_(st.r2) * 0.5f + d[SER_L2IRS];  // log2(R / R_sersic) without the square root
   st.u = exp2_(st.L2 * d[SER_INVN]);
   st.E = vexp<V>((st.u - 1.f) * -d[SER_BN]);
   return st.E * d[SER_IE];
 }
-template <class V, bool SRC>
+template <class V, bool SRC, bool ELL = true>
 __device__ __forceinline__ void sersic_vjp_v(const float* d, const SerStateV<V>& st, V gI, V* acc, V& gpx, V& gpy) {
-  const float c = d[SER_C], s = d[SER_S], sq = d[SER_SQ], isq = d[SER_ISQ];
-  V xt1 = st.a1 * sq, xt2 = st.a2 * isq;
   auto pos = st.r2 > V(0.f);
   V gE = gI * st.E;
   V tI = gE * d[SER_IE];
   V guu = -(tI * st.u) * d[SER_BN];
   V gL = guu * d[SER_INVN];
   V k = pos ? gL * rcp(st.r2) : V(0.f);
-  V gxt1 = k * xt1, gxt2 = k * xt2;
-  V ga1 = gxt1 * sq, ga2 = gxt2 * isq;
-  V gdx = ga1 * c - ga2 * s, gdy = ga1 * s + ga2 * c;
+  V gdx, gdy;
+  if constexpr (ELL) {
+    const float c = d[SER_C], s = d[SER_S], sq = d[SER_SQ], isq = d[SER_ISQ];
+    V xt1 = st.a1 * sq, xt2 = st.a2 * isq;
+    V gxt1 = k * xt1, gxt2 = k * xt2;
+    V ga1 = gxt1 * sq, ga2 = gxt2 * isq;
+    gdx = ga1 * c - ga2 * s;
+    gdy = ga1 * s + ga2 * c;
+    acc[SERA_PHI] += ga1 * st.a2 - ga2 * st.a1;
+    acc[SERA_SQ] += gxt1 * st.a1 - gxt2 * st.a2 * (isq * isq);
+  } else {
+    gdx = k * st.a1;
+    gdy = k * st.a2;
+  }
   acc[SERA_CX] -= gdx;
   acc[SERA_CY] -= gdy;
-  acc[SERA_PHI] += ga1 * st.a2 - ga2 * st.a1;
-  acc[SERA_SQ] += gxt1 * st.a1 - gxt2 * st.a2 * (isq * isq);
   acc[SERA_L] += gL;
   acc[SERA_INVN] += pos ? guu * st.L2 : V(0.f);  // x ln2 in the epilogue
   acc[SERA_BN] -= tI * (st.u - 1.f);

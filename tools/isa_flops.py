@@ -250,7 +250,9 @@ def pair_model(cfg, mean_series_pairs, frac_odd, W=2, frac_short=0.0):
     lane.  Its blocks are weighted as follows:
       * blocks that dominate the loop's latch run once per trip,
       * the inner loop (two series terms per trip) runs `mean_series_pairs` times on average,
-      * a conditional block holding >= 4 packed FMAs is the odd remainder term of the series: probability `frac_odd`,
+      * a conditional block behind the inner loop holding >= 4 packed FMAs is the term the two-term loop leaves over:
+        probability `frac_odd` (the caller passes the share of samples whose series length has that parity); its sibling
+        branch (register moves only) runs with the complementary probability,
       * the inner loop's preheader runs with probability 1 - `frac_short` (series of fewer than two terms skip the loop),
         the blocks of that bypass with probability `frac_short`,
       * other conditional blocks (optional loads of the mask / error planes: <= 3 VALU, no flops) are counted as executed.
@@ -277,8 +279,11 @@ def pair_model(cfg, mean_series_pairs, frac_odd, W=2, frac_short=0.0):
         detail["inner"].append(dict(header=hex(c.header), per_trip=t, trips=mean_series_pairs))
     for b in sorted(own - mandatory):
         t = cfg.tally([b])
-        if t["packed"] >= 4:
-            prob, why = frac_odd, "odd series term"
+        after_loop = any(h in cfg.dom[b] for h in inner_headers)  # only reachable through the series loop
+        if after_loop and t["packed"] >= 4:
+            prob, why = frac_odd, "series tail: the term left over by the two-term loop"
+        elif after_loop and t["valu"] > 3:
+            prob, why = 1.0 - frac_odd, "series tail: the other parity (register moves)"
         elif any(h in cfg.succ[b] for h in inner_headers):
             prob, why = 1.0 - frac_short, "series-loop preheader"
         elif t["flops"] == 0 and t["valu"] <= 3:
