@@ -151,12 +151,13 @@ def launch_ranks(args):
 
 
 def epl_series_stats(wl, x_struct):
-    """Mean trips of the two-term EPL series loop and the share of samples with a left-over term: the per-sample term
-    count K = ceil(log(1e-12) / log f + 2) - 1 (capped at niter) with f = (1-q)/(1+q) = min(|e|, 1), restated from
-    csrc/gl_profiles.h epl_prep (epl.py:22,37,47-54).  The Clenshaw loop of csrc/gl_vec.hip.h sums terms K..0 two per trip:
-    ceil(K / 2) trips, and the n = 0 term is left over when K is even.  None for models without EPL."""
+    """Trips of the EPL series loop over the batch: the per-sample term count K = ceil(log(1e-12) / log f + 2) - 1 (capped
+    at niter) with f = (1-q)/(1+q) = min(|e|, 1), restated from csrc/gl_profiles.h epl_prep (epl.py:22,37,47-54).  The
+    Clenshaw loop of csrc/gl_vec.hip.h takes the terms K..0 four at a time (the table is zero-filled above K), two
+    four-term groups per loop iteration with an exit after either: T = ceil((K + 1) / 4) groups, T / 2 iterations of the
+    ISA-level loop.  None for models without EPL."""
     import math
-    pairs, odd, ks, n = 0.0, 0.0, 0.0, 0
+    groups, ks, n = 0.0, 0.0, 0
     for prof, p in zip(wl.phys_model.lenses, x_struct.get("lens_mass", [])):
         if getattr(prof, "_kind", 0) != 1:
             continue
@@ -166,13 +167,12 @@ def epl_series_stats(wl, x_struct):
         niter = math.log(1e-12) / torch.log(f) + 2.0
         K = torch.where(niter > 1, torch.ceil(niter) - 1, torch.zeros_like(niter)).clamp(max=cap)
         K = torch.where(f >= 1.0, torch.full_like(K, float(cap)), K)
-        pairs += float(torch.ceil(K / 2).mean())
-        odd += float(1.0 - (K % 2).mean())  # "frac_odd" of the execution model = share of samples with the left-over term
+        groups += float(torch.ceil((K + 1) / 4).mean())
         ks += float(K.mean())
         n += 1
     if not n:
         return None
-    return {"mean_terms": ks / n, "mean_pair_trips": pairs / n, "frac_odd": odd / n}
+    return {"mean_terms": ks / n, "mean_four_term_groups": groups / n, "mean_pair_trips": 0.5 * groups / n, "frac_odd": 0.0}
 
 
 def isa_account(kernel_symbol, series):
@@ -271,7 +271,8 @@ def main():
                     break
             K = torch.ceil(math.log(1e-12) / torch.log(e.clamp(1e-30, 1 - 1e-12)) + 2.0) - 1
             pick = int(torch.argmin((K - round(s0["mean_terms"])).abs()))
-            series = {"mean_terms": float(K[pick]), "mean_pair_trips": float(torch.ceil(K[pick] / 2)), "frac_odd": float(1.0 - K[pick] % 2)}
+            g = float(torch.ceil((K[pick] + 1) / 4))
+            series = {"mean_terms": float(K[pick]), "mean_four_term_groups": g, "mean_pair_trips": 0.5 * g, "frac_odd": 0.0}
         mu = z0[pick].to(dev).contiguous().clone()
         lpk = ginf.tril_pack(torch.eye(d, device=dev) * 1e-3)
         sv_params = torch.cat([mu, lpk]).contiguous()

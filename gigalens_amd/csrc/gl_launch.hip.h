@@ -39,7 +39,9 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     constexpr int W1 = G ? 3 : 4, W2 = G ? 2 : 4;
     if (m->light_spherical) {
       switch (m->static_id) {
-        case ST_EPLSHEAR_SERSIC: GL_PAIR(W1, L_EplShear, C_None, C_Sersic); return true;
+        case ST_EPLSHEAR_SERSIC:
+          if (m->pair == 4) GL_PAIR(4, L_EplShear, C_None, C_Sersic); else GL_PAIR(W1, L_EplShear, C_None, C_Sersic);  // GIGALENS_HIP_PAIR=4: the 4-waves-per-SIMD budget (experiment)
+          return true;
         case ST_EPLSHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_EplShear, C_Sersic, C_Sersic); return true;
         case ST_SIE_SERSIC: GL_PAIR(W1, L_Sie, C_None, C_Sersic); return true;  // gradient mode: 4 VGPRs would spill at 4 waves
         case ST_SIESHEAR_SERSIC_SERSIC: GL_PAIR(W1, L_SieShear, C_Sersic, C_Sersic); return true;

@@ -209,6 +209,10 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
         // sum of gP P: the b-gradient is (t - 1) / b times it, the P0-gradient 1 / P0 times it (epl_vjp_v keeps one sum)
         tmp[EPLA_B] = tmp[EPLA_P0] * (dL[i][EPL_TM1] * dL[i][EPL_INVB]);
         tmp[EPLA_P0] *= rcp(dL[i][EPL_P0]);
+        // the centre gradients were summed in the lens frame: -(R g) with R the rotation by phi
+        const float gxr = tmp[EPLA_CX], gyr = tmp[EPLA_CY], cc = dL[i][EPL_C], ss = dL[i][EPL_S];
+        tmp[EPLA_CX] = -(gxr * cc - gyr * ss);
+        tmp[EPLA_CY] = -(gxr * ss + gyr * cc);
       }
 #pragma unroll
       for (int k = 0; k < G; ++k) put(tmp[k], comps[i].a_off + k);

@@ -85,7 +85,7 @@ GL_HD int kind_num_params(int kind, int iparam) {
 }
 GL_HD int kind_num_derived(int kind, int iparam) {
   switch (kind) {
-    case K_EPL: return EPL_TAB + 4 * (iparam + 2);  // rows 0..cap plus one spare row for the loop's prefetch
+    case K_EPL: return EPL_TAB + 4 * (iparam + 4);  // rows 0..cap plus three zero rows: the Clenshaw loop takes four rows per trip
     case K_SIE: return SIE_ND + 1;
     case K_NFW: return NFW_ND;
     case K_SHEAR: return SHR_ND + 2;
@@ -255,7 +255,7 @@ template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
     tab[4 * n + 2] = cf;
     tab[4 * n + 3] = ct;
   }
-  for (int j = 0; j < 4; ++j) tab[4 * (K + 1) + j] = (R)0;  // the prefetched-but-unused row
+  for (int j = 0; j < 12; ++j) tab[4 * (K + 1) + j] = (R)0;  // zero rows K+1..K+3: the four-row trips of the Clenshaw loop may start above K
   d[EPL_K] = (R)K;
   if (sizeof(R) == 4) {  // the same count as raw int bits, so a kernel can fetch it with a scalar load
     int* ki = reinterpret_cast<int*>(&d[EPL_KI]);

@@ -85,30 +85,41 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   const int K = reinterpret_cast<const int*>(gd)[EPL_KI];
   const float4* __restrict__ gtab = reinterpret_cast<const float4*>(gd + EPL_TAB);  // rows (c_n, (2n+1) c_n, dc_n/df, dc_n/dt)
   V o1 = V(0.f), o2 = V(0.f), f1 = V(0.f), f2 = V(0.f), t1 = V(0.f), t2 = V(0.f);  // b_{k+1}, b_{k+2}
-  int n = K;
-  for (; n >= 1; n -= 2) {  // terms n and n - 1; the two registers of a series swap roles, no moves
-    const float4 ca = gtab[n], cb = gtab[n - 1];
-    o2 = __builtin_elementwise_fma(twoc, o1, V(ca.x)) - o2;
-    o1 = __builtin_elementwise_fma(twoc, o2, V(cb.x)) - o1;
+  auto term = [&](const float4 ck, V& b1, V& b2, V& g1, V& g2, V& h1, V& h2) {  // b_k written over b_{k+2}
+    b2 = __builtin_elementwise_fma(twoc, b1, V(ck.x)) - b2;
     if (GRAD) {
-      f2 = __builtin_elementwise_fma(twoc, f1, V(ca.z)) - f2;
-      f1 = __builtin_elementwise_fma(twoc, f2, V(cb.z)) - f1;
-      t2 = __builtin_elementwise_fma(twoc, t1, V(ca.w)) - t2;
-      t1 = __builtin_elementwise_fma(twoc, t2, V(cb.w)) - t1;
+      g2 = __builtin_elementwise_fma(twoc, g1, V(ck.z)) - g2;
+      h2 = __builtin_elementwise_fma(twoc, h1, V(ck.w)) - h2;
     }
+  };
+  auto four = [&](const float4 r0, const float4 r1, const float4 r2, const float4 r3) {  // rows k..k+3, highest first
+    term(r3, o1, o2, f1, f2, t1, t2);
+    term(r2, o2, o1, f2, f1, t2, t1);
+    term(r1, o1, o2, f1, f2, t1, t2);
+    term(r0, o2, o1, f2, f1, t2, t1);  // leaves b_k in (o1, f1, t1) and b_{k+1} in (o2, f2, t2)
+  };
+  // Four terms per trip, from the top of the table down to row 0; epl_prep zero-fills rows K+1..K+3, and zero coefficients
+  // above K leave the recurrence at zero, so there is no remainder logic.  Two register sets in turn: the 16 dwords of
+  // the NEXT trip are requested before this trip's 24 packed instructions (scalar loads return out of order, so a wait
+  // means "all of them": one request in flight at a time).
+  int trips = (K + 4) >> 2;  // ceil((K + 1) / 4)
+  int row = 4 * trips - 4;   // first row of the current trip
+  const float4* __restrict__ p = gtab + row;
+  float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+  while (true) {
+    row = row >= 4 ? row - 4 : 0;  // the request made by the LAST trip is clamped to rows 0..3: inside the table, never used
+    p = gtab + row;
+    const float4 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+    four(a0, a1, a2, a3);
+    if (--trips == 0) break;
+    row = row >= 4 ? row - 4 : 0;
+    p = gtab + row;
+    a0 = p[0]; a1 = p[1]; a2 = p[2]; a3 = p[3];
+    four(b0, b1, b2, b3);
+    if (--trips == 0) break;
   }
-  V o0, ob;  // b_0, b_1 of Omega
-  if (n == 0) {  // K even: the n = 0 term (c_0 = 1, dc_0 = 0) is still to come
-    o0 = __builtin_elementwise_fma(twoc, o1, V(1.f)) - o2;
-    ob = o1;
-    if (GRAD) {
-      st.f0 = twoc * f1 - f2; st.f1 = f1;
-      st.t0 = twoc * t1 - t2; st.t1 = t1;
-    }
-  } else {
-    o0 = o1; ob = o2;
-    if (GRAD) { st.f0 = f1; st.f1 = f2; st.t0 = t1; st.t1 = t2; }
-  }
+  const V o0 = o1, ob = o2;  // b_0, b_1 of Omega
+  if (GRAD) { st.f0 = f1; st.f1 = f2; st.t0 = t1; st.t1 = t2; }
   st.Ox = (o0 - ob) * st.Cs;
   st.Oy = (o0 + ob) * st.Ss;
   st.L2 = log2_(iRc * d[EPL_B]);
@@ -123,9 +134,8 @@ __device__ __forceinline__ void epl_vjp_v(const float* d, V gx, V gy, const EplS
   const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q], tm1 = d[EPL_TM1];
   V P = st.P;
   V arx = P * st.Ox, ary = P * st.Oy;
-  V ax = arx * c - ary * s, ay = arx * s + ary * c;
-  V grx = gx * c + gy * s, gry = gy * c - gx * s;
-  V g_phi = gy * ax - gx * ay;
+  V grx = gx * c + gy * s, gry = gy * c - gx * s;  // the cotangent in the lens frame
+  V g_phi = gry * arx - grx * ary;                 // g x alpha is rotation invariant: no need for alpha in the sky frame
   V gP = grx * st.Ox + gry * st.Oy;
   V gOx = P * grx, gOy = P * gry;
   // dot and cross products of (gOx, gOy) with a series (Sx, Sy) = ((b0 - b1) Cs, (b0 + b1) Ss) straight from its tails:
@@ -144,8 +154,8 @@ __device__ __forceinline__ void epl_vjp_v(const float* d, V gx, V gy, const EplS
   V gyr = gR0 * st.Ss + gai * st.Cs;
   V gxr = gX * q;
   g_phi += gxr * st.yr - gyr * st.xr;
-  acc[EPLA_CX] -= gxr * c - gyr * s;
-  acc[EPLA_CY] -= gxr * s + gyr * c;
+  acc[EPLA_CX] += gxr;    // lens-frame sums: rotated to the sky frame (and negated) once, in the epilogue
+  acc[EPLA_CY] += gyr;
   acc[EPLA_PHI] += g_phi;
   acc[EPLA_Q] += gX * st.xr;
   acc[EPLA_T] += g_t;

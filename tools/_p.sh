@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r2e
-python -m pytest tests -m gpu -q -x > gpurun_out/r2e/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r2e/pytest.log
-python bench.py --no-cpu-baseline > gpurun_out/r2e/bench.json 2>&1; python3 -c "
-import json
-r=json.loads([l for l in open('gpurun_out/r2e/bench.json') if l.startswith('{')][-1]); print(r['value'], r['ms_per_step'], r['roofline']['kernel_ms'], r['roofline']['frac'], r['roofline']['valu_flop_frac'], r['roofline']['isa']['valu_insts_per_pixel'])"
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/r2e/pytest.log 2>&1; echo "rc=$?"; tail -2 gpurun_out/r2e/pytest.log | cut -c1-300
+python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(r['value'], r['ms_per_step'], r['roofline']['kernel_ms'], r['roofline']['isa'].get('valu_insts_per_pixel'), r['roofline'].get('valu_flop_frac'))"
