@@ -179,8 +179,13 @@ int run_galprep(const gl_model* m, const float* params, int B, const Workspace& 
 int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, hipStream_t stream) {
   int n_comp = (int)m->comps.size();
   int total = B * n_comp;
-  hipLaunchKernelGGL(gl_prep_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, params,
-                     m->P, B, w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
+  if (m->has_epl && n_comp <= 64 && m->wave_prep)  // one wavefront per sample: the EPL coefficient tables are built by a scan over its lanes
+    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, m->d_comps, n_comp, params, nullptr, 0,
+                       (const ZCol*)nullptr, (const int*)nullptr, (const float*)nullptr, m->P, B, (float*)nullptr, w.derived,
+                       m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
+  else
+    hipLaunchKernelGGL(gl_prep_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, params,
+                       m->P, B, w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
   GL_HIP(hipGetLastError());
   return run_galprep(m, params, B, w, stream);
 }
@@ -511,6 +516,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   }
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
+  m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
 
@@ -1205,9 +1211,14 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   int chunk, n_chunks;
   chunking(m, B, &chunk, &n_chunks);
   int n_comp = (int)m->comps.size();
-  hipLaunchKernelGGL(gl_zprep_kernel, dim3((B * n_comp + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, z,
-                     m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D,
-                     m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
+  if (m->has_epl && n_comp <= 64 && m->wave_prep)
+    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, m->d_comps, n_comp, (const float*)nullptr, z,
+                       m->d_z, (const ZCol*)m->d_zcols, (const int*)m->d_src, (const float*)m->d_const, m->P, B, w.params,
+                       w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
+  else
+    hipLaunchKernelGGL(gl_zprep_kernel, dim3((B * n_comp + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, z,
+                       m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D,
+                       m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
   GL_HIP(hipGetLastError());
   if ((rc = run_galprep(m, w.params, B, w, stream))) return rc;
   const float* extra = nullptr;

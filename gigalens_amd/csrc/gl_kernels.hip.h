@@ -299,6 +299,97 @@ __global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restric
   if (cost && c == cost_comp) cost[b] = reinterpret_cast<const int*>(dd)[EPL_KI];
 }
 
+// ---- wave-per-sample front end (models with EPL lenses) --------------------------------------------------------------
+// The thread-per-component kernels above leave the EPL coefficient table to ONE thread: ~15-50 dependent iterations with a
+// division each, 7.5 us of latency in front of a 90 us main kernel.  Here one wavefront owns a sample: lane c does what the
+// thread of component c does above except the table, then all 64 lanes build the table of each EPL lens -- lane n takes
+// row n: its factors (one division), and the running products by an inclusive scan over the lanes.  The recurrence
+//   (c, cf, ct) <- (c p, cf p + c r, ct p + c dp/dt)      [r = p / f = dp/df]
+// is the product of matrices [[p,0,0],[r,p,0],[dpdt,0,p]], closed under (P, Qf, Qt) o (P', Qf', Qt') =
+// (P P', Qf P' + P Qf', Qt P' + P Qt'): associative, so six shuffle steps replace the chain (no division by p or f:
+// f = 0 and gamma = 1 stay finite exactly like the sequential form).
+struct EplScan { float P, Qf, Qt; };
+__device__ __forceinline__ EplScan epl_scan_combine(const EplScan& lo, const EplScan& hi) {  // rows of `lo` come first
+  return EplScan{lo.P * hi.P, lo.Qf * hi.P + lo.P * hi.Qf, lo.Qt * hi.P + lo.P * hi.Qt};
+}
+__device__ __forceinline__ void epl_table_wave(float f, float two_mt, int K, float* __restrict__ tab, int lane) {
+  EplScan carry{1.f, 0.f, 0.f};
+  for (int base = 0; base <= K + 3; base += 64) {
+    const int n = base + lane;
+    EplScan v{1.f, 0.f, 0.f};  // row 0: c_0 = 1, derivatives 0
+    if (n >= 1 && n <= K) {
+      float r, pn, dpdt;
+      epl_row_factors<float>(n, f, two_mt, r, pn, dpdt);
+      v = EplScan{pn, r, dpdt};
+    }
+#pragma unroll
+    for (int delta = 1; delta < 64; delta <<= 1) {
+      EplScan u{__shfl_up(v.P, delta), __shfl_up(v.Qf, delta), __shfl_up(v.Qt, delta)};
+      if (lane >= delta) v = epl_scan_combine(u, v);
+    }
+    v = epl_scan_combine(carry, v);
+    if (n <= K) {
+      reinterpret_cast<float4*>(tab)[n] = float4{v.P, (float)(2 * n + 1) * v.P, v.Qf, v.Qt};
+    } else if (n <= K + 3) {
+      reinterpret_cast<float4*>(tab)[n] = float4{0.f, 0.f, 0.f, 0.f};  // the four-row trips of the Clenshaw loop may start above K
+    }
+    carry = EplScan{__shfl(v.P, 63), __shfl(v.Qf, 63), __shfl(v.Qt, 63)};
+  }
+}
+
+// params != null: packed constrained rows in (gl_prep_kernel's job); else z -> params_out through the bijectors
+// (gl_zprep_kernel's job).  n_comp <= 64.
+__global__ void __launch_bounds__(256) gl_prep_wave_kernel(const CompDesc* __restrict__ comps, int n_comp,
+                                                           const float* __restrict__ params_in, const float* __restrict__ z,
+                                                           int d_z, const ZCol* __restrict__ zcols,
+                                                           const int* __restrict__ src, const float* __restrict__ const_row,
+                                                           int P, int B, float* __restrict__ params_out,
+                                                           float* __restrict__ derived, int D, int* __restrict__ cost,
+                                                           int cost_comp) {
+  const int b = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (b >= B) return;  // whole wavefronts leave together
+  float f = 0.f, two_mt = 0.f;
+  int K = 0;
+  if (lane < n_comp) {
+    const CompDesc cd = comps[lane];
+    const float* p;
+    if (params_in) {
+      p = params_in + (size_t)b * P + cd.p_off;
+    } else {
+      float* po = params_out + (size_t)b * P + cd.p_off;
+      for (int j = 0; j < cd.n_par; ++j) {
+        const int col = cd.p_off + j, k = src[col];
+        po[j] = (k >= 0) ? z_eval(zcols[k], z[(size_t)b * d_z + k]).x : const_row[col];
+      }
+      p = po;
+    }
+    float* d = derived + (size_t)b * D + cd.d_off;
+    switch (cd.kind) {
+      case K_EPL: K = epl_prep_head<float>(p, cd.iparam, d, f, two_mt); break;
+      case K_SIE: sie_prep<float>(p, d); break;
+      case K_NFW: nfw_prep<float>(p, d); break;
+      case K_SHEAR: shear_prep<float>(p, d); break;
+      case K_SIS: sis_prep<float>(p, d); break;
+      case K_DPIS: case K_DPIE: case K_DPIEP: dpie_prep<float>(cd.kind, p, d); break;
+      case K_SCALED: d[0] = d[1] = d[2] = d[3] = 0.f; break;
+      case K_SERIES: d[0] = p[0]; d[1] = p[1]; d[2] = d[3] = 0.f; break;
+      case K_NFW_ELLIPSE: nfw_ell_prep<float>(p, d); break;
+      case K_TNFW: tnfw_prep<float>(p, d); break;
+      case K_CORE_SERSIC: core_sersic_prep<float>(p, d); break;
+      case K_SERSIC: sersic_prep<float>(p, false, d); break;
+      case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
+      case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, d); break;
+    }
+    if (cost && lane == cost_comp) cost[b] = K;
+  }
+  for (int c = 0; c < n_comp; ++c) {  // wave-uniform: every lane joins the table of every EPL lens
+    if (comps[c].kind != K_EPL) continue;
+    const float fc = __shfl(f, c), tc = __shfl(two_mt, c);
+    const int Kc = __shfl(K, c);
+    epl_table_wave(fc, tc, Kc, derived + (size_t)b * D + comps[c].d_off + EPL_TAB, lane);
+  }
+}
+
 // per (sample, galaxy) constants of the catalogue members: radii, amplitude and the map to the scale gradients
 __global__ void __launch_bounds__(128) gl_galprep_kernel(const CompDesc* __restrict__ comps,
                                                          const CatDev* __restrict__ cats, int n_cats,

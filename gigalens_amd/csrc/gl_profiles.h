@@ -215,7 +215,8 @@ GL_HD void ellip_chain(R theta_E, R e1, R e2, R cmax, R g_b, R g_q, R g_phi, R& 
 // derivatives w.r.t. theta, f and t together (forward mode inside the loop, no per-pixel tape).
 // Trip count: n < log(1e-12)/log(f) + 2, capped at niter (epl.py:37,47-54), evaluated per sample
 // (the reference takes max f over the batch; the extra terms it sums are < 1e-12 relative).
-template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
+// scalars of the derived block (d[0..EPL_TAB)); returns the series length K and hands out f and 2 - t for the table
+template <class R> GL_HD int epl_prep_head(const R* p, int cap, R* d, R& f_out, R& two_mt_out) {
   R theta_E = p[0], gamma = p[1], e1 = p[2], e2 = p[3];
   Ellip<R> el = ellip_prep(e1, e2, (R)1);
   R q = el.q;
@@ -234,19 +235,36 @@ template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
   d[10] = (R)0;
   d[EPL_F2] = (R)2 * f;
   R niter = p_log((R)1e-12) / p_log(f) + (R)2;
-  // terms n = 1..K with n < niter (epl.py:47-54), K <= cap:  K = ceil(niter) - 1, evaluated without a data-dependent
-  // exit so that the divisions of different n overlap (they are independent; only the products chain)
+  // terms n = 1..K with n < niter (epl.py:47-54), K <= cap:  K = ceil(niter) - 1
   int K = 0;
   if (niter > (R)1) K = (int)fmin_(-floor_(-niter) - (R)1, (R)cap);
+  d[EPL_K] = (R)K;
+  if (sizeof(R) == 4) {  // the same count as raw int bits, so a kernel can fetch it with a scalar load
+    int* ki = reinterpret_cast<int*>(&d[EPL_KI]);
+    *ki = K;
+  }
+  f_out = f;
+  two_mt_out = (R)2 - t;
+  return K;
+}
+// one row's factors: p_n = f r_n with r_n = -(2n - (2-t)) / (2n + (2-t)), and dp_n/dt
+template <class R> GL_HD void epl_row_factors(int n, R f, R two_mt, R& r, R& pn, R& dpdt) {
+  R iden = (R)1 / ((R)(2 * n) + two_mt);
+  r = -((R)(2 * n) - two_mt) * iden;
+  pn = f * r;
+  dpdt = -f * (R)(4 * n) * (iden * iden);
+}
+template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
+  R f, two_mt;
+  const int K = epl_prep_head(p, cap, d, f, two_mt);
+  // the divisions of different n are independent; only the products chain (the GPU front end builds the same table with a
+  // parallel scan over the lanes of a wave, gl_kernels.hip.h epl_table_wave)
   R* tab = d + EPL_TAB;
   R c = (R)1, cf = (R)0, ct = (R)0;
   tab[0] = (R)1; tab[1] = (R)1; tab[2] = (R)0; tab[3] = (R)0;
-  const R two_mt = (R)2 - t;
   for (int n = 1; n <= K; ++n) {
-    R iden = (R)1 / ((R)(2 * n) + two_mt);
-    R r = -((R)(2 * n) - two_mt) * iden;
-    R pn = f * r;
-    R dpdt = -f * (R)(4 * n) * (iden * iden);
+    R r, pn, dpdt;
+    epl_row_factors(n, f, two_mt, r, pn, dpdt);
     cf = cf * pn + c * r;
     ct = ct * pn + c * dpdt;
     c = c * pn;
@@ -256,11 +274,6 @@ template <class R> GL_HD void epl_prep(const R* p, int cap, R* d) {
     tab[4 * n + 3] = ct;
   }
   for (int j = 0; j < 12; ++j) tab[4 * (K + 1) + j] = (R)0;  // zero rows K+1..K+3: the four-row trips of the Clenshaw loop may start above K
-  d[EPL_K] = (R)K;
-  if (sizeof(R) == 4) {  // the same count as raw int bits, so a kernel can fetch it with a scalar load
-    int* ki = reinterpret_cast<int*>(&d[EPL_KI]);
-    *ki = K;
-  }
 }
 
 template <class R> GL_HD void epl_fwd(const R* d, R x, R y, R& ax, R& ay) {

@@ -1,6 +1,10 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2e
-timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/r2e/pytest.log 2>&1; echo "rc=$?"; tail -2 gpurun_out/r2e/pytest.log | cut -c1-300
-python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "
-import json,sys
-r=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(r['value'], r['ms_per_step'], r['roofline']['kernel_ms'], r['roofline']['isa'].get('valu_insts_per_pixel'), r['roofline'].get('valu_flop_frac'))"
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/r2f
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r2f/stats -- python3 $R/bench.py --no-cpu-baseline --steps 400 > $R/gpurun_out/r2f/b.log 2>&1
+python3 - <<'PY'
+import csv,glob,os
+f=sorted(glob.glob(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/r2f/stats/*/*_kernel_stats.csv'))[-1]
+for r in list(csv.DictReader(open(f)))[:8]:
+    print(r['Name'][:70], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3)
+PY
