@@ -293,11 +293,13 @@ def main():
 
     # untimed pre-roll: sustained load until the chip has settled at its working clock (see the module docstring), so
     # that the timed region reads the same whatever W and K the caller picks; then the W warm-up steps of the contract
+    # (the pre-roll is timed per rank, so it must not contain a collective: ranks would disagree on the number of calls --
+    # it runs the collective-free forward+gradient call, which is the load that matters for the clock)
     t_pre = time.perf_counter()
     n_pre = 0
     while time.perf_counter() - t_pre < args.preroll_seconds:
         for _ in range(50):
-            step()
+            pm.log_prob_and_grad(sim, z)
         torch.cuda.synchronize()
         n_pre += 50
     events = not args.no_kernel_events
@@ -324,6 +326,25 @@ def main():
     if events:
         model.set_timing(0)
     kernel_symbol = model.last_main_kernel()
+    # beside the line's value (not part of it): with several ranks, the same K steps of the plain forward+gradient call on
+    # each rank's shard and NO collective -- how MAP and HMC shard (jax/inference.py:32-80,157-208) -- so that the cost of the
+    # SVI step's extra launches and of its all-reduce can be read off the line
+    sharded = None
+    if world > 1 and mode == "svi":
+        for _ in range(min(args.warmup, 20)):
+            pm.log_prob_and_grad(sim, z)
+        gdist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            pm.log_prob_and_grad(sim, z)
+        torch.cuda.synchronize()
+        gdist.barrier()
+        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        gdist.allreduce_max_(e2)
+        sharded = {"value": round(B * world * args.steps / float(e2.item()), 1), "unit": "sims/s",
+                   "ms_per_step": round(1e3 * float(e2.item()) / args.steps, 4),
+                   "what": "ForwardProbModel.log_prob_and_grad on every rank's shard, no collective (MAP / HMC sharding)"}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -380,7 +401,8 @@ def main():
                        "samples_per_gpu": B, "pixels": N, "params_per_sample": P, "z_dim": d, "mode": mode,
                        "untimed_preroll_steps": n_pre, "kernel_events_in_timed_loop": events,
                        "epl_series": series,
-                       "parallelism": (f"dp{world}: particle shards, one {n_coll}-float RCCL all-reduce per step"
+                       "parallelism": (f"dp{world}: particle shards, one {n_coll}-float all-reduce per step "
+                                       f"(torch.distributed backend {torch.distributed.get_backend()}; nccl = RCCL over xGMI)"
                                        if world > 1 else "single GPU"),
                        "step": ("inference.svi_step_buffer (eps draw, gl_svi_sample, log_prob forward+gradient, gl_svi_grad, all-reduce of "
                                 f"the fused {n_coll}-float [ELBO, grad] buffer) + fused Adam launch (lr 0)" if mode == "svi" else
@@ -388,6 +410,8 @@ def main():
                                 "kernels, prior) in one native launch sequence")},
             "roofline": roofline,
         }
+        if sharded is not None:
+            out["sharded_fwdgrad_without_collective"] = sharded
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             n_cpu = args.cpu_samples or (256 if N <= 16384 else 32)
             out["cpu_baseline"] = cpu_baseline(wl, obs, seconds=args.cpu_seconds, sample_batch=min(n_cpu, B))

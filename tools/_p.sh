@@ -1,10 +1,8 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r2f
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r2f/stats -- python3 $R/bench.py --no-cpu-baseline --steps 400 > $R/gpurun_out/r2f/b.log 2>&1
-python3 - <<'PY'
-import csv,glob,os
-f=sorted(glob.glob(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/r2f/stats/*/*_kernel_stats.csv'))[-1]
-for r in list(csv.DictReader(open(f)))[:8]:
-    print(r['Name'][:70], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3)
-PY
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r2f
+GIGALENS_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 100 --warmup 10 > gpurun_out/r2f/bench_2rank_gloo.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/r2f/bench_2rank_gloo.log | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read()); print(r['n_gpus'], r['value'], r['ms_per_step'], r['config']['mode'], r['config']['parallelism'], r.get('sharded_fwdgrad_without_collective'))" && 
+GIGALENS_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 50 --warmup 5 --workload C5 > gpurun_out/r2f/bench_2rank_gloo_C5.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/r2f/bench_2rank_gloo_C5.log | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read()); print(r['n_gpus'], r['value'], r['ms_per_step'], r['config']['mode'], r['config']['parallelism'], r.get('sharded_fwdgrad_without_collective'))"
