@@ -240,6 +240,11 @@ def main():
     if not os.path.exists(_native.lib_path()):
         ge.build()
 
+    if world > 1:  # bring the communicator up (RCCL builds its rings / trees on the first collective: seconds) before anything is timed
+        warm = torch.ones(8, device=dev)
+        gdist.allreduce_mean_(warm)
+        gdist.barrier()
+        torch.cuda.synchronize()
     mode = args.mode if args.mode != "auto" else ("svi" if world > 1 else "fwdgrad")
     wl = workloads.make(args.workload, num_pix=args.num_pix, batch=args.batch)
     obs, err, _ = workloads.synthetic_observation(wl, LensSimulator)
