@@ -139,6 +139,7 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.out_scale = m->conversion_factor;
   a.partial = w.partial;
   a.shp_tab = m->d_shp_tab;
+  a.nfw_tab = m->d_nfw_tab;
   a.shp_stride = m->shp_stride;
   a.parts = 7u;
   a.cats = m->d_cats;
@@ -476,7 +477,9 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   m->D = std::max(d_off, 4);
   m->A = a_off;
   m->Apad = a_off | 1;  // odd: the 16 leader lanes of a wave land on 16 different LDS banks
-  m->ncols = ((size_t)(((m->D + 3) & ~3) + 64 * m->Apad) * sizeof(float) <= 60 * 1024) ? 64 : 16;
+  for (int i = 0; i < n_lens; ++i) m->has_nfw = m->has_nfw || m->comps[i].kind == K_NFW;
+  m->nfw_lds = m->has_nfw ? sizeof(float) * 2 * glh::kNfwNodes : 0;  // the h(X) table rides in every main kernel's LDS
+  m->ncols = ((size_t)(((m->D + 3) & ~3) + 64 * m->Apad) * sizeof(float) + m->nfw_lds <= 60 * 1024) ? 64 : 16;
   m->height = grid->height;
   m->width = grid->width;
   m->supersample = grid->supersample;
@@ -512,12 +515,13 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     for (int i = 0; i < n_lens && ok_c; ++i) ok_c = m->comps[i].d_off == 4 * i && m->comps[i].a_off == NSTAT + NFW_NACC * i;
     for (int i = 0; i < n_src && ok_c; ++i)
       ok_c = m->comps[n_lens + i].d_off == 4 * n_lens + 12 * i && m->comps[n_lens + i].a_off == NSTAT + NFW_NACC * n_lens + SER_NACC * i;
+    ok_c = ok_c && (size_t)64 * m->Apad * sizeof(float) + sizeof(float) * 2 * glh::kNfwNodes <= 64 * 1024;
     if (ok_c) m->cluster = ell ? 2 : 1;
   }
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
-  size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
+  size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
 
   auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
@@ -537,6 +541,11 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
         return fail(GL_EINVAL, "pix_index[%d]=%d out of range", i, grid->pix_index[i]);
       }
     ok = ok && up((void**)&m->d_pix, grid->pix_index, sizeof(int) * m->N);
+  }
+  if (m->has_nfw) {
+    std::vector<float> tab;
+    glh::build_nfw_table([](double X, double& g, double& gp) { glp::nfw_gw<double>(X, g, gp); }, tab);
+    ok = ok && up((void**)&m->d_nfw_tab, tab.data(), tab.size() * sizeof(float));
   }
   if (m->has_table) {
     std::vector<float> tab;
@@ -640,6 +649,7 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_gy) (void)hipFree(m->d_gy);
   if (m->d_pix) (void)hipFree(m->d_pix);
   if (m->d_shp_tab) (void)hipFree(m->d_shp_tab);
+  if (m->d_nfw_tab) (void)hipFree(m->d_nfw_tab);
   if (m->d_psf) (void)hipFree(m->d_psf);
   if (m->d_pos) (void)hipFree(m->d_pos);
   if (m->d_fam) (void)hipFree(m->d_fam);

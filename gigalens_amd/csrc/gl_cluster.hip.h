@@ -40,21 +40,19 @@ template <class V> struct SerStateC { V E, u; };  // log2(R/Rs) is recomputed in
 //   a = K0 h;  cot(K0) = ga h;  gX0 = ga p, p = [X0 > 1e-6] K0 h';  t = gR0 / R0 = ga w, w = [R0 > 1e-7] p / (Rs R0);
 //   cot(Rs) = -gX0 X0 / Rs = -ga uu, uu = p X0 / Rs        (ga = g . (dx, dy))
 template <class V>
-__device__ __forceinline__ void nfw_fwd_c(const float* __restrict__ d, V x, V y, V& bx, V& by, NfwStateC<V>& st) {
+__device__ __forceinline__ void nfw_fwd_c(const float* __restrict__ d, const float* __restrict__ s_tab, V x, V y, V& bx, V& by,
+                                          NfwStateC<V>& st) {
   const float invrs = d[NFW_INVRS], K0 = d[NFW_K0];
   V dx = x - d[NFW_CX], dy = y - d[NFW_CY];
   V r2 = dx * dx + dy * dy;
   V R0 = sqrt_(r2);
+  V iR0 = (r2 > V(0.f)) ? rcp(R0) : V(0.f);
   V X0 = vmax(R0, V(1e-7f)) * invrs;  // nfw.py:26
   V X = vmax(X0, V(1e-6f));           // nfw.py:37
-  V g, gp;
-  nfw_gw_v(X, g, gp);
   V iX = rcp(X);
-  V iX2 = iX * iX;
-  st.h = g * iX2;
-  V hp = gp * iX2 - (st.h + st.h) * iX;
+  V hp;
+  nfw_h_pair(s_tab, X, iX, st.h, hp);
   V p = (X0 > V(1e-6f)) ? hp * K0 : V(0.f);
-  V iR0 = (r2 > V(0.f)) ? rsq_(r2) : V(0.f);
   st.w = (R0 > V(1e-7f)) ? p * invrs * iR0 : V(0.f);
   st.uu = p * X0 * invrs;
   V a = st.h * K0;
@@ -172,10 +170,12 @@ __global__ void __launch_bounds__(WG, WAVES) gl_cluster_kernel(MainArgs a, int n
   constexpr int W = 2;
   constexpr int SERP = (SER_ND + 2 + 3) & ~3, NFWP = (NFW_ND + 3) & ~3;
   extern __shared__ float smem[];
-  float* s_acc = smem;  // [64][Apad]
+  float* s_acc = smem;                  // [64][Apad]
+  float* s_tab = smem + 64 * a.Apad;    // [NFW_TAB_NODES][2]: h(X), dh/du du
   const int tid = threadIdx.x;
   const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
   for (int i = tid; i < 64 * a.Apad; i += WG) s_acc[i] = 0.f;
+  for (int i = tid; i < 2 * NFW_TAB_NODES; i += WG) s_tab[i] = a.nfw_tab[i];
   __syncthreads();
   // this sample's derived constants: wave-uniform address -> scalar loads
   const float* __restrict__ gder = a.derived + (size_t)b * a.D;
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_cluster_kernel(MainArgs a, int n
 #pragma unroll
     for (int h = 0; h < NH; ++h)
       if (h < n_h) {
-        nfw_fwd_c<V>(dH + NFWP * h, x, y, bx, by, hst[h]);
+        nfw_fwd_c<V>(dH + NFWP * h, s_tab, x, y, bx, by, hst[h]);
         GL_SCHED_FENCE();
       }
     // ---- render the sources at beta (tf/simulator.py:128-138) ----

@@ -24,4 +24,36 @@ inline void build_shapelet_table(int n_max, std::vector<float>& tab, int* stride
   *stride = st;
 }
 
+
+// NFW:  h(X) = g(X) / X^2  -- the radial deflection of a spherical NFW halo is  alpha(R) = 4 rho0 Rs^2 g(X) / X * (d / R)
+// = K0 h(X) d  with X = R / Rs (tf/profiles/mass/nfw.py:26-52).  h has no parameters, so the cluster kernel reads it from
+// ONE table shared by every halo of every sample.  Nodes follow the float format itself: octave e in [kNfwLog2Lo,
+// kNfwLog2Hi), kNfwPerOctave equal steps of the mantissa inside it, X(e, j) = 2^e (1 + j / kNfwPerOctave), j = 0..kNfwPerOctave
+// (the last node of an octave repeats the first of the next with the slope scaled to its own interval width) -- so a
+// lane finds its interval and its position t inside it from the exponent and mantissa BITS of X, exactly, with no
+// logarithm.  Node = (h, dh/dX * dX_e), dX_e = 2^e / kNfwPerOctave, for cubic Hermite interpolation in X: interpolation
+// error ~1e-11 relative, so what is left is the rounding of a dozen fp32 operations, like any closed-form evaluation.
+// Built in float64 from the same nfw_gw the kernels instantiate.
+constexpr int kNfwPerOctave = 128, kNfwLog2Lo = -6, kNfwLog2Hi = 6;
+constexpr int kNfwOctaveStride = kNfwPerOctave + 1;
+constexpr int kNfwNodes = (kNfwLog2Hi - kNfwLog2Lo) * kNfwOctaveStride;
+
+template <class GW> inline void build_nfw_table(GW gw, std::vector<float>& tab) {
+  tab.assign((size_t)2 * kNfwNodes, 0.f);
+  for (int e = kNfwLog2Lo; e < kNfwLog2Hi; ++e)
+    for (int j = 0; j <= kNfwPerOctave; ++j) {
+      const double X = std::ldexp(1.0 + (double)j / kNfwPerOctave, e), dX = std::ldexp(1.0 / kNfwPerOctave, e);
+      double g, gp;
+      gw(X, g, gp);
+      if (X == 1.0) {  // the node AT X = 1 must carry the analytic value 1 - ln 2 (g' = 1/3), not the reference's g(1) = 1
+        g = 1.0 - 0.693147180559945309417232121458;  // (that quirk applies to the single float X == 1 and is handled in the kernel)
+        gp = 1.0 / 3.0;
+      }
+      const double iX = 1.0 / X, h = g * iX * iX, hp = gp * iX * iX - 2.0 * h * iX;
+      const size_t i = (size_t)(e - kNfwLog2Lo) * kNfwOctaveStride + j;
+      tab[2 * i] = (float)h;
+      tab[2 * i + 1] = (float)(hp * dX);
+    }
+}
+
 }  // namespace glh

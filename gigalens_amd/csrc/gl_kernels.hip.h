@@ -100,6 +100,7 @@ struct MainArgs {
   int scaled_first;  // the K_SCALED lens whose scale tangents ride along the ray-shooting pass (-1: none)
   int n_lin;         // IMG_BASIS: channels of the stack  img[B][n_lin][img_stride]
   const SeriesDev* series;
+  const float* nfw_tab;  // models with NFW lenses: the shared h(X) table (gl_host_tables.h), [kNfwNodes][2]; else null
 };
 
 // ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
@@ -596,12 +597,15 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
   extern __shared__ float smem[];
   float* s_d = smem;
   float* s_acc = smem + ((a.D + 3) & ~3);
+  float* s_nfw = s_acc + a.ncols * a.Apad;  // models with NFW lenses: the shared h(X) table (8-byte aligned: ncols is even)
   const int tid = threadIdx.x;
   const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
   const CompDesc* __restrict__ comps = a.comps;
   {
     const float* src = a.derived + (size_t)b * a.D;
     for (int i = tid; i < a.D; i += WG) s_d[i] = src[i];
+    if (a.nfw_tab)
+      for (int i = tid; i < 2 * NFW_TAB_NODES; i += WG) s_nfw[i] = a.nfw_tab[i];
     if (MODE != IMG_FWD && MODE != IMG_BASIS)
       for (int i = tid; i < a.ncols * a.Apad; i += WG) s_acc[i] = 0.f;
   }
@@ -647,7 +651,7 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
 #pragma unroll
             for (int t = 0; t < T; t += 2) {
               v2f vbx{bx[t], bx[t + 1]}, vby{by[t], by[t + 1]};
-              nfw_fwd_v<v2f>(d, v2f{x[t], x[t + 1]}, v2f{y[t], y[t + 1]}, vbx, vby);
+              nfw_fwd_v(d, s_nfw, v2f{x[t], x[t + 1]}, v2f{y[t], y[t + 1]}, vbx, vby);
               bx[t] = vbx.x; bx[t + 1] = vbx.y; by[t] = vby.x; by[t + 1] = vby.y;
             }
           } else {
@@ -919,7 +923,7 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
               for (int k = 0; k < NFW_NACC; ++k) va[k] = v2f(0.f);
 #pragma unroll
               for (int t = 0; t < T; t += 2)
-                nfw_vjp_v<v2f>(d, v2f{x[t], x[t + 1]}, v2f{y[t], y[t + 1]}, v2f{gbx[t], gbx[t + 1]}, v2f{gby[t], gby[t + 1]}, va);
+                nfw_vjp_v(d, s_nfw, v2f{x[t], x[t + 1]}, v2f{y[t], y[t + 1]}, v2f{gbx[t], gbx[t + 1]}, v2f{gby[t], gby[t + 1]}, va);
 #pragma unroll
               for (int k = 0; k < NFW_NACC; ++k) acc[k] = va[k].x + va[k].y;
             } else {

@@ -94,7 +94,7 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
 template <int MODE>
 int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream) {
   dim3 grid(n_chunks, B), block(WG);
-  size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float);
+  size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   // every timing_stride-th main launch is bracketed by an event pair (an event record costs ~2.5 us of stream time)
   const bool timed = m->timing_slots && (m->timing_calls++ % m->timing_stride) == 0;
   const int slot = timed ? (int)(m->timing_count % m->timing_slots) : 0;
@@ -109,7 +109,7 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
   bool done = false;
   if constexpr (MODE == IMG_BWD || MODE == LL_GRAD) {
     if (m->cluster && a.parts == 7u) {  // N x same-kind cluster model: forward state of every component kept in registers
-      const size_t sh = (size_t)64 * m->Apad * sizeof(float);
+      const size_t sh = (size_t)64 * m->Apad * sizeof(float) + sizeof(float) * 2 * NFW_TAB_NODES;  // gradient columns + the h(X) table
 #define GL_CLUSTER(NH_, NS_, E_, W_)                                                                     \
   do {                                                                                                 \
     m->last_main_fn = (const void*)&gl_cluster_kernel<MODE, NH_, NS_, E_, W_>;                          \

@@ -38,6 +38,9 @@ struct gl_model {
   float* d_gy = nullptr;
   int* d_pix = nullptr;
   float* d_shp_tab = nullptr;
+  float* d_nfw_tab = nullptr;  // models with NFW lenses: h(X) = g(X) / X^2 on the float format's own grid (gl_host_tables.h)
+  bool has_nfw = false;
+  size_t nfw_lds = 0;          // bytes of that table in a main kernel's LDS
   int shp_stride = 0;
   float* d_psf = nullptr;  // effective kernel flip(psf) (*) box(ss)/ss^2, see gl_post.hip.h
   int psf_h = 0, psf_w = 0;

@@ -279,39 +279,78 @@ __device__ __forceinline__ void sersic_vjp_v(const float* d, const SerStateV<V>&
 }
 
 
-// ---- NFW (tf/profiles/mass/nfw.py:15-52): g(X) per lane (branchy, see nfw_gw), the rest packed ---------------
-__device__ __forceinline__ void nfw_gw_v(float X, float& g, float& gp) { nfw_gw<float>(X, g, gp); }
-__device__ __forceinline__ void nfw_gw_v(v2f X, v2f& g, v2f& gp) {
-  float g0, g1, p0, p1;
-  nfw_gw<float>(X.x, g0, p0);
-  nfw_gw<float>(X.y, g1, p1);
-  g = v2f{g0, g1};
-  gp = v2f{p0, p1};
+// ---- NFW (tf/profiles/mass/nfw.py:15-52) ---------------------------------------------------------------------
+// the shared table of h(X) = g(X) / X^2 (gl_host_tables.h: same constants)
+constexpr int NFW_TAB_PER_OCTAVE = 128, NFW_TAB_LOG2_LO = -6, NFW_TAB_LOG2_HI = 6, NFW_TAB_STRIDE = NFW_TAB_PER_OCTAVE + 1;
+constexpr int NFW_TAB_NODES = (NFW_TAB_LOG2_HI - NFW_TAB_LOG2_LO) * NFW_TAB_STRIDE;
+
+
+// h(X) and dh/dX on a pixel pair.  g(X) in closed form costs ~45 VALU instructions and 6-8 quarter-rate transcendentals
+// per LANE (nfw_gw: branchy, not packable) -- 92 per pixel and halo, half of the whole kernel at 8 halos.  h has no
+// parameters, so inside [2^-6, 2^6) it is read from one LDS-resident table (gl_host_tables.h) by cubic Hermite
+// interpolation in X: the interval and the position inside it come from the exponent and mantissa bits of X (exact, no
+// logarithm), two 8-byte LDS reads per lane, a dozen packed instructions per pair.  Outside the table, and at exactly X = 1
+// where the reference returns g = 1 (nfw.py:38), the closed form runs.
+__device__ __forceinline__ void nfw_h_pair(const float* __restrict__ s_tab, v2f X, v2f iX, v2f& h, v2f& hp) {
+  // (element copies first: __builtin_bit_cast applied to an ext-vector ELEMENT expression reads element 0 for both)
+  const float x0 = X.x, x1 = X.y;
+  const int b0 = __float_as_int(x0), b1 = __float_as_int(x1);
+  const int e0 = (b0 >> 23) - 127, e1 = (b1 >> 23) - 127;  // X >= 1e-6 > 0: sign bit clear, normal numbers
+  const bool in0 = (e0 >= NFW_TAB_LOG2_LO) && (e0 < NFW_TAB_LOG2_HI) && (X.x != 1.f);
+  const bool in1 = (e1 >= NFW_TAB_LOG2_LO) && (e1 < NFW_TAB_LOG2_HI) && (X.y != 1.f);
+  const int o0 = min(max(e0 - NFW_TAB_LOG2_LO, 0), NFW_TAB_LOG2_HI - NFW_TAB_LOG2_LO - 1);
+  const int o1 = min(max(e1 - NFW_TAB_LOG2_LO, 0), NFW_TAB_LOG2_HI - NFW_TAB_LOG2_LO - 1);
+  const int i0 = o0 * NFW_TAB_STRIDE + ((b0 >> 16) & 127), i1 = o1 * NFW_TAB_STRIDE + ((b1 >> 16) & 127);
+  const float2 a0 = reinterpret_cast<const float2*>(s_tab)[i0], c0 = reinterpret_cast<const float2*>(s_tab)[i0 + 1];
+  const float2 a1 = reinterpret_cast<const float2*>(s_tab)[i1], c1 = reinterpret_cast<const float2*>(s_tab)[i1 + 1];
+  const v2f t = v2f{(float)(b0 & 0xFFFF), (float)(b1 & 0xFFFF)} * (1.f / 65536.f);  // the low 16 mantissa bits: exact
+  const v2f f0{a0.x, a1.x}, d0{a0.y, a1.y}, f1{c0.x, c1.x}, d1{c0.y, c1.y};
+  const v2f df = f1 - f0;
+  const v2f c2 = df * 3.f - d0 * 2.f - d1, c3 = d0 + d1 - df * 2.f;
+  h = ((c3 * t + c2) * t + d0) * t + f0;
+  const v2f dh = (c3 * (3.f * t) + c2 * 2.f) * t + d0;  // dh/dt, t = (X - X_node) / dX_e
+  // dh/dX = dh/dt / dX_e,  1 / dX_e = 128 * 2^-e: a power of two built from the exponent
+  const v2f inv_dx{__int_as_float((127 + 7 - e0) << 23), __int_as_float((127 + 7 - e1) << 23)};
+  hp = dh * inv_dx;
+  // rare: a lane outside the table (or exactly on the reference's g(1) = 1 point) takes the closed form, lane by lane
+  if (!in0) {
+    float g, gp;
+    nfw_gw<float>(X.x, g, gp);
+    const float i2 = iX.x * iX.x, he = g * i2;
+    h.x = he;
+    hp.x = gp * i2 - (he + he) * iX.x;
+  }
+  if (!in1) {
+    float g, gp;
+    nfw_gw<float>(X.y, g, gp);
+    const float i2 = iX.y * iX.y, he = g * i2;
+    h.y = he;
+    hp.y = gp * i2 - (he + he) * iX.y;
+  }
 }
-template <class V> __device__ __forceinline__ void nfw_fwd_v(const float* d, V x, V y, V& bx, V& by) {
-  V dx = x - d[NFW_CX], dy = y - d[NFW_CY];
-  V R0 = sqrt_(dx * dx + dy * dy);
-  V X = vmax(vmax(R0, V(1e-7f)) * d[NFW_INVRS], V(1e-6f));  // nfw.py:26,37
-  V g, gp;
-  nfw_gw_v(X, g, gp);
-  V iX = rcp(X);
-  V a = g * iX * iX * d[NFW_K0];
+
+// pixel-pair forward / VJP of the interpreter kernel (the cluster kernel splits the same maths at the forward state)
+__device__ __forceinline__ void nfw_fwd_v(const float* d, const float* __restrict__ s_tab, v2f x, v2f y, v2f& bx, v2f& by) {
+  v2f dx = x - d[NFW_CX], dy = y - d[NFW_CY];
+  v2f R0 = sqrt_(dx * dx + dy * dy);
+  v2f X = vmax(vmax(R0, v2f(1e-7f)) * d[NFW_INVRS], v2f(1e-6f));  // nfw.py:26,37
+  v2f h, hp;
+  nfw_h_pair(s_tab, X, rcp(X), h, hp);
+  v2f a = h * d[NFW_K0];
   bx -= a * dx;
   by -= a * dy;
 }
-template <class V> __device__ __forceinline__ void nfw_vjp_v(const float* d, V x, V y, V gx, V gy, V* acc) {
+__device__ __forceinline__ void nfw_vjp_v(const float* d, const float* __restrict__ s_tab, v2f x, v2f y, v2f gx, v2f gy, v2f* acc) {
+  using V = v2f;
   V dx = x - d[NFW_CX], dy = y - d[NFW_CY];
   V R0 = sqrt_(dx * dx + dy * dy);
   V X0 = vmax(R0, V(1e-7f)) * d[NFW_INVRS];
   V X = vmax(X0, V(1e-6f));
-  V g, gp;
-  nfw_gw_v(X, g, gp);
-  V iX = rcp(X);
-  V h = g * iX * iX;
+  V h, hp;
+  nfw_h_pair(s_tab, X, rcp(X), h, hp);
   const float K0 = d[NFW_K0];
   V a = h * K0;
   V ga = gx * dx + gy * dy;
-  V hp = gp * iX * iX - (h + h) * iX;
   V gX0 = (X0 > V(1e-6f)) ? ga * hp * K0 : V(0.f);
   V gR0 = (R0 > V(1e-7f)) ? gX0 * d[NFW_INVRS] : V(0.f);
   V iR0 = (R0 > V(0.f)) ? rcp(R0) : V(0.f);

@@ -388,6 +388,15 @@ def test_full_size_properties(gl, name, kw):
     sig2 = (wl.background_rms ** 2 + im / wl.exp_time) if err is None else (err.double() ** 2).expand_as(im)
     ll_img = -0.5 * (((im - o) ** 2 / sig2).sum((-2, -1)) + torch.log(2 * math.pi * sig2).sum((-2, -1)))
     assert torch.allclose(ll.detach().double(), ll_img, rtol=LL_RTOL)
+    # (1b) the float64 oracle on the first rows at the config's FULL pixel grid (the whole batch would take minutes): the
+    # reduced-size oracle cases cannot see errors that only matter on 65 536-pixel sums of large residuals
+    n_o = 4
+    wl_o = gl.workloads.make(name, **{**kw, "batch": n_o})
+    ll_o, _, g_o, _ = H.oracle_loglike_and_grad(wl_o, packed[:n_o].double().cpu(), obs.cpu().numpy(),
+                                                None if err is None else err.cpu().numpy(), n_o)
+    assert np.allclose(ll.detach()[:n_o].cpu().numpy(), ll_o, rtol=LL_RTOL)
+    assert np.allclose(ll_img[:n_o].cpu().numpy(), ll_o, rtol=LL_RTOL)
+    assert np.abs(p.grad[:n_o].cpu().numpy() - g_o).max() <= GRAD_RTOL * np.abs(g_o).max(1, keepdims=True).max()
     # (2) batch independence: a sub-batch gives the same rows (another batch size means another pixel chunking, i.e. another
     # fixed summation order of the fp32 partial sums: a few ulps of the 65 536-term sum)
     sim_small = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=7)
@@ -457,6 +466,55 @@ def test_cluster_kernel_matches_interpreter(gl, n_halos, n_sources, ellipse, num
         scale = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-6 * float(b.abs().max()))
         assert float(((a - b).abs() / scale).max()) < 2e-4
         assert float((a - b).abs().max()) > 0.0 or n_sources == 0  # two different kernels ran
+
+
+@pytest.mark.parametrize("cluster", ["1", "0"])
+def test_nfw_table_ranges_vs_oracle(gl, cluster, monkeypatch):
+    """The main kernels read h(X) = g(X)/X^2 of the NFW deflection (nfw.py:26-52) from an LDS table on [2^-6, 2^6) and take
+    the closed form outside it and at X == 1 (gl_vec.hip.h::nfw_h_pair).  Halos whose scale radius puts the image's pixels
+    below the table (Rs = 40: X down to 3e-4), above it (Rs = 0.01: X up to 300), across X = 1 (Rs = 1) and with a pixel 1e-5
+    from the halo centre against the float64 oracle: image, log-likelihood, gradient -- through the cluster kernel and
+    through the interpreter.  (The g(1) = 1 point itself: tests/test_hostmath_vjp.py::test_nfw_through_x_equal_one.)"""
+    import math
+    from gigalens_amd import prior as tfd
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.profiles.mass.nfw import NFW
+    from gigalens_amd.simulator import SimulatorConfig
+    monkeypatch.setenv("GIGALENS_HIP_CLUSTER", cluster)
+    J, S = tfd.JointDistributionNamed, tfd.JointDistributionSequential
+    phys = PhysicalModel([NFW()], [], [Sersic()])
+    prior = J(dict(lens_mass=S([J(dict(Rs=tfd.LogNormal(0.0, 1.0), alpha_Rs=tfd.LogNormal(0.0, 0.3), center_x=tfd.Normal(0, 1),
+                                       center_y=tfd.Normal(0, 1)))]),
+                   source_light=S([J(dict(R_sersic=tfd.LogNormal(math.log(0.3), 0.1), n_sersic=tfd.Uniform(1, 3),
+                                          center_x=tfd.Normal(0, 0.1), center_y=tfd.Normal(0, 0.1), Ie=tfd.LogNormal(math.log(100.0), 0.3)))])))
+    cfg = SimulatorConfig(delta_pix=0.065, num_pix=48)
+    rows = [  # Rs, alpha_Rs, cx, cy | R_sersic, n, cx, cy, Ie
+        [40.0, 30.0, 0.03, -0.01, 0.3, 1.5, 0.05, 0.02, 100.0],
+        [0.01, 0.02, 0.4, 0.3, 0.3, 2.0, 0.05, 0.02, 100.0],
+        [1.0, 1.0, 0.2, -0.1, 0.25, 1.0, -0.05, 0.1, 120.0],
+        [0.13, 0.5, 0.03249, 0.03251, 0.3, 2.5, 0.0, 0.0, 80.0],   # centre 1e-5 off a pixel (exactly ON it the reference's gradient is NaN: d sqrt at 0)
+        [5.0, 2.0, 3.0, -0.1, 0.3, 1.5, 0.05, 0.02, 100.0],
+    ]
+    B = len(rows)
+    wl = gl.workloads.Workload("NFWT", phys, prior, cfg, B)
+    sim = gl.LensSimulator(phys, cfg, bs=B)
+    packed = torch.tensor(rows, dtype=torch.float32, device="cuda")
+    obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    obs_np = obs.cpu().numpy()
+    ll_o, red_o, g_o, img_o = H.oracle_loglike_and_grad(wl, packed.cpu().double(), obs_np, None, B)
+    img = sim.simulate(packed).cpu().numpy().reshape(img_o.shape)
+    assert np.abs(img - img_o).max() <= IMG_RTOL * np.abs(img_o).max() + 1e-7
+    pm = gl.ForwardProbModel(prior, obs_np, wl.background_rms, wl.exp_time, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, _ = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    assert ("gl_cluster_kernel" if cluster == "1" else "gl_main_kernel") in sim._model.last_main_kernel()
+    assert np.allclose(ll.detach().cpu().numpy(), ll_o, rtol=LL_RTOL)
+    scale = np.abs(g_o).max(axis=1, keepdims=True)
+    g = p.grad.cpu().numpy()
+    bad = ~(np.abs(g - g_o) <= GRAD_RTOL * scale + 1e-6)
+    assert not bad.any(), (np.argwhere(bad)[:8], g[bad][:8], g_o[bad][:8], scale.ravel())
 
 
 def test_dispatched_kernels_do_not_spill(gl):
