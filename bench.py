@@ -150,8 +150,11 @@ def launch_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+EPL_SERIES_TOL = 1e-9  # csrc/gl_profiles.h epl_series_tol<float>(): where the float32 kernels stop the EPL angular series
+
+
 def epl_series_stats(wl, x_struct):
-    """Trips of the EPL series loop over the batch: the per-sample term count K = ceil(log(1e-12) / log f + 2) - 1 (capped
+    """Trips of the EPL series loop over the batch: the per-sample term count K = ceil(log(tol) / log f + 2) - 1 (capped
     at niter) with f = (1-q)/(1+q) = min(|e|, 1), restated from csrc/gl_profiles.h epl_prep (epl.py:22,37,47-54).  The
     Clenshaw loop of csrc/gl_vec.hip.h takes the terms K..0 four at a time (the table is zero-filled above K), two
     four-term groups per loop iteration with an exit after either: T = ceil((K + 1) / 4) groups, T / 2 iterations of the
@@ -164,7 +167,7 @@ def epl_series_stats(wl, x_struct):
         e = torch.sqrt(torch.as_tensor(p["e1"], dtype=torch.float64) ** 2 + torch.as_tensor(p["e2"], dtype=torch.float64) ** 2)
         f = e.clamp(1e-30, 1.0).reshape(-1)
         cap = int(getattr(prof, "niter", 50) or 50)
-        niter = math.log(1e-12) / torch.log(f) + 2.0
+        niter = math.log(EPL_SERIES_TOL) / torch.log(f) + 2.0
         K = torch.where(niter > 1, torch.ceil(niter) - 1, torch.zeros_like(niter)).clamp(max=cap)
         K = torch.where(f >= 1.0, torch.full_like(K, float(cap)), K)
         groups += float(torch.ceil((K + 1) / 4).mean())
@@ -274,7 +277,7 @@ def main():
                 if getattr(prof, "_kind", 0) == 1:
                     e = torch.sqrt(torch.as_tensor(p["e1"], dtype=torch.float64) ** 2 + torch.as_tensor(p["e2"], dtype=torch.float64) ** 2)
                     break
-            K = torch.ceil(math.log(1e-12) / torch.log(e.clamp(1e-30, 1 - 1e-12)) + 2.0) - 1
+            K = torch.ceil(math.log(EPL_SERIES_TOL) / torch.log(e.clamp(1e-30, 1 - 1e-12)) + 2.0) - 1
             pick = int(torch.argmin((K - round(s0["mean_terms"])).abs()))
             g = float(torch.ceil((K[pick] + 1) / 4))
             series = {"mean_terms": float(K[pick]), "mean_four_term_groups": g, "mean_pair_trips": 0.5 * g, "frac_odd": 0.0}

@@ -58,6 +58,7 @@ void chunking(const gl_model* m, int B, int* chunk, int* n_chunks) {
   long long want = std::max<long long>(1, (m->target_wgs + B - 1) / B);
   long long per = ((long long)m->N + want - 1) / want;
   per = std::max(tile_px, (per + tile_px - 1) / tile_px * tile_px);
+  if (m->chunk_px_override > 0) per = m->chunk_px_override;  // experiments: GIGALENS_HIP_CHUNK_PX (a multiple of the kernel's tile)
   *chunk = (int)per;
   *n_chunks = (int)(((long long)m->N + per - 1) / per);
 }
@@ -520,6 +521,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   }
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
+  m->chunk_px_override = env_int("GIGALENS_HIP_CHUNK_PX", 0);
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }

@@ -213,8 +213,11 @@ GL_HD void ellip_chain(R theta_E, R e1, R e2, R cmax, R g_b, R g_q, R g_phi, R& 
 // Omega = sum_n c_n e^{i(2n+1)theta} with per-sample coefficients c_n = prod p_k; the table below
 // holds c_n, (2n+1) c_n, dc_n/df and dc_n/dt so that one rotation per term yields Omega and its
 // derivatives w.r.t. theta, f and t together (forward mode inside the loop, no per-pixel tape).
-// Trip count: n < log(1e-12)/log(f) + 2, capped at niter (epl.py:37,47-54), evaluated per sample
-// (the reference takes max f over the batch; the extra terms it sums are < 1e-12 relative).
+// Trip count: n < log(tol)/log(f) + 2, capped at niter (epl.py:37,47-54), evaluated per sample (the reference takes max f
+// over the batch).  tol is the reference's 1e-12 in float64; the float32 kernels stop at 1e-9: |c_n| <= f^n, so the terms
+// left out sum to < 1e-9 f^2 / (1 - f) of an O(1) value -- under 0.02 ulp of a float32 sum, which the reference's own
+// float32 accumulation cannot register either -- and the f-derivative's tail (K + 1) f^K / (1 - f)^2 stays under 1 ulp.
+template <class R> GL_HD constexpr double epl_series_tol() { return sizeof(R) == 4 ? 1e-9 : 1e-12; }
 // scalars of the derived block (d[0..EPL_TAB)); returns the series length K and hands out f and 2 - t for the table
 template <class R> GL_HD int epl_prep_head(const R* p, int cap, R* d, R& f_out, R& two_mt_out) {
   R theta_E = p[0], gamma = p[1], e1 = p[2], e2 = p[3];
@@ -234,7 +237,7 @@ template <class R> GL_HD int epl_prep_head(const R* p, int cap, R* d, R& f_out, 
   d[EPL_INVB] = (R)1 / b;
   d[10] = (R)0;
   d[EPL_F2] = (R)2 * f;
-  R niter = p_log((R)1e-12) / p_log(f) + (R)2;
+  R niter = p_log((R)epl_series_tol<R>()) / p_log(f) + (R)2;
   // terms n = 1..K with n < niter (epl.py:47-54), K <= cap:  K = ceil(niter) - 1
   int K = 0;
   if (niter > (R)1) K = (int)fmin_(-floor_(-niter) - (R)1, (R)cap);
