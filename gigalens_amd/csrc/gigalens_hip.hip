@@ -141,6 +141,7 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.partial = w.partial;
   a.shp_tab = m->d_shp_tab;
   a.nfw_tab = m->d_nfw_tab;
+  a.dbg = m->dbg_flags;
   a.shp_stride = m->shp_stride;
   a.parts = 7u;
   a.cats = m->d_cats;
@@ -235,7 +236,7 @@ int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, co
 int run_order(const gl_model* m, int B, const Workspace& w, MainArgs* a, hipStream_t stream) {
   a->order = nullptr;
   if (!m->has_epl || !m->use_order || B < 2) return GL_OK;
-  hipLaunchKernelGGL(gl_order_kernel, dim3(1), dim3(256), 0, stream, m->d_comps, m->n_lens, w.derived, m->D, B,
+  hipLaunchKernelGGL(gl_order_kernel, dim3(1), dim3(ORDER_WG), 0, stream, m->d_comps, m->n_lens, w.derived, m->D, B,
                      w.order, m->epl_comp >= 0 ? w.cost : nullptr);
   GL_HIP(hipGetLastError());
   a->order = w.order;
@@ -522,6 +523,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
   m->chunk_px_override = env_int("GIGALENS_HIP_CHUNK_PX", 0);
+  m->dbg_flags = env_int("GIGALENS_HIP_DBGFLAGS", 0);
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }

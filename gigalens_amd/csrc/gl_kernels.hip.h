@@ -101,6 +101,7 @@ struct MainArgs {
   int n_lin;         // IMG_BASIS: channels of the stack  img[B][n_lin][img_stride]
   const SeriesDev* series;
   const float* nfw_tab;  // models with NFW lenses: the shared h(X) table (gl_host_tables.h), [kNfwNodes][2]; else null
+  int dbg;  // experiments (GIGALENS_HIP_DBGFLAGS): 1 skip the pixel tiles, 2 skip the epilogue reductions, 4 skip the constant staging
 };
 
 // ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
@@ -411,12 +412,16 @@ __global__ void __launch_bounds__(128) gl_galprep_kernel(const CompDesc* __restr
 
 // cost-ordered dispatch: samples sorted by descending EPL trip count (the only data-dependent cost on the
 // path), so the heaviest workgroups start first and the tail of the launch is filled with light ones.
-__global__ void __launch_bounds__(256) gl_order_kernel(const CompDesc* __restrict__ comps, int n_lens,
-                                                       const float* __restrict__ derived, int D, int B,
-                                                       int* __restrict__ order, const int* __restrict__ cost_in) {
+constexpr int ORDER_WG = 1024;
+__global__ void __launch_bounds__(ORDER_WG) gl_order_kernel(const CompDesc* __restrict__ comps, int n_lens,
+                                                            const float* __restrict__ derived, int D, int B,
+                                                            int* __restrict__ order, const int* __restrict__ cost_in) {
+  // counting sort on the cost (<= 255), three barriers in all: LDS histogram, one wavefront's scan over the 256 bins in
+  // descending order (four bins per lane + a shuffle scan), scatter through the bins' running offsets
   __shared__ int hist[256];
   __shared__ int offs[256];
-  hist[threadIdx.x] = 0;
+  const int tid = threadIdx.x;
+  if (tid < 256) hist[tid] = 0;
   __syncthreads();
   auto cost = [&](int b) {
     if (cost_in) return min(cost_in[b], 255);
@@ -425,24 +430,29 @@ __global__ void __launch_bounds__(256) gl_order_kernel(const CompDesc* __restric
       if (comps[l].kind == K_EPL) k += reinterpret_cast<const int*>(derived + (size_t)b * D + comps[l].d_off)[EPL_KI];
     return min(k, 255);
   };
-  for (int b = threadIdx.x; b < B; b += 256) atomicAdd(&hist[cost(b)], 1);
+  const int c0 = tid < B ? cost(tid) : 0;  // the first sample of a thread stays in a register (B <= 1024: the only one)
+  if (tid < B) atomicAdd(&hist[c0], 1);
+  for (int b = tid + ORDER_WG; b < B; b += ORDER_WG) atomicAdd(&hist[cost(b)], 1);
   __syncthreads();
-  {  // exclusive prefix over DESCENDING cost = inclusive suffix sum of the bins above: log-step scan in LDS
-    int v = hist[threadIdx.x];
-    offs[threadIdx.x] = v;
-    __syncthreads();
-    for (int step = 1; step < 256; step <<= 1) {
-      const int add = (threadIdx.x + step < 256) ? offs[threadIdx.x + step] : 0;
-      __syncthreads();
-      offs[threadIdx.x] += add;
-      __syncthreads();
+  if (tid < 64) {
+    const int top = 255 - 4 * tid;  // this lane's bins, heaviest first: top, top - 1, top - 2, top - 3
+    const int h0 = hist[top], h1 = hist[top - 1], h2 = hist[top - 2], h3 = hist[top - 3];
+    const int sum = h0 + h1 + h2 + h3;
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (tid >= d) incl += t;
     }
-    const int incl = offs[threadIdx.x];  // sum of bins >= own
-    __syncthreads();
-    offs[threadIdx.x] = incl - v;        // bins strictly above
+    const int excl = incl - sum;  // samples in strictly heavier bins of other lanes
+    offs[top] = excl;
+    offs[top - 1] = excl + h0;
+    offs[top - 2] = excl + h0 + h1;
+    offs[top - 3] = excl + h0 + h1 + h2;
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < B; b += 256) order[atomicAdd(&offs[cost(b)], 1)] = b;
+  if (tid < B) order[atomicAdd(&offs[c0], 1)] = tid;
+  for (int b = tid + ORDER_WG; b < B; b += ORDER_WG) order[atomicAdd(&offs[cost(b)], 1)] = b;
 }
 
 #endif  // GL_AUX_KERNELS

@@ -40,6 +40,7 @@ struct gl_model {
   float* d_shp_tab = nullptr;
   float* d_nfw_tab = nullptr;  // models with NFW lenses: h(X) = g(X) / X^2 on the float format's own grid (gl_host_tables.h)
   int chunk_px_override = 0;
+  int dbg_flags = 0;
   bool has_nfw = false;
   size_t nfw_lds = 0;          // bytes of that table in a main kernel's LDS
   int shp_stride = 0;
