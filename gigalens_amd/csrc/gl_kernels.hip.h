@@ -264,6 +264,13 @@ __device__ __forceinline__ ZEval z_eval(const ZCol& c, float z) {
   return o;
 }
 
+// the constrained value alone (the front end needs nothing else of z_eval)
+__device__ __forceinline__ float z_eval_x(const ZCol& c, float z) {
+  if (c.bijector == 0) return z;
+  if (c.bijector == 1) return expf(z);
+  return c.lo + (c.hi - c.lo) * (1.f / (1.f + expf(-z)));
+}
+
 // z [B,d] -> packed constrained rows [B,P] (also kept for finalize) -> derived constants
 __global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restrict__ comps, int n_comp,
                                                        const float* __restrict__ z, int d_z,
@@ -352,19 +359,21 @@ __global__ void __launch_bounds__(256) gl_prep_wave_kernel(const CompDesc* __res
   if (b >= B) return;  // whole wavefronts leave together
   float f = 0.f, two_mt = 0.f;
   int K = 0;
+  if (!params_in) {
+    // z -> constrained row, one COLUMN per lane: the bijectors of a sample's columns are independent, so their loads
+    // (column descriptor, z) and transcendentals overlap instead of forming one lane's chain of n_par dependent round trips
+    float* po = params_out + (size_t)b * P;
+    for (int k = lane; k < d_z; k += 64) {
+      const ZCol zc = zcols[k];
+      po[zc.param_col] = z_eval_x(zc, z[(size_t)b * d_z + k]);
+    }
+    for (int col = lane; col < P; col += 64)
+      if (src[col] < 0) po[col] = const_row[col];
+    __threadfence_block();  // the component lanes below read the row back (same wavefront, same L1)
+  }
   if (lane < n_comp) {
     const CompDesc cd = comps[lane];
-    const float* p;
-    if (params_in) {
-      p = params_in + (size_t)b * P + cd.p_off;
-    } else {
-      float* po = params_out + (size_t)b * P + cd.p_off;
-      for (int j = 0; j < cd.n_par; ++j) {
-        const int col = cd.p_off + j, k = src[col];
-        po[j] = (k >= 0) ? z_eval(zcols[k], z[(size_t)b * d_z + k]).x : const_row[col];
-      }
-      p = po;
-    }
+    const float* p = (params_in ? params_in : params_out) + (size_t)b * P + cd.p_off;
     float* d = derived + (size_t)b * D + cd.d_off;
     switch (cd.kind) {
       case K_EPL: K = epl_prep_head<float>(p, cd.iparam, d, f, two_mt); break;
@@ -1060,7 +1069,11 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
   const int A = f.A, P = f.P, d_z = f.d_z;
   float* s_g = s + ((A + 3) & ~3);
   float* s_t = s_g + ((P + 3) & ~3);
+  float* s_e = s_t + ((d_z + 3) & ~3);  // [3][d_z]: dlogp/dx, dx/dz, dfldj/dz of every column
   const float* src = partial + (size_t)b * n_chunks * A;
+  // Phase 0 -- three independent jobs on three groups of threads, so their global round trips and transcendentals overlap
+  // instead of queueing behind two barriers: (a) sum the chunk partials, (b) bijector / prior terms of z (they do not depend
+  // on the accumulators), (c) fetch the component descriptors
   for (int k = tid; k < A; k += NT) {
     float v = 0.f;
     if (f.use_partial)
@@ -1068,11 +1081,24 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
     if (f.extra_stats && k < 2) v += f.extra_stats[2 * b + k];  // chi2 / normalisation of a materialised image (PSF path)
     s[k] = v;
   }
-  __syncthreads();
+  constexpr int ZT0 = NT / 2;  // the upper half of the workgroup serves the columns of z
+  if (f.zcols && tid >= ZT0) {
+    for (int k = tid - ZT0; k < d_z; k += NT - ZT0) {
+      const ZCol c = f.zcols[k];
+      const ZEval e = z_eval(c, f.z[(size_t)b * d_z + k]);
+      s_t[k] = e.logp_plus_fldj;
+      s_e[k] = e.dlogp_dx;
+      s_e[d_z + k] = e.dxdz;
+      s_e[2 * d_z + k] = e.dfldj_dz;
+    }
+  }
   const bool want_grad = f.grad != nullptr || f.grad_z != nullptr;
+  CompDesc cd{};
+  if (want_grad && tid < f.n_comp) cd = comps[tid];
+  __syncthreads();
   if (want_grad) {
     for (int c = tid; c < f.n_comp; c += NT) {
-      CompDesc cd = comps[c];
+      if (c != tid) cd = comps[c];
       const float* p = f.params + (size_t)b * P + cd.p_off;
       float* g = s_g + cd.p_off;
       const float* acc = s + cd.a_off;
@@ -1104,15 +1130,9 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
     }
     if (f.grad)
       for (int k = tid; k < P; k += NT) f.grad[(size_t)b * P + k] = s_g[k];
-  }
-  if (f.zcols) {
-    for (int k = tid; k < d_z; k += NT) {
-      ZCol c = f.zcols[k];
-      ZEval e = z_eval(c, f.z[(size_t)b * d_z + k]);
-      s_t[k] = e.logp_plus_fldj;
-      if (f.grad_z) f.grad_z[(size_t)b * d_z + k] = (s_g[c.param_col] + e.dlogp_dx) * e.dxdz + e.dfldj_dz;
-    }
-    __syncthreads();
+    if (f.zcols && f.grad_z && tid >= ZT0)
+      for (int k = tid - ZT0; k < d_z; k += NT - ZT0)
+        f.grad_z[(size_t)b * d_z + k] = (s_g[f.zcols[k].param_col] + s_e[k]) * s_e[d_z + k] + s_e[2 * d_z + k];
   }
   if (tid == 0 && f.loglike) {
     float ll = -0.5f * (s[0] + s[1]);  // tf/model.py:99
@@ -1133,7 +1153,7 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
 
 __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __restrict__ comps, FinArgs f,
                                                           const float* __restrict__ partial, int n_chunks) {
-  extern __shared__ float s[];  // [A] accumulators, then [P] parameter gradients, then [d_z] prior terms
+  extern __shared__ float s[];  // [A] accumulators, [P] parameter gradients, [d_z] prior terms, [3][d_z] bijector / prior derivatives
   finalize_sample<128>(comps, f, partial, n_chunks, blockIdx.x, threadIdx.x, s);
 }
 
