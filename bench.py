@@ -291,8 +291,11 @@ def main():
             lp_, _, g_ = pm.log_prob_and_grad(sim, zz)
             return lp_, g_
 
+        pool = ginf.NormalPool(gen, B, d, device=dev)  # the driver's own draw schedule (ModellingSequence.SVI)
+
         def step():
-            buf = ginf.svi_step_buffer(sv_params[:d], sv_params[d:], None, B, gen, value_and_grad_fn=vg, full_rank=True)
+            buf = ginf.svi_step_buffer(sv_params[:d], sv_params[d:], None, B, gen, value_and_grad_fn=vg, full_rank=True,
+                                       eps=pool.next())
             opt.step(sv_params, buf[1:])
             return buf
     else:
