@@ -496,6 +496,16 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   m->static_id = env_int("GIGALENS_HIP_STATIC", 1) ? match_static(m) : 0;
   m->static_variant = env_int("GIGALENS_HIP_STATIC_VARIANT", 0);
   m->pair = env_int("GIGALENS_HIP_PAIR", 1);
+  if (m->pair && m->static_id) {
+    // the pair kernels' epilogue addresses the accumulator row in closed form: [NSTAT | components in order, static_nacc each]
+    int off = NSTAT;
+    bool ok_row = true;
+    for (int i = 0; i < n_comp; ++i) {
+      ok_row = ok_row && m->comps[i].a_off == off;
+      off += static_nacc(m->comps[i].kind);
+    }
+    if (!ok_row || off != m->A) m->pair = 0;
+  }
   m->light_spherical = n_comp > n_lens;
   for (int i = n_lens; i < n_comp; ++i) m->light_spherical = m->light_spherical && m->comps[i].kind == K_SERSIC;
   if (!m->tile_grad) m->tile_grad = m->static_id ? 1 : 2;  // measured: T=1 wins once the VJP state lives in registers

@@ -134,20 +134,6 @@ __device__ __forceinline__ void sersic_vjp_c(const float* __restrict__ d, V x, V
   gpy += gdy;
 }
 
-// 4 x 4 transpose-reduction inside a quad: lane q of every quad receives  sum over the quad's lanes of v_q.
-// Step 1 exchanges with lane ^ 1 (even lanes keep v0 / v2, odd lanes v1 / v3), step 2 with lane ^ 2.
-__device__ __forceinline__ float dpp_xor1(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm:[1,0,3,2]
-}
-__device__ __forceinline__ float dpp_xor2(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
-}
-__device__ __forceinline__ float quad_transpose_sum(float v0, float v1, float v2, float v3, bool odd, bool hi) {
-  const float r01 = (odd ? v1 : v0) + dpp_xor1(odd ? v0 : v1);
-  const float r23 = (odd ? v3 : v2) + dpp_xor1(odd ? v2 : v3);
-  return (hi ? r23 : r01) + dpp_xor2(hi ? r01 : r23);
-}
-
 // accumulator slot (inside the sample's accumulator row) of lane q of running sum g -- the inverse of the packing in the loop
 template <int NH, bool ELL> __device__ __forceinline__ int cluster_slot(int g, int q, int n_h, int n_s) {
   if (g < NH) return g < n_h ? NSTAT + NFW_NACC * g + q : -1;

@@ -139,6 +139,20 @@ __device__ __forceinline__ float quad_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
   return v;
 }
+// 4 x 4 transpose-reduction inside a quad: lane q of every quad receives  sum over the quad's lanes of v_q.
+// Step 1 exchanges with lane ^ 1 (even lanes keep v0 / v2, odd lanes v1 / v3), step 2 with lane ^ 2.
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
+}
+__device__ __forceinline__ float quad_transpose_sum(float v0, float v1, float v2, float v3, bool odd, bool hi) {
+  const float r01 = (odd ? v1 : v0) + dpp_xor1(odd ? v0 : v1);
+  const float r23 = (odd ? v3 : v2) + dpp_xor1(odd ? v2 : v3);
+  return (hi ? r23 : r01) + dpp_xor2(hi ? r01 : r23);
+}
+
 __device__ __forceinline__ float row_sum15(float v) {  // lane 15 of each 16-lane row holds the row sum
   v = dpp_add(v, 0x111, 0xF);
   v = dpp_add(v, 0x112, 0xF);

@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
     for (; base < p1; base += WG * W) tile(base, std::true_type{});
   }
   if (MODE == IMG_FWD) return;
+  float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
   // ---- epilogue: per-sample scale factors deferred out of the pixel loop, lane sum, one reduction ----
   // accumulators live in registers for the whole chunk, so ONE full wave64 reduction per value per workgroup
   // is cheap: lane 63 of each wave stores its sums into the wave's own LDS row (no zero-fill, no read-modify-write)
@@ -188,16 +189,17 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
     for (int i = tid; i < 4 * a.Apad; i += WG) s_acc[i] = 0.f;
     __syncthreads();
   }
-  float* s_row = s_acc + (tid >> 6) * a.Apad;
-  const bool last_lane = (tid & 63) == 63;
-  auto put = [&](float v, int idx) {
-    if (!(a.dbg & 2)) v = wave_sum63(v);
-    if (last_lane) s_row[idx] = v;
-  };
-  put((MODE == LL_FWD || MODE == LL_GRAD) ? hsum(st0) : 0.f, 0);
-  put((MODE == LL_FWD || MODE == LL_GRAD) ? hsum(st1) : 0.f, 1);
-  if (last_lane) { s_row[2] = 0.f; s_row[3] = 0.f; }
   if constexpr (GRAD) {
+    // Gradient modes: the whole accumulator row [chi2, norm, 0, 0 | lenses | lights] is reduced FOUR values per register
+    // (the cluster kernel's 4 x 4 transpose inside every quad, then two row shifts): lane 12 + q of each 16-lane row holds
+    // the row's sum of value 4 g + q -- 11 instead of 28 cross-lane adds per four values -- and the 16 rows of the workgroup
+    // are summed in fixed order below.  Offsets inside the row are the layout gl_model_create assigns (host-checked).
+    constexpr int NV = NSTAT + NACC_L + NACC_C, NVP = (NV + 3) & ~3;
+    float vals[NVP];
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) vals[k] = 0.f;
+    vals[0] = (MODE == LL_GRAD) ? hsum(st0) : 0.f;
+    vals[1] = (MODE == LL_GRAD) ? hsum(st1) : 0.f;
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int kind = LK::kinds[i];
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
         tmp[EPLA_CY] = -(gxr * ss + gyr * cc);
       }
 #pragma unroll
-      for (int k = 0; k < G; ++k) put(tmp[k], comps[i].a_off + k);
+      for (int k = 0; k < G; ++k) vals[NSTAT + off + k] = tmp[k];
     }, std::make_integer_sequence<int, NL>{});
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
@@ -225,17 +227,37 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
         for (int j = 0; j < i; ++j) n += static_nacc(j < NLL ? LLK::kinds[j < NLL ? j : 0] : SK::kinds[j >= NLL ? j - NLL : 0]);
         return n;
       }();
-      constexpr int G = SER_NACC;
-      float tmp[G];
 #pragma unroll
-      for (int k = 0; k < G; ++k) tmp[k] = hsum(accC[off + k]);
-      tmp[SERA_INVN] *= (float)kLn2;
-#pragma unroll
-      for (int k = 0; k < G; ++k) put(tmp[k], comps[NL + i].a_off + k);
+      for (int k = 0; k < SER_NACC; ++k) vals[NSTAT + NACC_L + off + k] = hsum(accC[off + k]) * (k == SERA_INVN ? (float)kLn2 : 1.f);
     }, std::make_integer_sequence<int, NLIGHT>{});
+    const bool odd = tid & 1, hi = tid & 2;
+    float* s_row16 = s_acc + (tid >> 4) * a.Apad;  // [16 rows of the workgroup][Apad]
+#pragma unroll
+    for (int g = 0; g < NVP / 4; ++g) {
+      float r = quad_transpose_sum(vals[4 * g], vals[4 * g + 1], vals[4 * g + 2], vals[4 * g + 3], odd, hi);
+      r = dpp_add(r, 0x114, 0xF);  // row_shr:4
+      r = dpp_add(r, 0x118, 0xF);  // row_shr:8 -> lanes 12..15 of the row: the row's sums of values 4g .. 4g + 3
+      if ((tid & 15) >= 12 && 4 * g + (tid & 3) < NV) s_row16[4 * g + (tid & 3)] = r;
+    }
+    __syncthreads();
+    for (int k = tid; k < NV; k += WG) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v += s_acc[j * a.Apad + k];
+      out[k] = v;
+    }
+    return;
   }
+  float* s_row = s_acc + (tid >> 6) * a.Apad;
+  const bool last_lane = (tid & 63) == 63;
+  auto put = [&](float v, int idx) {
+    if (!(a.dbg & 2)) v = wave_sum63(v);
+    if (last_lane) s_row[idx] = v;
+  };
+  put((MODE == LL_FWD || MODE == LL_GRAD) ? hsum(st0) : 0.f, 0);
+  put((MODE == LL_FWD || MODE == LL_GRAD) ? hsum(st1) : 0.f, 1);
+  if (last_lane) { s_row[2] = 0.f; s_row[3] = 0.f; }
   __syncthreads();
-  float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
   for (int k = tid; k < a.A; k += WG) {
     out[k] = (s_acc[k] + s_acc[a.Apad + k]) + (s_acc[2 * a.Apad + k] + s_acc[3 * a.Apad + k]);
   }
