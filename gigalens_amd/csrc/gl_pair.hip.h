@@ -31,7 +31,11 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   const CompDesc* __restrict__ comps = a.comps;
   const float* __restrict__ gder = a.derived + (size_t)b * a.D;
   if (!(a.dbg & 4)) {
-    for (int i = tid; i < a.D; i += WG) s_d[i] = gder[i];
+    if (a.D <= WG) {  // the usual case (EPL at niter = 50: D = 244): one predicated load per thread, no loop scaffolding
+      if (tid < a.D) s_d[tid] = gder[tid];
+    } else {
+      for (int i = tid; i < a.D; i += WG) s_d[i] = gder[i];
+    }
   }
   __syncthreads();
   constexpr int NACC_L = [] { int n = 0; for (int i = 0; i < NL; ++i) n += static_nacc(LK::kinds[i]); return n; }();
