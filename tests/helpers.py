@@ -44,3 +44,17 @@ def oracle_loglike_and_grad(wl, packed64, obs, err, bs, dtype=torch.float64):
 def relerr(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def oracle_loglike_chunked(wl, packed64, obs, err, n, step=16):
+    """Float64 oracle log-likelihood of the first ``n`` rows, forward only, ``step`` rows at a time (full-size pixel grids)."""
+    from oracle import ref_torch as ref
+    out = []
+    with torch.no_grad():
+        for i0 in range(0, n, step):
+            m = min(step, n - i0)
+            rs = ref.RefSimulator(wl.phys_model, wl.sim_config, m, dtype=torch.float64)
+            params = struct_from_packed(wl.phys_model, packed64[i0:i0 + m])
+            ll, _ = ref.stats_pixels(rs, params, obs, wl.background_rms, wl.exp_time, error_map=err)
+            out.append(ll.numpy())
+    return np.concatenate(out)

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-printf "X=0\nGIGALENS_HIP_CHUNK_PX=5632\nGIGALENS_HIP_CHUNK_PX=4096\n" > /tmp/sw.txt
-bash tools/dev/sweep_env.sh /tmp/sw.txt
+mkdir -p gpurun_out/r2l
+timeout -k 10 800 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "many_samples" > gpurun_out/r2l/pytest_many.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/r2l/pytest_many.log | cut -c1-300
