@@ -511,7 +511,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   if (!m->tile_grad) m->tile_grad = m->static_id ? 1 : 2;  // measured: T=1 wins once the VJP state lives in registers
   if (!m->static_id) {  // the interpreter kernel is built for T = 2 and 4
     const bool env_tile = env_int("GIGALENS_HIP_TILE", 0) != 0;
-    if (!env_tile && !m->has_epl && !m->has_shapelets && !m->fam) m->tile = m->tile_grad = 4;  // cheap profiles: amortise the per-tile accumulation
+    if (!env_tile && !m->has_epl && !m->has_shapelets && !m->fam) m->tile = 4;  // cheap profiles, forward modes: amortise the per-tile work
     if (m->tile == 1) m->tile = 2;
     if (m->tile_grad == 1) m->tile_grad = 2;
   }

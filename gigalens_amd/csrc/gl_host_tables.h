@@ -9,7 +9,7 @@ constexpr int kShapeletNodes = 6000;
 inline void build_shapelet_table(int n_max, std::vector<float>& tab, int* stride) {
   // shapelets.py:39-40,50-51: phi_n(linspace(-5,5,6000)) in f64 stored as f32; node-major layout.
   const int st = (n_max + 1 + 3) & ~3;
-  tab.assign((size_t)kShapeletNodes * st, 0.f);
+  tab.assign((size_t)(kShapeletNodes + 2) * st, 0.f);  // + two zero rows: where coordinates outside [-5, 5] are sent (fill 0, shapelets.py:58-60)
   for (int i = 0; i < kShapeletNodes; ++i) {
     double x = -5.0 + 10.0 * (double)i / (double)(kShapeletNodes - 1);
     double hm2 = 0.0, hm1 = 0.75112554446494248286 * exp(-0.5 * x * x);  // n = 0

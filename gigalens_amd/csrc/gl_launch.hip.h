@@ -39,9 +39,7 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     constexpr int W1 = G ? 3 : 4, W2 = G ? 2 : 4;
     if (m->light_spherical) {
       switch (m->static_id) {
-        case ST_EPLSHEAR_SERSIC:
-          if (m->pair == 4) GL_PAIR(4, L_EplShear, C_None, C_Sersic); else GL_PAIR(W1, L_EplShear, C_None, C_Sersic);  // GIGALENS_HIP_PAIR=4: the 4-waves-per-SIMD budget (experiment)
-          return true;
+        case ST_EPLSHEAR_SERSIC: GL_PAIR(W1, L_EplShear, C_None, C_Sersic); return true;  // (a 4-waves-per-SIMD budget spills 22 VGPRs: 98 vs 92 us)
         case ST_EPLSHEAR_SERSIC_SERSIC: GL_PAIR(W2, L_EplShear, C_Sersic, C_Sersic); return true;
         case ST_SIE_SERSIC: GL_PAIR(W1, L_Sie, C_None, C_Sersic); return true;  // gradient mode: 4 VGPRs would spill at 4 waves
         case ST_SIESHEAR_SERSIC_SERSIC: GL_PAIR(W1, L_SieShear, C_Sersic, C_Sersic); return true;
@@ -128,9 +126,16 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
   } else if (m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
     // specialised kernel launched
   } else {
-    const int Tg = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
-    if (m->has_shapelets) { if (Tg == 4) GL_MAIN_FAM(4, true); else GL_MAIN_FAM(2, true); }
-    else { if (Tg == 4) GL_MAIN_FAM(4, false); else GL_MAIN_FAM(2, false); }
+    // four pixels per thread only in the forward modes: the gradient instantiations at T = 4 spill (94 VGPRs on the plain
+    // families) and measure no faster than T = 2 (C4 through the interpreter: 2.41 ms either way)
+    constexpr bool GRADM = (MODE == IMG_BWD || MODE == LL_GRAD);
+    const int Tg = GRADM ? 2 : m->tile;
+    if constexpr (GRADM) {
+      if (m->has_shapelets) GL_MAIN_FAM(2, true); else GL_MAIN_FAM(2, false);
+    } else {
+      if (m->has_shapelets) { if (Tg == 4) GL_MAIN_FAM(4, true); else GL_MAIN_FAM(2, true); }
+      else { if (Tg == 4) GL_MAIN_FAM(4, false); else GL_MAIN_FAM(2, false); }
+    }
   }
 #undef GL_MAIN_FAM
 #undef GL_MAIN

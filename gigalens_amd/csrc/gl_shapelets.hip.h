@@ -22,6 +22,7 @@ using namespace glp;
 template <int CAP> struct ShpState {
   float X[CAP + 1], Y[CAP + 1], dX[CAP + 1], dY[CAP + 1], t[CAP + 1];
   float fac, u, v, dx, dy, S;
+  float ds;  // table mode: dX / dY hold node differences, the derivative is ds times them
 };
 
 // linear interpolation on the 6000-node table (tfp.math.interp_regular_1d_grid, fill 0 outside, shapelets.py:58-60);
@@ -37,7 +38,8 @@ __device__ __forceinline__ void shp_table_basis(const float* __restrict__ tab, f
   const float fa = fmin_(fb + 1.f, (float)(SH_NODES - 1));
   fb = fmax_(fa - 1.f, 0.f);
   const float tt = fic - fb;
-  const float4* __restrict__ r = reinterpret_cast<const float4*>(tab + (size_t)(int)fb * 12);
+  // outside the table: the two zero rows appended to it (value and slope 0 without a select per order)
+  const float4* __restrict__ r = reinterpret_cast<const float4*>(tab + (size_t)(inside ? (int)fb : SH_NODES) * 12);
   float lo[12], hi[12];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
@@ -46,9 +48,10 @@ __device__ __forceinline__ void shp_table_basis(const float* __restrict__ tab, f
     hi[4 * q] = b.x; hi[4 * q + 1] = b.y; hi[4 * q + 2] = b.z; hi[4 * q + 3] = b.w;
   }
 #pragma unroll
-  for (int n = 0; n <= CAP; ++n) {
-    Xv[n] = inside ? tt * hi[n] + (1.f - tt) * lo[n] : 0.f;
-    dXv[n] = inside ? (hi[n] - lo[n]) * scale : 0.f;
+  for (int n = 0; n <= CAP; ++n) {  // three instructions per order: the node difference serves the value and the slope
+    const float dn = hi[n] - lo[n];
+    Xv[n] = fmaf(tt, dn, lo[n]);
+    dXv[n] = dn;  // x (nodes per unit) once, on the contracted derivative (ShpState::ds)
   }
 }
 
@@ -65,6 +68,7 @@ __device__ __forceinline__ float shp_fwd_state(const float* d, const float* __re
   st.u = st.dx * ib;
   st.v = st.dy * ib;
   st.fac = 1.f;
+  st.ds = interp ? (float)(SH_NODES - 1) / 10.f : 1.f;
   if (interp) {
     shp_table_basis<CAP>(tab, st.u, st.X, st.dX);
     shp_table_basis<CAP>(tab, st.v, st.Y, st.dY);
@@ -109,7 +113,7 @@ __device__ __forceinline__ void shp_vjp_state(const float* d, const float* __res
     for (int n2 = 0; n2 <= CAP - n1; ++n2)
       acc[SHPA_AMP + shp_idx(n1, n2)] = fmaf(gx, st.Y[n2], acc[SHPA_AMP + shp_idx(n1, n2)]);
   }
-  float gu = gS * Su, gv = gS * Sv;
+  float gu = gS * (Su * st.ds), gv = gS * (Sv * st.ds);
   if (!interp) {  // d fac/du = -u fac
     const float gIf = gI * (st.fac * st.S);
     gu -= gIf * st.u;

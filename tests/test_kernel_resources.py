@@ -45,3 +45,22 @@ def test_dispatched_instantiations_do_not_spill(metadata, config):
             import isa_flops as isa
             ins = isa.disassemble(md["co"], md["symbol"])
             assert not [i for i in ins if i[1].startswith("scratch_")], (hits[0], md["scratch_bytes"])
+
+
+# Instantiations that are allowed to spill, and why none of them is on a default dispatch path of a BASELINE config
+# (everything else in the library must compile without VGPR spills):
+ALLOWED_SPILLS = [
+    (r"gl_main_kernel<\d, \d, (true|false), 2>", "FAM 2: the profile families beyond SURVEY section 8 (NFW_ELLIPSE, TNFW with its float64 core, CoreSersic)"),
+    (r"gl_main_kernel<[13], 2, true, [01]>", "shapelets through the interpreter, gradient modes (models outside the specialised compositions)"),
+    (r"gl_static_kernel<[13], [24], ", "pre-pair tile variants of the specialised kernels in gradient modes: reached only with GIGALENS_HIP_PAIR=0 / GIGALENS_HIP_TILE*"),
+    (r"gl_series_hessian_precompute_kernel<", "one-off float64 jet precompute of the Hessian series (not on the per-step path)"),
+]
+
+
+def test_no_unexpected_spills(metadata):
+    import re
+    bad = []
+    for name, md in metadata.items():
+        if md["vgpr_spill_count"] and not any(re.search(p, name) for p, _ in ALLOWED_SPILLS):
+            bad.append((name[:120], md["vgpr_spill_count"]))
+    assert not bad, bad
