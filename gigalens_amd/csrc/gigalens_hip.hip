@@ -224,10 +224,15 @@ int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, co
                  float* chi2, float* grad, hipStream_t stream, const float* z = nullptr, float* logprob = nullptr,
                  float* grad_z = nullptr, float chi2_scale = 1.f, const float* extra_stats = nullptr,
                  int use_partial = 1, bool with_positions = false, float pos_chi2_scale = 0.f) {
-  size_t shmem = (size_t)(((m->A + 3) & ~3) + ((m->P + 3) & ~3) + ((m->d_z + 3) & ~3) + 3 * m->d_z + 4) * sizeof(float);
+  size_t shmem = (size_t)(((m->A + 3) & ~3) + ((m->P + 3) & ~3) + ((m->d_z + 3) & ~3) + 4 * m->d_z + 4) * sizeof(float);
   FinArgs f = fin_args(m, params, w, loglike, chi2, grad, z, logprob, grad_z, chi2_scale, extra_stats, use_partial,
                        with_positions, pos_chi2_scale);
-  hipLaunchKernelGGL(gl_finalize_kernel, dim3(B), dim3(128), shmem, stream, m->d_comps, f, w.partial, n_chunks);
+  bool basic = true;
+  for (const CompDesc& c : m->comps)
+    basic = basic && (c.kind == K_EPL || c.kind == K_SIE || c.kind == K_SHEAR || c.kind == K_SIS || c.kind == K_SERSIC || c.kind == K_SERSIC_ELLIPSE);
+  const int nc = (m->dbg_flags & 8) ? -1 : n_chunks;
+  if (basic) hipLaunchKernelGGL(gl_finalize_kernel<true>, dim3(B), dim3(128), shmem, stream, m->d_comps, f, w.partial, nc);
+  else hipLaunchKernelGGL(gl_finalize_kernel<false>, dim3(B), dim3(128), shmem, stream, m->d_comps, f, w.partial, nc);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

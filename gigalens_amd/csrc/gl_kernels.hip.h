@@ -1076,14 +1076,16 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
 // + log|J| is added:  log_prob = loglike + sum_k [log p_k(x_k) + fldj_k(z_k)]   (tf/model.py:164-167).
 
 // one sample, executed by NT threads of one workgroup; `s`: LDS scratch of A + P + d_z (+12) floats
-template <int NT>
+// BASIC: only EPL / SIE / Shear / SIS / Sersic in the model -- the other families' chain rules (TNFW's float64 core, shapelets,
+// dPIE, ...) stay out of the kernel: a third of the code, and the finalize launch is instruction-fetch bound
+template <int NT, bool BASIC = false>
 __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ comps, const FinArgs& f,
                                                 const float* __restrict__ partial, int n_chunks, int b, int tid,
                                                 float* s) {
   const int A = f.A, P = f.P, d_z = f.d_z;
   float* s_g = s + ((A + 3) & ~3);
   float* s_t = s_g + ((P + 3) & ~3);
-  float* s_e = s_t + ((d_z + 3) & ~3);  // [3][d_z]: dlogp/dx, dx/dz, dfldj/dz of every column
+  float* s_e = s_t + ((d_z + 3) & ~3);  // [4][d_z]: dlogp/dx, dx/dz, dfldj/dz, parameter column of every column of z
   const float* src = partial + (size_t)b * n_chunks * A;
   // Phase 0 -- three independent jobs on three groups of threads, so their global round trips and transcendentals overlap
   // instead of queueing behind two barriers: (a) sum the chunk partials, (b) bijector / prior terms of z (they do not depend
@@ -1104,37 +1106,47 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
       s_e[k] = e.dlogp_dx;
       s_e[d_z + k] = e.dxdz;
       s_e[2 * d_z + k] = e.dfldj_dz;
+      s_e[3 * d_z + k] = __int_as_float(c.param_col);
     }
   }
   const bool want_grad = f.grad != nullptr || f.grad_z != nullptr;
   CompDesc cd{};
-  if (want_grad && tid < f.n_comp) cd = comps[tid];
+  constexpr int NPRE = 8;  // a component's parameters are fetched before the barrier too (every kind but shapelets fits)
+  float pre[NPRE];
+  if (want_grad && tid < f.n_comp) {
+    cd = comps[tid];
+    const float* pp = f.params + (size_t)b * P + cd.p_off;
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) pre[j] = j < cd.n_par ? pp[j] : 0.f;
+  }
   __syncthreads();
   if (want_grad) {
     for (int c = tid; c < f.n_comp; c += NT) {
       if (c != tid) cd = comps[c];
-      const float* p = f.params + (size_t)b * P + cd.p_off;
+      const float* p = (c == tid && cd.n_par <= NPRE) ? pre : f.params + (size_t)b * P + cd.p_off;
       float* g = s_g + cd.p_off;
       const float* acc = s + cd.a_off;
       switch (cd.kind) {
         case K_EPL: epl_finalize<float>(p, acc, g); break;
         case K_SIE: sie_finalize<float>(p, acc, g); break;
-        case K_NFW: nfw_finalize<float>(p, acc, g); break;
+        case K_NFW: if constexpr (!BASIC) nfw_finalize<float>(p, acc, g); break;
         case K_SHEAR: shear_finalize<float>(p, acc, g); break;
         case K_SIS: sis_finalize<float>(p, acc, g); break;
-        case K_DPIS: case K_DPIE: case K_DPIEP: dpie_finalize<float>(cd.kind, p, acc, g); break;
-        case K_SCALED: {
-          const CatDev cat = f.cats[cd.iparam];
-          for (int k = 0; k < 3; ++k)
-            if (cat.col[k] >= 0) g[cat.col[k]] = acc[k];
-        } break;
-        case K_SERIES: g[0] = acc[0]; g[1] = acc[1]; break;
-        case K_NFW_ELLIPSE: nfw_ell_finalize<float>(p, acc, g); break;
-        case K_TNFW: tnfw_finalize<float>(p, acc, g); break;
-        case K_CORE_SERSIC: core_sersic_finalize<float>(p, acc, g); break;
+        case K_DPIS: case K_DPIE: case K_DPIEP: if constexpr (!BASIC) dpie_finalize<float>(cd.kind, p, acc, g); break;
+        case K_SCALED:
+          if constexpr (!BASIC) {
+            const CatDev cat = f.cats[cd.iparam];
+            for (int k = 0; k < 3; ++k)
+              if (cat.col[k] >= 0) g[cat.col[k]] = acc[k];
+          }
+          break;
+        case K_SERIES: if constexpr (!BASIC) { g[0] = acc[0]; g[1] = acc[1]; } break;
+        case K_NFW_ELLIPSE: if constexpr (!BASIC) nfw_ell_finalize<float>(p, acc, g); break;
+        case K_TNFW: if constexpr (!BASIC) tnfw_finalize<float>(p, acc, g); break;
+        case K_CORE_SERSIC: if constexpr (!BASIC) core_sersic_finalize<float>(p, acc, g); break;
         case K_SERSIC: sersic_finalize<float>(p, false, acc, g); break;
         case K_SERSIC_ELLIPSE: sersic_finalize<float>(p, true, acc, g); break;
-        case K_SHAPELETS: shapelets_finalize<float>(p, cd.iparam, acc, g); break;
+        case K_SHAPELETS: if constexpr (!BASIC) shapelets_finalize<float>(p, cd.iparam, acc, g); break;
       }
     }
     __syncthreads();
@@ -1146,7 +1158,7 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
       for (int k = tid; k < P; k += NT) f.grad[(size_t)b * P + k] = s_g[k];
     if (f.zcols && f.grad_z && tid >= ZT0)
       for (int k = tid - ZT0; k < d_z; k += NT - ZT0)
-        f.grad_z[(size_t)b * d_z + k] = (s_g[f.zcols[k].param_col] + s_e[k]) * s_e[d_z + k] + s_e[2 * d_z + k];
+        f.grad_z[(size_t)b * d_z + k] = (s_g[__float_as_int(s_e[3 * d_z + k])] + s_e[k]) * s_e[d_z + k] + s_e[2 * d_z + k];
   }
   if (tid == 0 && f.loglike) {
     float ll = -0.5f * (s[0] + s[1]);  // tf/model.py:99
@@ -1165,10 +1177,12 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
   }
 }
 
+template <bool BASIC>
 __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __restrict__ comps, FinArgs f,
                                                           const float* __restrict__ partial, int n_chunks) {
   extern __shared__ float s[];  // [A] accumulators, [P] parameter gradients, [d_z] prior terms, [3][d_z] bijector / prior derivatives
-  finalize_sample<128>(comps, f, partial, n_chunks, blockIdx.x, threadIdx.x, s);
+  if (n_chunks < 0) return;  // GIGALENS_HIP_DBGFLAGS & 8: the cost of the bare launch (results undefined)
+  finalize_sample<128, BASIC>(comps, f, partial, n_chunks, blockIdx.x, threadIdx.x, s);
 }
 
 // Fused form (specialised kernels, likelihood modes): the LAST workgroup of a sample to publish its partial row runs

@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2o
-timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r2o/pytest_all.log 2>&1; echo "rc=$?"; tail -2 gpurun_out/r2o/pytest_all.log | cut -c1-300
-bash tools/collect_profiles.sh r2 2>&1 | tail -1 | cut -c1-400
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/pt.log 2>&1; echo "rc=$?"; tail -2 gpurun_out/pt.log | cut -c1-200
