@@ -163,15 +163,34 @@ GL_HD float p_pow(float x, float y) { return ::powf(x, y); }
 
 // (e1,e2) -> (phi, c, q) with c = min(|e|, cmax); EPL passes cmax = 1 (epl.py:22), every other
 // elliptical profile 0.9999 (sie.py:17, sersic.py:57).  Arithmetic in R like the reference's fp32.
-template <class R> struct Ellip { R phi, ee, c, q, cphi, sphi; };
+// cos / sin of phi = atan2(e2, e1) / 2 in (-pi/2, pi/2] come from the half-angle identities on cos 2phi = e1 / |e| -- the
+// cancellation-free branch of each, the other through sin 2phi = 2 sin phi cos phi -- instead of atan2 + cos + sin (three
+// library calls of ~80 dependent instructions each on the one lane that prepares a sample's lens).  e = 0: phi = atan2(+-0, +-0) / 2.
+// sign bit of the innermost value (dual / jet types decide on values: their val() is found by argument-dependent lookup)
+GL_HD bool neg_sign(float x) { return __builtin_signbitf(x); }
+GL_HD bool neg_sign(double x) { return __builtin_signbit(x); }
+template <class R> GL_HD auto neg_sign(const R& x) -> decltype(neg_sign(val(x))) { return neg_sign(val(x)); }
+template <class R> struct Ellip { R ee, c, q, cphi, sphi; };
 template <class R> GL_HD Ellip<R> ellip_prep(R e1, R e2, R cmax) {
   Ellip<R> o;
-  o.phi = p_atan2(e2, e1) / (R)2;
   o.ee = p_sqrt(e1 * e1 + e2 * e2);
   o.c = fmin_(o.ee, cmax);
   o.q = ((R)1 - o.c) / ((R)1 + o.c);
-  o.cphi = p_cos(o.phi);
-  o.sphi = p_sin(o.phi);
+  const bool neg2 = neg_sign(e2), neg1 = neg_sign(e1);
+  if (o.ee > (R)0) {
+    const R c2 = e1 / o.ee, s2 = e2 / o.ee;  // cos 2phi, sin 2phi
+    if (c2 >= (R)0) {
+      o.cphi = p_sqrt(((R)1 + c2) * (R)0.5);
+      o.sphi = s2 / ((R)2 * o.cphi);
+    } else {
+      const R sa = p_sqrt(((R)1 - c2) * (R)0.5);  // |sin phi|
+      o.sphi = neg2 ? -sa : sa;
+      o.cphi = (neg2 ? -s2 : s2) / ((R)2 * sa);
+    }
+  } else {  // atan2 of signed zeros: 0, +-pi -> phi = 0 or +-pi/2
+    o.cphi = neg1 ? (R)0 : (R)1;
+    o.sphi = neg1 ? (neg2 ? (R)-1 : (R)1) : (R)0;
+  }
   return o;
 }
 // b = theta_E / sqrt((1+q^2)/(2q)) * sqrt((1+q^2)/2)   (epl.py:24-25, sie.py:19-20; == theta_E sqrt(q))
