@@ -297,7 +297,39 @@ PostArgs post_args(const gl_model* m, float scale) {
   return p;
 }
 // supersampled pre-PSF image S [B,Hs,Ws] -> final image [B,H,W] (x conversion factor)
+// the register-blocked pair kernel on one plan (gl_post.hip.h); false: no instantiation for this kernel width / stride
+bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* out, float scale, hipStream_t stream) {
+  if (!pl.ok) return false;
+  CorrArgs a = pl.args;
+  a.B = B;
+  a.scale = scale;
+  const int TR = (CORR_TR - 1) * pl.ST + pl.max_KH, TC = ((CORR_TCG * CORR_OX - 1) * pl.ST + pl.KWP) | 1;
+  const int ks = pl.ST == 2 ? 4 : 2;
+  const size_t sh = std::max((size_t)TR * TC, (size_t)(ks - 1) * a.ncj * CORR_OX * CORR_GT) * sizeof(float2);
+  if (sh > 64 * 1024) return false;
+  const dim3 grid((pl.max_Wo + CORR_TCG * CORR_OX - 1) / (CORR_TCG * CORR_OX), (pl.max_Ho + CORR_TR - 1) / CORR_TR,
+                  (unsigned)(a.n_class * ((B + 1) / 2)));
+#define GL_CORR(KWP_, ST_, KS_, NCJ_) hipLaunchKernelGGL((gl_corr_pair_kernel<KWP_, ST_, KS_, NCJ_>), grid, dim3(CORR_GT * KS_), sh, stream, in, out, a); return true
+#define GL_CORR_W(ST_, KS_, NCJ_)                                                                                     \
+  switch (pl.KWP) {                                                                                                   \
+    case 4: GL_CORR(4, ST_, KS_, NCJ_); case 8: GL_CORR(8, ST_, KS_, NCJ_); case 12: GL_CORR(12, ST_, KS_, NCJ_);       \
+    case 16: GL_CORR(16, ST_, KS_, NCJ_); case 20: GL_CORR(20, ST_, KS_, NCJ_); case 24: GL_CORR(24, ST_, KS_, NCJ_);   \
+    case 28: GL_CORR(28, ST_, KS_, NCJ_); case 32: GL_CORR(32, ST_, KS_, NCJ_);                                        \
+    default: return false;                                                                                            \
+  }
+  if (pl.ST == 2 && a.ncj == 1) { GL_CORR_W(2, 4, 1) }  // forward at supersample 2
+  if (pl.ST == 1 && a.ncj == 1) { GL_CORR_W(1, 2, 1) }  // forward / transpose at supersample 1
+  if (pl.ST == 1 && a.ncj == 2) { GL_CORR_W(1, 2, 2) }  // transpose at supersample 2
+#undef GL_CORR_W
+#undef GL_CORR
+  return false;
+}
+
 int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t stream, float scale = -1.f) {
+  if (launch_corr(m->corr_fwd, B, S, out, scale < 0.f ? m->conversion_factor : scale, stream)) {
+    GL_HIP(hipGetLastError());
+    return GL_OK;
+  }
   PostArgs p = post_args(m, scale < 0.f ? m->conversion_factor : scale);
   const int TR = (PT - 1) * p.ss + p.KH, TC = ((PT - 1) * p.ss + p.KW) | 1;
   size_t shmem = (size_t)TR * TC * sizeof(float);
@@ -309,6 +341,10 @@ int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t s
 }
 // cotangent of the final image [B,H,W] -> cotangent of S [B,Hs,Ws]
 int post_bwd(const gl_model* m, int B, const float* gP, float* gS, hipStream_t stream) {
+  if (launch_corr(m->corr_bwd, B, gP, gS, m->conversion_factor, stream)) {
+    GL_HIP(hipGetLastError());
+    return GL_OK;
+  }
   PostArgs p = post_args(m, m->conversion_factor);
   const int TR = (PT - 1 + p.KH) / p.ss + 3, TC = ((PT - 1 + p.KW) / p.ss + 3) | 1;
   size_t shmem = (size_t)TR * TC * sizeof(float);
@@ -591,6 +627,73 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
       }
     std::vector<float> kf(keff.begin(), keff.end());
     ok = ok && up((void**)&m->d_psf, kf.data(), sizeof(float) * kf.size());
+    // plans of the register-blocked pair kernel: forward = one class (stride ss, Keff), transpose = ss^2 residue classes
+    // (stride 1, the class's decimated and flipped sub-kernel); rows padded to a multiple of four taps
+    if (env_int("GIGALENS_HIP_CORR_PAIR", 1) && ss <= 2 && m->KW <= 32 && m->KH <= 64) {
+      const int Hs = m->height, Ws = m->width, H = Hs / ss, W = Ws / ss;
+      std::vector<float> kbuf;
+      auto pad4 = [](int n) { return std::max(4, (n + 3) & ~3); };
+      {
+        gl_model::CorrPlan& f = m->corr_fwd;
+        f.KWP = pad4(m->KW);
+        f.ST = ss;
+        CorrClass c{};
+        c.koff = 0; c.KH = m->KH; c.pt = m->pad_t; c.pl = m->pad_l; c.Ho = H; c.Wo[0] = W; c.oo_r = 0; c.oo_c[0] = 0;
+        kbuf.assign((size_t)m->KH * f.KWP, 0.f);
+        for (int u = 0; u < m->KH; ++u)
+          for (int v = 0; v < m->KW; ++v) kbuf[(size_t)u * f.KWP + v] = (float)keff[(size_t)u * m->KW + v];
+        f.args.n_class = 1; f.args.ncj = 1; f.args.Hi = Hs; f.args.Wi = Ws; f.args.Hout = H; f.args.Wout = W; f.args.os = 1;
+        f.args.cls[0] = c;
+        f.max_Ho = H; f.max_Wo = W; f.max_KH = m->KH; f.ok = true;
+      }
+      {
+        // transpose: row class pi = (i + pt) mod ss -> one workgroup family; its ss column classes pj share a thread.  Class
+        // (pi, pj): outputs i = ss n + ri, j = ss q + rj;  gS = sum_{t, s} gP[n + t - padT][q + s - padL] Kf[t][s] with the
+        // flipped decimated kernel Kf[t][s] = Keff[pi + ss (A - 1 - t)][pj + ss (C - 1 - s)].  The column classes' left
+        // paddings differ by at most one: they are levelled to the largest by shifting the kernel right.
+        gl_model::CorrPlan& g = m->corr_bwd;
+        g.ST = 1;
+        g.args.n_class = ss; g.args.ncj = ss; g.args.Hi = H; g.args.Wi = W; g.args.Hout = Hs; g.args.Wout = Ws; g.args.os = ss;
+        int Cn[4], rjn[4], pln[4], max_pl = -(1 << 30), width = 1;
+        for (int pj = 0; pj < ss; ++pj) {
+          Cn[pj] = m->KW > pj ? (m->KW - pj + ss - 1) / ss : 0;
+          rjn[pj] = ((pj - m->pad_l) % ss + ss) % ss;
+          pln[pj] = (Cn[pj] - 1) - (rjn[pj] + m->pad_l - pj) / ss;
+          max_pl = std::max(max_pl, pln[pj]);
+        }
+        for (int pj = 0; pj < ss; ++pj) width = std::max(width, Cn[pj] + (max_pl - pln[pj]));
+        g.KWP = pad4(width);
+        // column classes ordered by their output offset, so Wo[0] is the largest
+        int order[4];
+        for (int pj = 0; pj < ss; ++pj) order[rjn[pj]] = pj;
+        for (int pi = 0; pi < ss; ++pi) {
+          const int A = m->KH > pi ? (m->KH - pi + ss - 1) / ss : 0;
+          const int ri = ((pi - m->pad_t) % ss + ss) % ss;
+          CorrClass c{};
+          c.koff = (int)kbuf.size();
+          c.KH = A;
+          c.pt = (A - 1) - (ri + m->pad_t - pi) / ss;
+          c.pl = max_pl;
+          c.Ho = ri < Hs ? (Hs - ri + ss - 1) / ss : 0;
+          c.oo_r = ri;
+          kbuf.resize(kbuf.size() + (size_t)A * ss * g.KWP, 0.f);
+          for (int jj = 0; jj < ss; ++jj) {
+            const int pj = order[jj], C = Cn[pj], sh = max_pl - pln[pj];
+            c.Wo[jj] = rjn[pj] < Ws ? (Ws - rjn[pj] + ss - 1) / ss : 0;
+            c.oo_c[jj] = rjn[pj];
+            for (int t = 0; t < A; ++t)
+              for (int q = 0; q < C; ++q)
+                kbuf[(size_t)c.koff + ((size_t)t * ss + jj) * g.KWP + sh + q] =
+                    (float)keff[(size_t)(pi + ss * (A - 1 - t)) * m->KW + (pj + ss * (C - 1 - q))];
+          }
+          g.args.cls[pi] = c;
+          g.max_Ho = std::max(g.max_Ho, c.Ho); g.max_Wo = std::max(g.max_Wo, c.Wo[0]); g.max_KH = std::max(g.max_KH, c.KH);
+        }
+        g.ok = true;
+      }
+      ok = ok && up((void**)&m->d_corr_k, kbuf.data(), sizeof(float) * kbuf.size());
+      m->corr_fwd.args.k = m->corr_bwd.args.k = m->d_corr_k;
+    }
   }
   if (!ok) {
     gl_model_destroy(m);
@@ -669,6 +772,7 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_pix) (void)hipFree(m->d_pix);
   if (m->d_shp_tab) (void)hipFree(m->d_shp_tab);
   if (m->d_nfw_tab) (void)hipFree(m->d_nfw_tab);
+  if (m->d_corr_k) (void)hipFree(m->d_corr_k);
   if (m->d_psf) (void)hipFree(m->d_psf);
   if (m->d_pos) (void)hipFree(m->d_pos);
   if (m->d_fam) (void)hipFree(m->d_fam);

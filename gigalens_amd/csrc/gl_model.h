@@ -25,6 +25,24 @@ using glk::CatDev;
 using glk::SeriesDev;
 using glk::ZCol;
 
+namespace glk {
+// plans of gl_corr_pair_kernel (gl_post.hip.h)
+struct CorrClass {  // one ROW class; its column classes (ncj of them) are computed by the same thread
+  int koff;        // offset of this class's [KH][ncj][KWP] kernel block in the kernel buffer
+  int KH, pt, pl;  // taps per column, top / left padding of the window (common to the column classes: kernels are shifted)
+  int Ho, Wo[4];   // outputs of the class (rows; columns per column class)
+  int oo_r, oo_c[4];  // placement of output (0, 0) in the output image
+};
+struct CorrArgs {
+  const float* k;
+  int n_class, ncj, B;  // row classes (one per workgroup along z), column classes per thread
+  int Hi, Wi;          // input image
+  int Hout, Wout, os;  // output image and the placement stride of a class's outputs
+  float scale;
+  CorrClass cls[16];
+};
+}  // namespace glk
+
 struct gl_model {
   std::vector<CompDesc> comps;
   int n_lens = 0, n_ll = 0, n_src = 0;
@@ -45,6 +63,10 @@ struct gl_model {
   size_t nfw_lds = 0;          // bytes of that table in a main kernel's LDS
   int shp_stride = 0;
   float* d_psf = nullptr;  // effective kernel flip(psf) (*) box(ss)/ss^2, see gl_post.hip.h
+  // the register-blocked pair kernel's plans (gl_post.hip.h gl_corr_pair_kernel): class tables, padded kernels on the device
+  struct CorrPlan { glk::CorrArgs args{}; int KWP = 0, ST = 0, max_Ho = 0, max_Wo = 0, max_KH = 0; bool ok = false; };
+  CorrPlan corr_fwd, corr_bwd;
+  float* d_corr_k = nullptr;
   int psf_h = 0, psf_w = 0;
   int KH = 1, KW = 1, pad_t = 0, pad_l = 0;
   bool has_post = false;

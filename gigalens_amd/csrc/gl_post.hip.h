@@ -91,6 +91,139 @@ __global__ void __launch_bounds__(256) gl_psf_pool_bwd_kernel(const float* __res
   if (i < p.Hs && j < p.Ws) gS[((size_t)b * p.Hs + i) * p.Ws + j] = acc * p.scale;
 }
 
+// ---- register-blocked, sample-pair-packed correlation (the fast path of both directions) -----------------------------
+// The kernels above spend one LDS read and one scalar-loaded tap per multiply-add: 17 (forward) and 8 (transpose) TFLOP/s on
+// the reference's demo set-up, where they are 80 % of a log-prob step.  Here
+//   * a thread owns EIGHT consecutive outputs of a row and keeps the input window they share ((8 - 1) ST + KWP columns) in
+//     registers: one LDS read per 5 multiply-adds instead of one per one (with four outputs the LDS pipe, shared by the four
+//     SIMDs of a CU, was still the bound), every tap an SGPR operand;
+//   * the two halves of every packed fp32 instruction are TWO SAMPLES (b, b + 1): the LDS tile interleaves them, a tap
+//     multiplies both (v_pk_fma_f32 with a scalar operand) -- the only pairing whose operands are adjacent registers;
+//   * both directions are the same kernel.  Forward: stride ST = ss over the supersampled image with Keff.  Transpose: for
+//     each of the ss^2 residue classes (i + pt, j + pl) mod ss the gather over the pooled cotangents is a stride-1
+//     correlation with the class's decimated, flipped sub-kernel (~KH / ss taps a side), written back with stride ss.
+// Kernels are stored row-padded to KWP (a multiple of 4, zero taps) so the tap loop unrolls at compile time.
+// (CorrClass / CorrArgs: gl_model.h, the model keeps one plan per direction)
+constexpr int CORR_TR = 16, CORR_TCG = 4, CORR_OX = 8;  // output tile: 16 rows x (4 threads x 8 outputs) columns
+constexpr int CORR_GT = CORR_TR * CORR_TCG;             // threads of one group (one wavefront)
+
+// KS: the kernel's rows are dealt to KS wavefronts (u = g, g + KS, ..) that share the LDS tile and add their sums at the end --
+// the stride-2 tile is 41 KB, so one wavefront per tile would leave a CU with three.
+// NCJ: column classes per thread (transpose: ss -- a thread then writes ss * 8 CONSECUTIVE floats of a row; one class per
+// launch unit wrote every ss-th float of a 29 MB buffer from different workgroups, and the partial-line writes bound the kernel)
+template <int KWP, int ST, int KS, int NCJ>
+__global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float* __restrict__ in, float* __restrict__ out, CorrArgs p) {
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  extern __shared__ float2 ctile[];
+  constexpr int NT = CORR_GT * KS;
+  const int ci = blockIdx.z % p.n_class, bp = blockIdx.z / p.n_class;
+  const CorrClass c = p.cls[ci];
+  const int I0 = blockIdx.y * CORR_TR, J0 = blockIdx.x * (CORR_TCG * CORR_OX);
+  if (I0 >= c.Ho || J0 >= c.Wo[0]) return;  // classes differ in size: whole workgroups leave together (Wo[0] is the largest)
+  const int TR = (CORR_TR - 1) * ST + c.KH;
+  constexpr int TC = (CORR_TCG * CORR_OX - 1) * ST + KWP, TCp = TC | 1;
+  const int b0 = 2 * bp, b1 = min(b0 + 1, p.B - 1);
+  const bool has1 = b0 + 1 < p.B;
+  const float* in0 = in + (size_t)b0 * p.Hi * p.Wi;
+  const float* in1 = in + (size_t)b1 * p.Hi * p.Wi;
+  const int r0 = I0 * ST - c.pt, c0 = J0 * ST - c.pl;
+  // fill: one wavefront per tile row, lanes along the row (no index division, row-contiguous global reads); four rows'
+  // loads are issued before the first LDS write, so a wavefront pays the global round trip once per four rows (eight: slower)
+  constexpr int NW = NT / 64, FR = 4, CPASS = (TC + 63) / 64;
+  for (int rb = threadIdx.x >> 6; rb < TR; rb += NW * FR) {
+    float2 v[FR][CPASS];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      const int r = rb + f * NW, gr = r0 + r;
+      const bool rin = r < TR && gr >= 0 && gr < p.Hi;
+      const size_t roff = (size_t)(rin ? gr : 0) * p.Wi;
+#pragma unroll
+      for (int q = 0; q < CPASS; ++q) {
+        const int gc = c0 + (int)(threadIdx.x & 63) + 64 * q;
+        const bool inside = rin && gc >= 0 && gc < p.Wi;
+        const size_t off = roff + (inside ? gc : 0);
+        const float a0 = in0[off], a1 = in1[off];
+        v[f][q] = inside ? float2{a0, a1} : float2{0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      const int r = rb + f * NW;
+#pragma unroll
+      for (int q = 0; q < CPASS; ++q) {
+        const int cc = (int)(threadIdx.x & 63) + 64 * q;
+        if (r < TR && cc < TC) ctile[r * TCp + cc] = v[f][q];
+      }
+    }
+  }
+  __syncthreads();
+  // lane -> (row ti fastest, column group tg): the 16 lanes of an LDS pass read 16 different rows, ST * TCp float2 apart with
+  // TCp odd -> distinct banks (column groups are 16 banks apart: four of them would collide)
+  static_assert(CORR_GT == 64, "one group = one wavefront: its kernel row is wave-uniform");
+  const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / CORR_GT)), t128 = threadIdx.x % CORR_GT;  // scalar: taps come through s_load
+  const int ti = t128 % CORR_TR, tg = t128 / CORR_TR;
+  constexpr int WIN = (CORR_OX - 1) * ST + KWP;
+  v2 acc[NCJ][CORR_OX];
+#pragma unroll
+  for (int j = 0; j < NCJ; ++j)
+#pragma unroll
+    for (int o = 0; o < CORR_OX; ++o) acc[j][o] = v2{0.f, 0.f};
+  const float2* base = ctile + (ti * ST) * TCp + tg * CORR_OX * ST;
+  const float* __restrict__ kc = p.k + c.koff;
+  for (int u = g; u < c.KH; u += KS) {
+    const float2* row = base + u * TCp;
+    v2 w[WIN];
+#pragma unroll
+    for (int q = 0; q < WIN; ++q) { const float2 t = row[q]; w[q] = v2{t.x, t.y}; }
+    const float* __restrict__ kr = kc + u * (NCJ * KWP);  // wave-uniform: scalar loads
+#pragma unroll
+    for (int j = 0; j < NCJ; ++j)
+#pragma unroll
+      for (int v = 0; v < KWP; ++v) {
+        const float kv = kr[j * KWP + v];
+#pragma unroll
+        for (int o = 0; o < CORR_OX; ++o) acc[j][o] = __builtin_elementwise_fma(w[o * ST + v], v2{kv, kv}, acc[j][o]);
+      }
+  }
+  if constexpr (KS > 1) {  // groups 1.. hand their sums to group 0 through the (now free) tile
+    __syncthreads();
+    float2* sred = ctile;
+    if (g > 0) {
+#pragma unroll
+      for (int j = 0; j < NCJ; ++j)
+#pragma unroll
+        for (int o = 0; o < CORR_OX; ++o)
+          sred[(((g - 1) * NCJ + j) * CORR_OX + o) * CORR_GT + t128] = float2{acc[j][o].x, acc[j][o].y};
+    }
+    __syncthreads();
+    if (g > 0) return;
+#pragma unroll
+    for (int gg = 1; gg < KS; ++gg)
+#pragma unroll
+      for (int j = 0; j < NCJ; ++j)
+#pragma unroll
+        for (int o = 0; o < CORR_OX; ++o) {
+          const float2 t = sred[(((gg - 1) * NCJ + j) * CORR_OX + o) * CORR_GT + t128];
+          acc[j][o] += v2{t.x, t.y};
+        }
+  }
+  const int I = I0 + ti;
+  if (I < c.Ho) {
+    float* o0 = out + (size_t)b0 * p.Hout * p.Wout + (size_t)(I * p.os + c.oo_r) * p.Wout;
+    float* o1 = out + (size_t)b1 * p.Hout * p.Wout + (size_t)(I * p.os + c.oo_r) * p.Wout;
+#pragma unroll
+    for (int o = 0; o < CORR_OX; ++o) {
+      const int J = J0 + tg * CORR_OX + o;
+#pragma unroll
+      for (int j = 0; j < NCJ; ++j)
+        if (J < c.Wo[j]) {
+          o0[(size_t)J * p.os + c.oo_c[j]] = acc[j][o].x * p.scale;
+          if (has1) o1[(size_t)J * p.os + c.oo_c[j]] = acc[j][o].y * p.scale;
+        }
+    }
+  }
+}
+
 // pixel statistics of a materialised image (tf/model.py:89-101) and d loglike / d image
 __global__ void __launch_bounds__(256) gl_imgstats_kernel(const float* __restrict__ img, const float* __restrict__ obs,
                                                           const float* __restrict__ err, const float* __restrict__ mask,

@@ -586,8 +586,15 @@ def _gauss_psf(n, sigma, seed=0):
     return (k / k.sum()).astype(np.float32)
 
 
-@pytest.mark.parametrize("ss,ksize", [(1, 7), (2, 0), (2, 9), (3, 5), (2, 8)])
-def test_psf_supersample_vs_oracle(gl, ss, ksize):
+@pytest.mark.parametrize("ss,ksize,n,B", [(1, 7, 22, 3), (2, 0, 22, 3), (2, 9, 22, 3), (3, 5, 22, 3), (2, 8, 22, 3),
+                                          (2, 13, 60, 5),   # the reference's demo geometry: 27-tap effective kernel, several tiles, odd batch
+                                          (1, 13, 60, 4),
+                                          (2, 33, 36, 2)])  # wider than the register-blocked kernel serves: the tap-by-tap kernels
+def test_psf_supersample_vs_oracle(gl, ss, ksize, n, B):
+    """simulate(), the pixel likelihood and their gradients with a PSF and / or supersampling against the float64 oracle --
+    through the register-blocked sample-pair correlation (gl_corr_pair_kernel: supersample <= 2, effective kernel <= 32 taps
+    wide; forward = stride-ss correlation, transpose = ss^2 decimated flipped sub-kernels) and through the tap-by-tap
+    kernels that serve everything else."""
     from gigalens_amd.model import PhysicalModel
     from gigalens_amd.profiles.light.sersic import SersicEllipse
     from gigalens_amd.profiles.mass.epl import EPL
@@ -595,7 +602,6 @@ def test_psf_supersample_vs_oracle(gl, ss, ksize):
     from gigalens_amd.simulator import SimulatorConfig
     from oracle import ref_torch as ref
     from tests.test_prior_host import default_prior
-    n, B = 22, 3
     phys = PhysicalModel([EPL(), Shear()], [SersicEllipse()], [SersicEllipse()])
     prior = default_prior()
     psf = _gauss_psf(ksize, 1.2 * ss) if ksize else None

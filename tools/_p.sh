@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-printf "X=0\n" > /tmp/sw.txt
-bash tools/dev/sweep_env.sh /tmp/sw.txt
-timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/pt.log 2>&1; echo "rc=$?"; tail -2 gpurun_out/pt.log | cut -c1-200
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "psf_supersample" > gpurun_out/pt.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/pt.log | cut -c1-300
