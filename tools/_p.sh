@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "psf_supersample" > gpurun_out/pt.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/pt.log | cut -c1-300
+mkdir -p gpurun_out/r2r
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r2r/pytest_all.log 2>&1; echo "rc=$?"; tail -2 gpurun_out/r2r/pytest_all.log | cut -c1-300
+bash tools/collect_profiles.sh r2 2>&1 | tail -1 | cut -c1-200

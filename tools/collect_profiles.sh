@@ -12,6 +12,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- pyth
 for W in C2 C3 C4 C5 C6; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_$W -- python3 $R/tools/prof_kernel.py --workload $W --iters 20 > $OUT/kernel_stats_$W.log 2>&1
 done
+# the reference's demo set-up (60x60, supersample 2, 13x13 PSF through subgrid_kernel, 500 samples): PSF / pooling kernels + pair kernels
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_demo -- python3 $R/tools/dev/prof_demo.py 2 > $OUT/kernel_stats_demo.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_C3L -- python3 $R/tools/prof_kernel.py --workload C3L --mode lstsq --iters 8 > $OUT/kernel_stats_C3L.log 2>&1
 # the simulate() boundary itself at C2: gl_simulate_fwd writes the image, gl_simulate_bwd reads its cotangent (the pair that moves B1)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_simpair -- python3 $R/tools/prof_kernel.py --workload C2 --mode simpair --iters 40 > $OUT/kernel_stats_simpair.log 2>&1

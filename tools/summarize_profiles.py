@@ -49,7 +49,7 @@ def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_ker
 
 summary = {}
 rows = stats_table("bench_stats", f"{tag}_bench_kernel_stats.md")
-for w in ("C2", "C3", "C4", "C5", "C6", "C3L", "simpair"):
+for w in ("C2", "C3", "C4", "C5", "C6", "C3L", "simpair", "demo"):
     stats_table(f"kernel_stats_{w}", f"{tag}_{w}_kernel_stats.md", top=6)
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mix", "pmc_clk"):
     summary[d] = pmc(d)
