@@ -298,14 +298,16 @@ PostArgs post_args(const gl_model* m, float scale) {
 }
 // supersampled pre-PSF image S [B,Hs,Ws] -> final image [B,H,W] (x conversion factor)
 // the register-blocked pair kernel on one plan (gl_post.hip.h); false: no instantiation for this kernel width / stride
-bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* out, float scale, hipStream_t stream) {
+bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* out, float scale, hipStream_t stream, int dbg = 0) {
   if (!pl.ok) return false;
   CorrArgs a = pl.args;
   a.B = B;
   a.scale = scale;
+  a.dbg = dbg;
   const int TR = (CORR_TR - 1) * pl.ST + pl.max_KH, TC = ((CORR_TCG * CORR_OX - 1) * pl.ST + pl.KWP) | 1;
   const int ks = pl.ST == 2 ? 4 : 2;
-  const size_t sh = std::max((size_t)TR * TC, (size_t)(ks - 1) * a.ncj * CORR_OX * CORR_GT) * sizeof(float2);
+  const size_t sh = std::max((size_t)TR * TC * sizeof(float2), (size_t)(ks - 1) * a.ncj * CORR_OX * CORR_GT * sizeof(float2) +
+                                                                   (size_t)2 * CORR_TR * CORR_TCG * CORR_OX * a.ncj * sizeof(float));
   if (sh > 64 * 1024) return false;
   const dim3 grid((pl.max_Wo + CORR_TCG * CORR_OX - 1) / (CORR_TCG * CORR_OX), (pl.max_Ho + CORR_TR - 1) / CORR_TR,
                   (unsigned)(a.n_class * ((B + 1) / 2)));
@@ -326,7 +328,7 @@ bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* ou
 }
 
 int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t stream, float scale = -1.f) {
-  if (launch_corr(m->corr_fwd, B, S, out, scale < 0.f ? m->conversion_factor : scale, stream)) {
+  if (launch_corr(m->corr_fwd, B, S, out, scale < 0.f ? m->conversion_factor : scale, stream, m->dbg_flags)) {
     GL_HIP(hipGetLastError());
     return GL_OK;
   }
@@ -341,7 +343,7 @@ int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t s
 }
 // cotangent of the final image [B,H,W] -> cotangent of S [B,Hs,Ws]
 int post_bwd(const gl_model* m, int B, const float* gP, float* gS, hipStream_t stream) {
-  if (launch_corr(m->corr_bwd, B, gP, gS, m->conversion_factor, stream)) {
+  if (launch_corr(m->corr_bwd, B, gP, gS, m->conversion_factor, stream, m->dbg_flags)) {
     GL_HIP(hipGetLastError());
     return GL_OK;
   }

@@ -39,6 +39,7 @@ struct CorrArgs {
   int Hi, Wi;          // input image
   int Hout, Wout, os;  // output image and the placement stride of a class's outputs
   float scale;
+  int dbg;  // experiments (GIGALENS_HIP_DBGFLAGS): 16 skip the tile fill, 32 skip the multiply-add loop
   CorrClass cls[16];
 };
 }  // namespace glk

@@ -127,10 +127,10 @@ __global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float*
   const float* in0 = in + (size_t)b0 * p.Hi * p.Wi;
   const float* in1 = in + (size_t)b1 * p.Hi * p.Wi;
   const int r0 = I0 * ST - c.pt, c0 = J0 * ST - c.pl;
-  // fill: one wavefront per tile row, lanes along the row (no index division, row-contiguous global reads); four rows'
-  // loads are issued before the first LDS write, so a wavefront pays the global round trip once per four rows (eight: slower)
-  constexpr int NW = NT / 64, FR = 4, CPASS = (TC + 63) / 64;
-  for (int rb = threadIdx.x >> 6; rb < TR; rb += NW * FR) {
+  // fill: one wavefront per tile row, lanes along the row (no index division, row-contiguous global reads); all of a wavefront's
+  // loads (up to 16 per lane) are issued before the first LDS write: one global round trip per wavefront instead of one per row
+  constexpr int NW = NT / 64, CPASS = (TC + 63) / 64, FR = 16 / CPASS;  // 16 float2 of loads in flight per lane
+  for (int rb = (p.dbg & 16) ? TR : (int)(threadIdx.x >> 6); rb < TR; rb += NW * FR) {
     float2 v[FR][CPASS];
 #pragma unroll
     for (int f = 0; f < FR; ++f) {
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float*
     for (int o = 0; o < CORR_OX; ++o) acc[j][o] = v2{0.f, 0.f};
   const float2* base = ctile + (ti * ST) * TCp + tg * CORR_OX * ST;
   const float* __restrict__ kc = p.k + c.koff;
-  for (int u = g; u < c.KH; u += KS) {
+  for (int u = (p.dbg & 32) ? c.KH : g; u < c.KH; u += KS) {
     const float2* row = base + u * TCp;
     v2 w[WIN];
 #pragma unroll
@@ -185,9 +185,14 @@ __global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float*
         for (int o = 0; o < CORR_OX; ++o) acc[j][o] = __builtin_elementwise_fma(w[o * ST + v], v2{kv, kv}, acc[j][o]);
       }
   }
-  if constexpr (KS > 1) {  // groups 1.. hand their sums to group 0 through the (now free) tile
-    __syncthreads();
-    float2* sred = ctile;
+  // ---- epilogue: sums of the row groups, then the tile leaves through LDS so that the global writes are row-contiguous (a lane
+  // owns eight outputs of ONE row and neighbouring lanes different rows: written from registers every store instruction touched
+  // 64 cache lines -- 42 of the transpose's 64 us were those stores)
+  float2* sred = ctile;
+  float* otile = reinterpret_cast<float*>(ctile + (KS - 1) * NCJ * CORR_OX * CORR_GT);  // [2 samples][16 rows][32 NCJ columns]
+  constexpr int WT = CORR_TCG * CORR_OX * NCJ;
+  __syncthreads();  // every wavefront is done with the input tile
+  if constexpr (KS > 1) {
     if (g > 0) {
 #pragma unroll
       for (int j = 0; j < NCJ; ++j)
@@ -196,31 +201,30 @@ __global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float*
           sred[(((g - 1) * NCJ + j) * CORR_OX + o) * CORR_GT + t128] = float2{acc[j][o].x, acc[j][o].y};
     }
     __syncthreads();
-    if (g > 0) return;
-#pragma unroll
-    for (int gg = 1; gg < KS; ++gg)
-#pragma unroll
-      for (int j = 0; j < NCJ; ++j)
-#pragma unroll
-        for (int o = 0; o < CORR_OX; ++o) {
-          const float2 t = sred[(((gg - 1) * NCJ + j) * CORR_OX + o) * CORR_GT + t128];
-          acc[j][o] += v2{t.x, t.y};
-        }
   }
-  const int I = I0 + ti;
-  if (I < c.Ho) {
-    float* o0 = out + (size_t)b0 * p.Hout * p.Wout + (size_t)(I * p.os + c.oo_r) * p.Wout;
-    float* o1 = out + (size_t)b1 * p.Hout * p.Wout + (size_t)(I * p.os + c.oo_r) * p.Wout;
+  if (g == 0) {
 #pragma unroll
-    for (int o = 0; o < CORR_OX; ++o) {
-      const int J = J0 + tg * CORR_OX + o;
+    for (int j = 0; j < NCJ; ++j)
 #pragma unroll
-      for (int j = 0; j < NCJ; ++j)
-        if (J < c.Wo[j]) {
-          o0[(size_t)J * p.os + c.oo_c[j]] = acc[j][o].x * p.scale;
-          if (has1) o1[(size_t)J * p.os + c.oo_c[j]] = acc[j][o].y * p.scale;
+      for (int o = 0; o < CORR_OX; ++o) {
+        v2 a = acc[j][o];
+#pragma unroll
+        for (int gg = 1; gg < KS; ++gg) {
+          const float2 t = sred[(((gg - 1) * NCJ + j) * CORR_OX + o) * CORR_GT + t128];
+          a += v2{t.x, t.y};
         }
-    }
+        const int col = (tg * CORR_OX + o) * NCJ + c.oo_c[j];  // NCJ == the placement stride of the plan
+        otile[ti * WT + col] = a.x * p.scale;
+        otile[(CORR_TR + ti) * WT + col] = a.y * p.scale;
+      }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * CORR_TR * WT; idx += NT) {
+    const int sidx = idx / (CORR_TR * WT), rem = idx - sidx * (CORR_TR * WT);
+    const int row = rem / WT, col = rem - row * WT;
+    const int gi = (I0 + row) * p.os + c.oo_r, gj = J0 * p.os + col;
+    if (gi < p.Hout && I0 + row < c.Ho && gj < p.Wout && (sidx == 0 || has1))
+      out[((size_t)(sidx ? b1 : b0) * p.Hout + gi) * p.Wout + gj] = otile[idx];
   }
 }
 
