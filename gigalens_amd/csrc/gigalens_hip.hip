@@ -309,6 +309,17 @@ bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* ou
   const size_t sh = std::max((size_t)TR * TC * sizeof(float2), (size_t)(ks - 1) * a.ncj * CORR_OX * CORR_GT * sizeof(float2) +
                                                                    (size_t)2 * CORR_TR * CORR_TCG * CORR_OX * a.ncj * sizeof(float));
   if (sh > 64 * 1024) return false;
+  // grid.z carries (row class, sample pair): at most 65535 per launch -- larger batches (the basis stack of lstsq_simulate is
+  // B x D images) go out in slices
+  const int max_pairs_env = env_int("GIGALENS_HIP_CORR_MAXPAIRS", 0);  // tests: force the slicing
+  const int max_pairs = max_pairs_env > 0 ? max_pairs_env : 65535 / a.n_class;
+  if ((B + 1) / 2 > max_pairs) {
+    for (int b_lo = 0; b_lo < B; b_lo += 2 * max_pairs) {
+      const int nb = std::min(B - b_lo, 2 * max_pairs);
+      if (!launch_corr(pl, nb, in + (size_t)b_lo * a.Hi * a.Wi, out + (size_t)b_lo * a.Hout * a.Wout, scale, stream, dbg)) return false;
+    }
+    return true;
+  }
   const dim3 grid((pl.max_Wo + CORR_TCG * CORR_OX - 1) / (CORR_TCG * CORR_OX), (pl.max_Ho + CORR_TR - 1) / CORR_TR,
                   (unsigned)(a.n_class * ((B + 1) / 2)));
 #define GL_CORR(KWP_, ST_, KS_, NCJ_) hipLaunchKernelGGL((gl_corr_pair_kernel<KWP_, ST_, KS_, NCJ_>), grid, dim3(CORR_GT * KS_), sh, stream, in, out, a); return true

@@ -590,7 +590,7 @@ def _gauss_psf(n, sigma, seed=0):
                                           (2, 13, 60, 5),   # the reference's demo geometry: 27-tap effective kernel, several tiles, odd batch
                                           (1, 13, 60, 4),
                                           (2, 33, 36, 2)])  # wider than the register-blocked kernel serves: the tap-by-tap kernels
-def test_psf_supersample_vs_oracle(gl, ss, ksize, n, B):
+def test_psf_supersample_vs_oracle(gl, ss, ksize, n, B, monkeypatch):
     """simulate(), the pixel likelihood and their gradients with a PSF and / or supersampling against the float64 oracle --
     through the register-blocked sample-pair correlation (gl_corr_pair_kernel: supersample <= 2, effective kernel <= 32 taps
     wide; forward = stride-ss correlation, transpose = ss^2 decimated flipped sub-kernels) and through the tap-by-tap
@@ -602,6 +602,8 @@ def test_psf_supersample_vs_oracle(gl, ss, ksize, n, B):
     from gigalens_amd.simulator import SimulatorConfig
     from oracle import ref_torch as ref
     from tests.test_prior_host import default_prior
+    if (ss, ksize, n) == (1, 13, 60):  # batches beyond the launch's grid.z go out in slices: forced here to one pair per slice
+        monkeypatch.setenv("GIGALENS_HIP_CORR_MAXPAIRS", "1")
     phys = PhysicalModel([EPL(), Shear()], [SersicEllipse()], [SersicEllipse()])
     prior = default_prior()
     psf = _gauss_psf(ksize, 1.2 * ss) if ksize else None
