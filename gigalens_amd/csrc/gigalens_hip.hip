@@ -55,7 +55,11 @@ namespace {
 // (dynamic load balance: EPL trip counts differ per sample), but whole tiles per chunk.
 void chunking(const gl_model* m, int B, int* chunk, int* n_chunks) {
   const long long tile_px = (long long)WG * 4;  // whole tiles for every T in {1, 2, 4}
-  long long want = std::max<long long>(1, (m->target_wgs + B - 1) / B);
+  // chunks per sample: enough workgroups for one resident round of the chip (768 = 256 CUs x 3), and at most ~8192 pixels
+  // (16 pair tiles) per workgroup so the tail of the launch stays short -- measured at B = 64 .. 1024, 60^2 .. 256^2 px:
+  // never behind the older "2048 workgroups" rule, 2-5 % ahead of it at small batches.  GIGALENS_HIP_TARGET_WGS restores that rule.
+  long long want = std::max<long long>((768 + B - 1) / B, ((long long)m->N + 8191) / 8192);
+  if (m->target_wgs_set) want = std::max<long long>(1, (m->target_wgs + B - 1) / B);
   long long per = ((long long)m->N + want - 1) / want;
   per = std::max(tile_px, (per + tile_px - 1) / tile_px * tile_px);
   if (m->chunk_px_override > 0) per = m->chunk_px_override;  // experiments: GIGALENS_HIP_CHUNK_PX (a multiple of the kernel's tile)
@@ -585,6 +589,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     if (ok_c) m->cluster = ell ? 2 : 1;
   }
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
+  m->target_wgs_set = getenv("GIGALENS_HIP_TARGET_WGS") != nullptr;
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
   m->chunk_px_override = env_int("GIGALENS_HIP_CHUNK_PX", 0);
   m->dbg_flags = env_int("GIGALENS_HIP_DBGFLAGS", 0);

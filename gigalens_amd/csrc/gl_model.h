@@ -114,7 +114,8 @@ struct gl_model {
   int* d_lin_cols = nullptr;
   int tile = 2;          // pixels per thread per tile (template T) for forward-only launches
   int tile_grad = 2;     // ... and for launches that also produce gradients
-  int target_wgs = 2048;  // work decomposition target (>= 8 workgroups per CU)
+  int target_wgs = 2048;  // work decomposition target of GIGALENS_HIP_TARGET_WGS (see chunking())
+  bool target_wgs_set = false;
 };
 
 namespace glk {
