@@ -59,7 +59,9 @@ void chunking(const gl_model* m, int B, int* chunk, int* n_chunks) {
   // (16 pair tiles) per workgroup so the tail of the launch stays short -- measured at B = 64 .. 1024, 60^2 .. 256^2 px:
   // never behind the older "2048 workgroups" rule, 2-5 % ahead of it at small batches.  GIGALENS_HIP_TARGET_WGS restores that rule.
   long long want = std::max<long long>((768 + B - 1) / B, ((long long)m->N + 8191) / 8192);
-  if (m->target_wgs_set) want = std::max<long long>(1, (m->target_wgs + B - 1) / B);
+  // (the specialised compositions only: with hundreds to thousands of instructions per pixel -- interpreter and cluster
+  // kernels -- a workgroup's fixed costs vanish and more, smaller workgroups balance better: C6 4.83 vs 4.98 ms)
+  if (m->target_wgs_set || !m->static_id) want = std::max<long long>(1, (m->target_wgs + B - 1) / B);
   long long per = ((long long)m->N + want - 1) / want;
   per = std::max(tile_px, (per + tile_px - 1) / tile_px * tile_px);
   if (m->chunk_px_override > 0) per = m->chunk_px_override;  // experiments: GIGALENS_HIP_CHUNK_PX (a multiple of the kernel's tile)
