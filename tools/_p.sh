@@ -1,8 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python3 tools/bench_configs.py 2>/dev/null | python3 -c "
-import sys,json
-for l in sys.stdin:
-    try: r=json.loads(l)
-    except: continue
-    print(r['config'][:70], r['ms_per_step'])"
-timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/pt.log 2>&1; echo "rc=$?"; tail -2 gpurun_out/pt.log | cut -c1-200
+mkdir -p gpurun_out/r2u
+HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 tools/rehearse_2rank.py > gpurun_out/r2u/rehearse_2rank.log 2>&1; echo "rehearse rc=$?"; tail -5 gpurun_out/r2u/rehearse_2rank.log | cut -c1-200
