@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2u
-HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 tools/rehearse_2rank.py > gpurun_out/r2u/rehearse_2rank.log 2>&1; echo "rehearse rc=$?"; tail -5 gpurun_out/r2u/rehearse_2rank.log | cut -c1-200
+time python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; python3 -c "
+import json
+r=json.loads(open('gpurun_out/bench_final.json').read().strip().splitlines()[-1])
+print(r['value'], r['ms_per_step'], r['roofline']['kernel_ms'], r['roofline']['frac'], r['roofline']['valu_flop_frac'], r['cpu_baseline']['value'], r['cpu_baseline']['sample'][:60])"
+time python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline | tail -1 | cut -c1-200
