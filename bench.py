@@ -135,19 +135,47 @@ def _free_port():
     return port
 
 
+def visible_gpus():
+    """GPUs visible to this process WITHOUT touching the HIP runtime (the parent of a multi-rank run must stay GPU-free so
+    that its child ranks start from a clean process): KFD topology nodes with SIMDs, narrowed by the *_VISIBLE_DEVICES
+    variables.  None when the topology cannot be read (then every rank validates its own device instead)."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def launch_ranks(args):
-    """--gpus N without a launcher: start the N ranks as a CHILD process tree (the parent never initialises a GPU and
-    never replaces itself); exit with the child's code."""
-    n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
-    if n_dev < args.gpus:
+    """--gpus N without a launcher: start the N ranks as a CHILD process tree (the parent never initialises a GPU -- it
+    counts devices from the KFD topology in sysfs, not through HIP -- and never replaces itself); exit with the child's code."""
+    n_dev = visible_gpus()
+    if n_dev is not None and n_dev < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible; refusing to run fewer ranks "
                          "than asked for\n")
         sys.exit(2)
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd, env=env))
+    sys.exit(subprocess.call(cmd, env=dict(os.environ)))
+
+
+def refuse_tuning_environment():
+    """The line must describe the shipped configuration: any GIGALENS_HIP_* override (kernel selection, decomposition, the
+    dissection knobs of -DGL_EXPERIMENTS builds) makes the run something else.  GIGALENS_HIP_LIB (which library file) and
+    GIGALENS_DIST_BACKEND / GIGALENS_CPU_THREADS (host-side) are not overrides of the measured path."""
+    bad = sorted(k for k in os.environ if k.startswith("GIGALENS_HIP_") and k != "GIGALENS_HIP_LIB")
+    if bad:
+        sys.stderr.write("bench.py: refusing to measure with kernel overrides in the environment: " + ", ".join(bad) + "\n")
+        sys.exit(3)
 
 
 EPL_SERIES_TOL = 1e-9  # csrc/gl_profiles.h epl_series_tol<float>(): where the float32 kernels stop the EPL angular series
@@ -219,6 +247,7 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    refuse_tuning_environment()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)  # does not return
 

@@ -146,6 +146,7 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.out_scale = m->conversion_factor;
   a.partial = w.partial;
   a.shp_tab = m->d_shp_tab;
+  a.shp_tab2 = m->d_shp_tab2;
   a.nfw_tab = m->d_nfw_tab;
   a.dbg = m->dbg_flags;
   a.shp_stride = m->shp_stride;
@@ -236,7 +237,7 @@ int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, co
   bool basic = true;
   for (const CompDesc& c : m->comps)
     basic = basic && (c.kind == K_EPL || c.kind == K_SIE || c.kind == K_SHEAR || c.kind == K_SIS || c.kind == K_SERSIC || c.kind == K_SERSIC_ELLIPSE);
-  const int nc = (m->dbg_flags & 8) ? -1 : n_chunks;
+  const int nc = GL_DBG(m->dbg_flags, 8) ? -1 : n_chunks;
   if (basic) hipLaunchKernelGGL(gl_finalize_kernel<true>, dim3(B), dim3(128), shmem, stream, m->d_comps, f, w.partial, nc);
   else hipLaunchKernelGGL(gl_finalize_kernel<false>, dim3(B), dim3(128), shmem, stream, m->d_comps, f, w.partial, nc);
   GL_HIP(hipGetLastError());
@@ -304,7 +305,8 @@ PostArgs post_args(const gl_model* m, float scale) {
 }
 // supersampled pre-PSF image S [B,Hs,Ws] -> final image [B,H,W] (x conversion factor)
 // the register-blocked pair kernel on one plan (gl_post.hip.h); false: no instantiation for this kernel width / stride
-bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* out, float scale, hipStream_t stream, int dbg = 0) {
+bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* out, float scale, hipStream_t stream, int dbg = 0,
+                 int max_pairs_env = 0) {
   if (!pl.ok) return false;
   CorrArgs a = pl.args;
   a.B = B;
@@ -317,12 +319,11 @@ bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* ou
   if (sh > 64 * 1024) return false;
   // grid.z carries (row class, sample pair): at most 65535 per launch -- larger batches (the basis stack of lstsq_simulate is
   // B x D images) go out in slices
-  const int max_pairs_env = env_int("GIGALENS_HIP_CORR_MAXPAIRS", 0);  // tests: force the slicing
   const int max_pairs = max_pairs_env > 0 ? max_pairs_env : 65535 / a.n_class;
   if ((B + 1) / 2 > max_pairs) {
     for (int b_lo = 0; b_lo < B; b_lo += 2 * max_pairs) {
       const int nb = std::min(B - b_lo, 2 * max_pairs);
-      if (!launch_corr(pl, nb, in + (size_t)b_lo * a.Hi * a.Wi, out + (size_t)b_lo * a.Hout * a.Wout, scale, stream, dbg)) return false;
+      if (!launch_corr(pl, nb, in + (size_t)b_lo * a.Hi * a.Wi, out + (size_t)b_lo * a.Hout * a.Wout, scale, stream, dbg, max_pairs_env)) return false;
     }
     return true;
   }
@@ -345,7 +346,7 @@ bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* ou
 }
 
 int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t stream, float scale = -1.f) {
-  if (launch_corr(m->corr_fwd, B, S, out, scale < 0.f ? m->conversion_factor : scale, stream, m->dbg_flags)) {
+  if (launch_corr(m->corr_fwd, B, S, out, scale < 0.f ? m->conversion_factor : scale, stream, m->dbg_flags, m->corr_max_pairs)) {
     GL_HIP(hipGetLastError());
     return GL_OK;
   }
@@ -360,7 +361,7 @@ int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t s
 }
 // cotangent of the final image [B,H,W] -> cotangent of S [B,Hs,Ws]
 int post_bwd(const gl_model* m, int B, const float* gP, float* gS, hipStream_t stream) {
-  if (launch_corr(m->corr_bwd, B, gP, gS, m->conversion_factor, stream, m->dbg_flags)) {
+  if (launch_corr(m->corr_bwd, B, gP, gS, m->conversion_factor, stream, m->dbg_flags, m->corr_max_pairs)) {
     GL_HIP(hipGetLastError());
     return GL_OK;
   }
@@ -566,6 +567,17 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     }
     if (!ok_row || off != m->A) m->pair = 0;
   }
+  // gl_shp.hip.h addresses the row as [NSTAT | lenses | lens lights | shapelet] in closed form and needs a table-mode model's pair table
+  {
+    int off = NSTAT;
+    bool ok_row = true;
+    for (int i = 0; i < n_comp; ++i) {
+      ok_row = ok_row && m->comps[i].a_off == off;
+      off += static_nacc(m->comps[i].kind);
+    }
+    m->shp_kernel = env_int("GIGALENS_HIP_SHP", 1) && env_int("GIGALENS_HIP_PAIR", 1) && m->static_id && ok_row && n_src == 1 &&
+                    m->comps.back().kind == K_SHAPELETS;
+  }
   m->light_spherical = n_comp > n_lens;
   for (int i = n_lens; i < n_comp; ++i) m->light_spherical = m->light_spherical && m->comps[i].kind == K_SERSIC;
   if (!m->tile_grad) m->tile_grad = m->static_id ? 1 : 2;  // measured: T=1 wins once the VJP state lives in registers
@@ -593,8 +605,29 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   m->target_wgs_set = getenv("GIGALENS_HIP_TARGET_WGS") != nullptr;
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
+#ifdef GL_EXPERIMENTS
+  // dissection builds only (hipcc -DGL_EXPERIMENTS; never __graft_entry__.build()): work-skipping flags and a raw chunk size
   m->chunk_px_override = env_int("GIGALENS_HIP_CHUNK_PX", 0);
   m->dbg_flags = env_int("GIGALENS_HIP_DBGFLAGS", 0);
+  if (m->chunk_px_override < 0 || m->chunk_px_override % (WG * 4) != 0) {
+    const int bad = m->chunk_px_override;
+    delete m;
+    return fail(GL_EINVAL, "GIGALENS_HIP_CHUNK_PX=%d is not a positive multiple of the tile (%d pixels)", bad, WG * 4);
+  }
+  if (m->dbg_flags || m->chunk_px_override)
+    fprintf(stderr, "libgigalens_hip: EXPERIMENT BUILD with GIGALENS_HIP_DBGFLAGS=%d GIGALENS_HIP_CHUNK_PX=%d -- results are not valid\n",
+            m->dbg_flags, m->chunk_px_override);
+#else
+  // the shipped library has no work-skipping paths: a stray dissection variable is an error, not a silently ignored hint
+  for (const char* name : {"GIGALENS_HIP_DBGFLAGS", "GIGALENS_HIP_CHUNK_PX"}) {
+    const char* v = getenv(name);
+    if (v && *v && atoi(v) != 0) {
+      delete m;
+      return fail(GL_EINVAL, "%s is set but this library was built without -DGL_EXPERIMENTS (the dissection knobs do not exist in it)", name);
+    }
+  }
+#endif
+  m->corr_max_pairs = env_int("GIGALENS_HIP_CORR_MAXPAIRS", 0);  // tests: force the slicing of the PSF launches (read once)
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
@@ -627,6 +660,9 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     (void)sh_nmax;  // always the full n_max = 10 table: stride 12, two rows of a node pair = six aligned float4
     glh::build_shapelet_table(GL_SHAPELETS_NMAX_CAP, tab, &m->shp_stride);
     ok = ok && up((void**)&m->d_shp_tab, tab.data(), tab.size() * sizeof(float));
+    std::vector<float> tab2;  // gl_shp.hip.h: values | differences per node, order pairs in loaded register pairs
+    glh::build_shapelet_pair_table(tab, m->shp_stride, GL_SHAPELETS_NMAX_CAP, SH_SQ, tab2);
+    ok = ok && up((void**)&m->d_shp_tab2, tab2.data(), tab2.size() * sizeof(float));
   }
   m->has_post = grid->psf != nullptr || grid->supersample != 1;
   if (m->has_post) {
@@ -729,7 +765,8 @@ int gl_model_set_timing(gl_model* m, int slots) {
   for (hipEvent_t e : m->evs) (void)hipEventDestroy(e);
   m->evs.clear();
   m->timing_slots = 0;
-  m->timing_count = m->timing_calls = 0;
+  m->timing_count = 0;
+  m->timing_calls = 0;
   m->evs.reserve((size_t)2 * slots);
   for (int i = 0; i < 2 * slots; ++i) {
     hipEvent_t e;
@@ -751,7 +788,7 @@ int gl_model_set_timing_stride(gl_model* m, int stride) {
 int gl_model_last_main_ms(gl_model* m, float* ms) {
   if (!m || !ms) return fail(GL_EINVAL, "null argument");
   if (!m->timing_slots || !m->timing_count) return fail(GL_EINVAL, "no timed main launch on this model");
-  const int slot = (int)((m->timing_count - 1) % m->timing_slots);
+  const int slot = (int)((m->timing_count.load() - 1) % m->timing_slots);
   GL_HIP(hipEventSynchronize(m->evs[2 * slot + 1]));
   GL_HIP(hipEventElapsedTime(ms, m->evs[2 * slot], m->evs[2 * slot + 1]));
   return GL_OK;
@@ -761,23 +798,25 @@ int gl_model_timing_drain(gl_model* m, float* ms, int cap, int* n_out) {
   if (!m || !ms || !n_out || cap < 0) return fail(GL_EINVAL, "bad argument");
   *n_out = 0;
   if (!m->timing_slots) return fail(GL_EINVAL, "timing is not enabled on this model");
-  const long long have = std::min<long long>(m->timing_count, m->timing_slots);
-  const long long first = m->timing_count - have;  // oldest launch still in the ring
+  const long long count = m->timing_count.load();
+  const long long have = std::min<long long>(count, m->timing_slots);
+  const long long first = count - have;  // oldest launch still in the ring
   int n = 0;
-  for (long long k = first; k < m->timing_count && n < cap; ++k, ++n) {
+  for (long long k = first; k < count && n < cap; ++k, ++n) {
     const int slot = (int)(k % m->timing_slots);
     GL_HIP(hipEventSynchronize(m->evs[2 * slot + 1]));
     GL_HIP(hipEventElapsedTime(&ms[n], m->evs[2 * slot], m->evs[2 * slot + 1]));
   }
   *n_out = n;
-  m->timing_count = m->timing_calls = 0;
+  m->timing_count = 0;
+  m->timing_calls = 0;
   return GL_OK;
 }
 
 int gl_model_last_main_kernel(const gl_model* m, char* buf, size_t cap) {
   if (!m || !buf || cap == 0) return fail(GL_EINVAL, "bad argument");
   if (!m->last_main_fn) return fail(GL_EINVAL, "no main kernel has been launched on this model yet");
-  const char* name = hipKernelNameRefByPtr(m->last_main_fn, nullptr);
+  const char* name = hipKernelNameRefByPtr(m->last_main_fn.load(), nullptr);
   if (!name) return fail(GL_ELAUNCH, "hipKernelNameRefByPtr returned no name");
   snprintf(buf, cap, "%s", name);
   return GL_OK;
@@ -791,6 +830,7 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_gy) (void)hipFree(m->d_gy);
   if (m->d_pix) (void)hipFree(m->d_pix);
   if (m->d_shp_tab) (void)hipFree(m->d_shp_tab);
+  if (m->d_shp_tab2) (void)hipFree(m->d_shp_tab2);
   if (m->d_nfw_tab) (void)hipFree(m->d_nfw_tab);
   if (m->d_corr_k) (void)hipFree(m->d_corr_k);
   if (m->d_psf) (void)hipFree(m->d_psf);

@@ -90,6 +90,7 @@ struct MainArgs {
   float* partial;  // [B][n_chunks][A]
   const float* shp_tab;
   int shp_stride;
+  const float* shp_tab2;  // gl_shp.hip.h: per node the values of orders 0..11 then the differences to the next node; node 6000 = zeros
   const int* order;  // cost-ordered dispatch: blockIdx.y -> sample index (heaviest first), or null
   unsigned parts;    // forward-only partial renders (tf/simulator.py:242-328): bit0 deflect, bit1 lens light, bit2 sources
   // galaxy catalogues (K_SCALED): per-galaxy static blocks [G][DP_NS], per-(sample, galaxy) blocks [B][G][GM_ND]
@@ -101,8 +102,16 @@ struct MainArgs {
   int n_lin;         // IMG_BASIS: channels of the stack  img[B][n_lin][img_stride]
   const SeriesDev* series;
   const float* nfw_tab;  // models with NFW lenses: the shared h(X) table (gl_host_tables.h), [kNfwNodes][2]; else null
-  int dbg;  // experiments (GIGALENS_HIP_DBGFLAGS): 1 skip the pixel tiles, 2 skip the epilogue reductions, 4 skip the constant staging
+  int dbg;  // -DGL_EXPERIMENTS builds only (GIGALENS_HIP_DBGFLAGS): 1 skip the pixel tiles, 2 skip the epilogue reductions, 4 skip the constant staging
 };
+
+// The work-skipping dissection knobs exist only in builds made with -DGL_EXPERIMENTS (never by __graft_entry__.build()):
+// in the shipped library GL_DBG is a compile-time false and gl_model_create refuses the environment variables.
+#ifdef GL_EXPERIMENTS
+#define GL_DBG(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define GL_DBG(flags, bit) false
+#endif
 
 // ---- wave64 sum, result valid in lane 63 (DPP row shifts + row broadcasts, no LDS) -------------
 __device__ __forceinline__ float dpp_add(float v, int ctrl, int row_mask) {
@@ -1181,7 +1190,9 @@ template <bool BASIC>
 __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __restrict__ comps, FinArgs f,
                                                           const float* __restrict__ partial, int n_chunks) {
   extern __shared__ float s[];  // [A] accumulators, [P] parameter gradients, [d_z] prior terms, [3][d_z] bijector / prior derivatives
+#ifdef GL_EXPERIMENTS
   if (n_chunks < 0) return;  // GIGALENS_HIP_DBGFLAGS & 8: the cost of the bare launch (results undefined)
+#endif
   finalize_sample<128, BASIC>(comps, f, partial, n_chunks, blockIdx.x, threadIdx.x, s);
 }
 
@@ -1406,7 +1417,7 @@ __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float*
     case K_SERSIC: { float d[SER_ND + 2]; sersic_prep<float>(p, false, d); o0 = sersic_fwd(d, px, py); } break;
     case K_SERSIC_ELLIPSE: { float d[SER_ND + 2]; sersic_prep<float>(p, true, d); o0 = sersic_fwd(d, px, py); } break;
     case K_SHAPELETS: {
-      float d[SHP_AMP + 68];
+      float d[SHP_SQ + SH_SQ * SH_SQ];
       shapelets_prep<float>(p, cd.iparam, d);
       o0 = shapelets_fwd<float, SH_CAP>(d, shp_tab, shp_stride, cd.flags & 1u, px, py);
     } break;

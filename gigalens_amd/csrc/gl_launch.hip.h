@@ -7,6 +7,7 @@
 #include "gl_static.hip.h"
 #include "gl_pair.hip.h"
 #include "gl_cluster.hip.h"
+#include "gl_shp.hip.h"
 
 namespace glk {
 
@@ -56,6 +57,22 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     }
   }
 #undef GL_PAIR
+  // lenses | [Sersic lens light] | one shapelet source: the order-pair / matrix-pipe kernel (gl_shp.hip.h), every mode
+  if (m->shp_kernel && (m->static_id == ST_EPLSHEAR_SHAPELETS || m->static_id == ST_EPLSHEAR_SERSIC_SHAPELETS)) {
+    constexpr int NPS = SH_SQ / 2;
+    const size_t epi = (size_t)(16 * m->Apad + 4 * 16 * 17) * sizeof(float);
+    const size_t sh = (size_t)((m->D + 3) & ~3) * sizeof(float) + std::max(shp_exchange_bytes(NPS), epi);
+    const bool interp = (m->comps.back().flags & GL_FLAG_SHAPELETS_INTERPOLATE) != 0;
+#define GL_SHP(LLK_, I_)                                                                                  \
+  do {                                                                                                    \
+    m->last_main_fn = (const void*)&gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_>;                     \
+    hipLaunchKernelGGL((gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_>), grid, block, sh, stream, a);   \
+  } while (0)
+    if (m->static_id == ST_EPLSHEAR_SHAPELETS) { if (interp) GL_SHP(C_None, true); else GL_SHP(C_None, false); }
+    else { if (interp) GL_SHP(C_SersicE, true); else GL_SHP(C_SersicE, false); }
+#undef GL_SHP
+    return true;
+  }
 #define GL_LAUNCH(TT, WW, LK, CK, SK)                                                        \
   do {                                                                                       \
     m->last_main_fn = (const void*)&gl_static_kernel<MODE, TT, WW, LK, CK, SK>;              \
@@ -94,8 +111,8 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
   dim3 grid(n_chunks, B), block(WG);
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   // every timing_stride-th main launch is bracketed by an event pair (an event record costs ~2.5 us of stream time)
-  const bool timed = m->timing_slots && (m->timing_calls++ % m->timing_stride) == 0;
-  const int slot = timed ? (int)(m->timing_count % m->timing_slots) : 0;
+  const bool timed = m->timing_slots && (m->timing_calls.fetch_add(1) % m->timing_stride) == 0;
+  const int slot = timed ? (int)(m->timing_count.fetch_add(1) % m->timing_slots) : 0;  // the slot is claimed here
   if (timed) GL_HIP(hipEventRecord(m->evs[2 * slot], stream));
 #define GL_MAIN(TT, S_, F_)                                                              \
   do {                                                                                   \
@@ -141,7 +158,6 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
 #undef GL_MAIN
   if (timed) {
     GL_HIP(hipEventRecord(m->evs[2 * slot + 1], stream));
-    ++m->timing_count;
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

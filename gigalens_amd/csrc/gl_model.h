@@ -6,6 +6,8 @@
 
 #include <vector>
 
+#include <atomic>
+
 #include "../../include/gigalens_hip.h"
 #include "gl_kernels.hip.h"
 
@@ -39,7 +41,7 @@ struct CorrArgs {
   int Hi, Wi;          // input image
   int Hout, Wout, os;  // output image and the placement stride of a class's outputs
   float scale;
-  int dbg;  // experiments (GIGALENS_HIP_DBGFLAGS): 16 skip the tile fill, 32 skip the multiply-add loop
+  int dbg;  // -DGL_EXPERIMENTS builds only (GIGALENS_HIP_DBGFLAGS): 16 skip the tile fill, 32 skip the multiply-add loop
   CorrClass cls[16];
 };
 }  // namespace glk
@@ -57,9 +59,11 @@ struct gl_model {
   float* d_gy = nullptr;
   int* d_pix = nullptr;
   float* d_shp_tab = nullptr;
+  float* d_shp_tab2 = nullptr;  // gl_shp.hip.h layout (values | differences per node)
   float* d_nfw_tab = nullptr;  // models with NFW lenses: h(X) = g(X) / X^2 on the float format's own grid (gl_host_tables.h)
-  int chunk_px_override = 0;
-  int dbg_flags = 0;
+  int chunk_px_override = 0;  // -DGL_EXPERIMENTS builds only
+  int dbg_flags = 0;          // -DGL_EXPERIMENTS builds only
+  int corr_max_pairs = 0;     // GIGALENS_HIP_CORR_MAXPAIRS, read once at gl_model_create
   bool has_nfw = false;
   size_t nfw_lds = 0;          // bytes of that table in a main kernel's LDS
   int shp_stride = 0;
@@ -93,9 +97,10 @@ struct gl_model {
   // measurement hooks (gl_model_set_timing): a ring of event pairs around the main-kernel launches, and the host
   // function of the most recent main launch (gl_model_last_main_kernel)
   int timing_slots = 0, timing_stride = 1;
-  mutable long long timing_count = 0, timing_calls = 0;
+  // (atomics: two host threads may drive one model on different streams; each timed launch claims its ring slot)
+  mutable std::atomic<long long> timing_count{0}, timing_calls{0};
   std::vector<hipEvent_t> evs;  // 2 * timing_slots
-  mutable const void* last_main_fn = nullptr;
+  mutable std::atomic<const void*> last_main_fn{nullptr};
   // galaxy catalogues of the GL_SCALED components (gl_model_set_catalogue)
   struct Cat { CatDev dev; std::vector<float> table; };
   std::vector<Cat> cats;
@@ -112,6 +117,7 @@ struct gl_model {
   // linear amplitudes (lstsq_simulate): channel k of the basis stack <-> packed parameter column
   std::vector<int> lin_cols;
   int* d_lin_cols = nullptr;
+  int shp_kernel = 0;    // lenses | [Sersic lens lights] | one shapelet source: served by gl_shp.hip.h (GIGALENS_HIP_SHP=0: the round-2 kernels)
   int tile = 2;          // pixels per thread per tile (template T) for forward-only launches
   int tile_grad = 2;     // ... and for launches that also produce gradients
   int target_wgs = 2048;  // work decomposition target of GIGALENS_HIP_TARGET_WGS (see chunking())

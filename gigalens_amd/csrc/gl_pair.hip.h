@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
   const CompDesc* __restrict__ comps = a.comps;
   const float* __restrict__ gder = a.derived + (size_t)b * a.D;
-  if (!(a.dbg & 4)) {
+  if (!GL_DBG(a.dbg, 4)) {
     if (a.D <= WG) {  // the usual case (EPL at niter = 50: D = 244): one predicated load per thread, no loop scaffolding
       if (tid < a.D) s_d[tid] = gder[tid];
     } else {
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   {
     const bool plain = !has_mask;
     int base = p0;
-    if (a.dbg & 1) base = p1;
+    if (GL_DBG(a.dbg, 1)) base = p1;
     if (plain)
       for (; base + WG * W <= p1; base += WG * W) tile(base, std::false_type{});
     for (; base < p1; base += WG * W) tile(base, std::true_type{});
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   float* s_row = s_acc + (tid >> 6) * a.Apad;
   const bool last_lane = (tid & 63) == 63;
   auto put = [&](float v, int idx) {
-    if (!(a.dbg & 2)) v = wave_sum63(v);
+    if (!GL_DBG(a.dbg, 2)) v = wave_sum63(v);
     if (last_lane) s_row[idx] = v;
   };
   put((MODE == LL_FWD || MODE == LL_GRAD) ? hsum(st0) : 0.f, 0);

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float*
   // fill: one wavefront per tile row, lanes along the row (no index division, row-contiguous global reads); all of a wavefront's
   // loads (up to 16 per lane) are issued before the first LDS write: one global round trip per wavefront instead of one per row
   constexpr int NW = NT / 64, CPASS = (TC + 63) / 64, FR = 16 / CPASS;  // 16 float2 of loads in flight per lane
-  for (int rb = (p.dbg & 16) ? TR : (int)(threadIdx.x >> 6); rb < TR; rb += NW * FR) {
+  for (int rb = GL_DBG(p.dbg, 16) ? TR : (int)(threadIdx.x >> 6); rb < TR; rb += NW * FR) {
     float2 v[FR][CPASS];
 #pragma unroll
     for (int f = 0; f < FR; ++f) {
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float*
     for (int o = 0; o < CORR_OX; ++o) acc[j][o] = v2{0.f, 0.f};
   const float2* base = ctile + (ti * ST) * TCp + tg * CORR_OX * ST;
   const float* __restrict__ kc = p.k + c.koff;
-  for (int u = (p.dbg & 32) ? c.KH : g; u < c.KH; u += KS) {
+  for (int u = GL_DBG(p.dbg, 32) ? c.KH : g; u < c.KH; u += KS) {
     const float2* row = base + u * TCp;
     v2 w[WIN];
 #pragma unroll

@@ -58,6 +58,10 @@ enum { SER_CX = 0, SER_CY, SER_C, SER_S, SER_SQ, SER_ISQ, SER_INVRS, SER_INVN, S
 enum { SERA_CX = 0, SERA_CY, SERA_PHI, SERA_SQ, SERA_L, SERA_INVN, SERA_BN, SERA_IE, SER_NACC };
 // SHAPELETS
 enum { SHP_CX = 0, SHP_CY, SHP_IB, SHP_NMAX, SHP_AMP = 4 };
+// behind the zero-padded amplitude triangle: the same amplitudes as a zero-padded SQUARE matrix a[n1][n2], row-major with
+// SH_SQ columns -- gl_shp.hip.h reads its rows as SGPR pairs (n2 = 2j, 2j + 1)
+constexpr int SH_SQ = 12;
+constexpr int SHP_SQ = SHP_AMP + ((SH_MAXL + 3) & ~3);
 enum { SHPA_CX = 0, SHPA_CY, SHPA_IB, SHPA_AMP = 3 };
 
 GL_HD int sh_layers(int n_max) { return (n_max + 1) * (n_max + 2) / 2; }
@@ -100,7 +104,7 @@ GL_HD int kind_num_derived(int kind, int iparam) {
     case K_CORE_SERSIC: return 16;
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_ND + 2;
-    case K_SHAPELETS: return SHP_AMP + ((SH_MAXL + 3) & ~3);  // amplitude triangle zero-padded to n_max = 10
+    case K_SHAPELETS: return SHP_SQ + SH_SQ * SH_SQ;  // amplitude triangle zero-padded to n_max = 10, then the square matrix
   }
   return -1;
 }
@@ -756,6 +760,11 @@ template <class R> GL_HD void shapelets_prep(const R* p, int n_max, R* d) {
   int L = sh_layers(n_max);
   for (int i = 0; i < L; ++i) d[SHP_AMP + i] = p[3 + i];
   for (int i = L; i < ((SH_MAXL + 3) & ~3); ++i) d[SHP_AMP + i] = (R)0;  // the separable kernels run the full triangle
+  for (int n1 = 0; n1 < SH_SQ; ++n1)
+    for (int n2 = 0; n2 < SH_SQ; ++n2) {
+      const int n = n1 + n2;
+      d[SHP_SQ + n1 * SH_SQ + n2] = n <= n_max ? p[3 + n * (n + 1) / 2 + n2] : (R)0;
+    }
 }
 
 // orthonormal Gauss-Hermite functions without the Gaussian: X_n = H_n / sqrt(2^n sqrt(pi) n!)

@@ -1,0 +1,426 @@
+// gl_shp.hip.h -- the specialised kernel for "lenses | [Sersic lens lights] | ONE shapelet source" models (BASELINE config 3 and
+// the reference's shapelets-demo model; tf/profiles/light/shapelets.py:20-85).
+//
+// Round-3 redesign of the shapelet render / VJP (the scalar one-pixel-per-thread kernel it replaces spent 574 VALU
+// instructions per pixel, 69 accumulator registers per lane and ran at 2 waves per SIMD):
+//   * lens side in pixel-PAIR form (gl_vec.hip.h): the ray-shoot, the chi^2 terms and the lens VJP issue as packed fp32.
+//   * shapelet side one pixel at a time, packed over ORDER pairs: the interpolation table stores, per node, the values of
+//     orders (0 .. 2 NP - 1) followed by the differences to the next node, so a coordinate costs six 16-byte loads and NP
+//     packed FMAs -- the loaded register pairs ARE the packed operands (orders 2j, 2j+1), no shuffles.
+//   * ONE contraction serves the value and both derivatives: with s_n2 = sum_n1 a(n1,n2) X_n1 and s'_n2 the same sum over
+//     the derivative basis X'_n1,   S = sum Y s,  dS/du = sum Y s',  dS/dv = sum Y' s.   The amplitude matrix is read row by row
+//     through scalar loads (SGPR pairs a(n1, 2j..2j+1): shapelets_prep writes the zero-padded square matrix behind the
+//     triangle), X_n1 is a broadcast half of a register pair: 2 x 36 + 18 packed FMAs per pixel where the separable form of
+//     round 2 spent 242 scalar ones.
+//   * the amplitude gradient  G(n1,n2) = sum_pixels gS X_n1 Y_n2  is a rank-1 update per pixel -- a GEMM with the pixels as
+//     the contraction index.  It runs on the matrix pipe in exact fp32 (v_mfma_f32_16x16x4_f32: same arithmetic as an FMA
+//     chain): each wave parks (gS X) and Y of its pixels in LDS as order-pair planes [j][pixel][2] (conflict-free 8-byte
+//     stores) and reads them back transposed -- lane (m, k) = order m of pixel 4 kb + k, conflict-free 4-byte reads: plane
+//     stride = 4 mod 32 banks -- as the A and B operands of one MFMA per four pixels.  G lives in FOUR accumulator registers
+//     per lane instead of 66 VGPRs, co-issues with the vector work of the other waves, and the 66-value epilogue reduction
+//     of the scalar kernel disappears (one 16 x 16 tile per wave, summed over the four waves in fixed order).
+// Bitwise reproducible like every other kernel of the path: no atomics, fixed summation order.
+#pragma once
+#include "gl_pair.hip.h"
+
+namespace glk {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// dwords per order-pair plane of a wave's exchange buffer: 128 pixels (two per lane) x 2 + 4 pad: stride = 4 (mod 32 banks)
+constexpr int SHX_PLANE = 128 * 2 + 4;
+__host__ __device__ constexpr size_t shp_exchange_bytes(int np) { return (size_t)4 /*waves*/ * 2 /*gX, Y*/ * np * SHX_PLANE * sizeof(float); }
+
+template <int NP> struct ShpPix {
+  v2f X[NP];  // basis along u, order pairs; multiplied by gS before it is parked for the MFMA pass
+  float S, Su, Sv, u, v, dx, dy, fac;
+};
+
+// table row of one coordinate: NP pairs of values at the node below and NP pairs of differences to the next node
+template <int NP>
+__device__ __forceinline__ void shp_row(const float* __restrict__ tab, float u, v2f (&val)[NP], v2f (&dif)[NP], float& tt) {
+  const float scale = (float)(SH_NODES - 1) / 10.f;
+  const float fi = (u + 5.f) * scale;  // tfp.math.interp_regular_1d_grid on [-5, 5], fill 0 outside (shapelets.py:58-60)
+  const bool inside = (fi >= 0.f) && (fi <= (float)(SH_NODES - 1));
+  const float fic = clamp_(fi, 0.f, (float)(SH_NODES - 1));
+  const float fb = fmin_(floor_(fic), (float)(SH_NODES - 2));  // the last node belongs to the last interval (t = 1)
+  tt = fic - fb;
+  const unsigned row = inside ? (unsigned)(int)fb : (unsigned)SH_NODES;  // outside (or NaN): the zero row appended to the table
+  // 32-bit byte offset from the (scalar) table base: one VALU for the address, 4 NP floats per node
+  const float4* __restrict__ r = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + row * (unsigned)(16 * NP));
+#pragma unroll
+  for (int q = 0; q < NP / 2; ++q) {
+    const float4 a = r[q], b = r[NP / 2 + q];
+    val[2 * q] = v2f{a.x, a.y}; val[2 * q + 1] = v2f{a.z, a.w};
+    dif[2 * q] = v2f{b.x, b.y}; dif[2 * q + 1] = v2f{b.z, b.w};
+  }
+}
+
+// direct mode (shapelets.py:67-85): normalised Hermite recurrence, X'_n = sqrt(2n) X_{n-1}; orders above n_max stay zero
+template <int NP>
+__device__ __forceinline__ void shp_hermite(float u, int n_max, v2f (&val)[NP], v2f (&dif)[NP]) {
+  float X[2 * NP], dX[2 * NP];
+  X[0] = 0.75112554446494248286f;
+  dX[0] = 0.f;
+#pragma unroll
+  for (int n = 1; n < 2 * NP; ++n) {
+    const float a = (float)__builtin_sqrt(2.0 / n), bc = (float)__builtin_sqrt((n - 1.0) / n), dc = (float)__builtin_sqrt(2.0 * n);
+    const float xn = a * u * X[n - 1] - (n >= 2 ? bc * X[n - 2] : 0.f);
+    X[n] = n <= n_max ? xn : 0.f;
+    dX[n] = n <= n_max ? dc * X[n - 1] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    val[j] = v2f{X[2 * j], X[2 * j + 1]};
+    dif[j] = v2f{dX[2 * j], dX[2 * j + 1]};
+  }
+}
+
+// ---- forward of one pixel, in two steps so that the kernel can put the table gathers of BOTH pixels of a lane in flight before
+// either chain starts (a gather is a full trip to the L2; issued one row at a time the chains are latency-bound) ------------------
+template <int NP> struct ShpRows { v2f xv[NP], xd[NP], yv[NP], yd[NP]; float tu, tv; };
+
+template <int NP, bool INTERP>
+__device__ __forceinline__ void shp_pixel_gather(const float* d, const float* __restrict__ tab, float px, float py, ShpPix<NP>& st,
+                                                 ShpRows<NP>& r) {
+  const float ib = d[SHP_IB];
+  st.dx = px - d[SHP_CX];
+  st.dy = py - d[SHP_CY];
+  st.u = st.dx * ib;
+  st.v = st.dy * ib;
+  if constexpr (INTERP) {
+    shp_row<NP>(tab, st.u, r.xv, r.xd, r.tu);
+    shp_row<NP>(tab, st.v, r.yv, r.yd, r.tv);
+  }
+}
+
+//   gA : the sample's zero-padded square amplitude matrix [2NP][2NP] in GLOBAL memory (wave-uniform address: scalar loads)
+//   ybuf: this lane's slot of the wave's Y planes (dword address of plane 0): Y is parked there for the MFMA pass
+template <int NP, bool INTERP, bool GRAD>
+__device__ __forceinline__ float shp_pixel_fwd(const float* d, const v2f* __restrict__ gA, ShpRows<NP>& r, float* __restrict__ ybuf,
+                                               ShpPix<NP>& st) {
+  if constexpr (INTERP) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) st.X[j] = __builtin_elementwise_fma(v2f(r.tu), r.xd[j], r.xv[j]);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) r.yv[j] = __builtin_elementwise_fma(v2f(r.tv), r.yd[j], r.yv[j]);
+    st.fac = 1.f;
+  } else {
+    const int n_max = (int)d[SHP_NMAX];
+    shp_hermite<NP>(st.u, n_max, st.X, r.xd);
+    shp_hermite<NP>(st.v, n_max, r.yv, r.yd);
+    st.fac = exp_(-(st.u * st.u + st.v * st.v) * 0.5f);  // shapelets.py:70
+  }
+  if constexpr (GRAD) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) *reinterpret_cast<v2f*>(ybuf + j * SHX_PLANE) = r.yv[j];
+  }
+  // s_n2 = sum_n1 a(n1, n2) X_n1 (and s'_n2 with X'_n1), two n2 per register; rows beyond the triangle are zero and skipped
+  v2f s[NP], sd[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) { s[j] = v2f(0.f); sd[j] = v2f(0.f); }
+  // (The 72 matrix entries are scalar loads the compiler issues together; with the kernel's pointers that is more SGPRs than a
+  // wave has, so some pointers are parked in VGPR lanes: ~60 v_readlane per tile.  Splitting the rows into dependent groups, a
+  // scheduling barrier, or a laundered pointer all made the allocation worse: measured, see DESIGN.md.)
+#pragma unroll
+  for (int n1 = 0; n1 < 2 * NP - 1; ++n1) {
+    const float xn = (n1 & 1) ? st.X[n1 >> 1].y : st.X[n1 >> 1].x;
+    const float dn = (n1 & 1) ? r.xd[n1 >> 1].y : r.xd[n1 >> 1].x;
+#pragma unroll
+    for (int j = 0; 2 * j + n1 < 2 * NP - 1; ++j) {  // n2 = 2j, 2j+1 with n1 + n2 <= 2 NP - 2 (the largest n_max this NP serves)
+      const v2f arow = gA[n1 * NP + j];
+      s[j] = __builtin_elementwise_fma(v2f(xn), arow, s[j]);
+      if (GRAD) sd[j] = __builtin_elementwise_fma(v2f(dn), arow, sd[j]);
+    }
+  }
+  v2f S2 = v2f(0.f), Su2 = v2f(0.f), Sv2 = v2f(0.f);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    S2 = __builtin_elementwise_fma(r.yv[j], s[j], S2);
+    if (GRAD) {
+      Su2 = __builtin_elementwise_fma(r.yv[j], sd[j], Su2);
+      Sv2 = __builtin_elementwise_fma(r.yd[j], s[j], Sv2);
+    }
+  }
+  st.S = S2.x + S2.y;
+  if (GRAD) { st.Su = Su2.x + Su2.y; st.Sv = Sv2.x + Sv2.y; }
+  return st.fac * st.S;
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------------------------
+// Component list: LK lenses, LLK lens lights (Sersic kinds), then exactly one K_SHAPELETS source.  Every thread owns pixels
+// (j, j + 256) of a 512-pixel tile; the two shapelet chains of a lane run one after the other.
+template <int MODE, int WAVES, class LK, class LLK, int NP, bool INTERP>
+__global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
+  using V = v2f;
+  constexpr int NL = LK::n, NLL = LLK::n;
+  constexpr bool GRAD = (MODE == IMG_BWD || MODE == LL_GRAD);
+  extern __shared__ float smem[];
+  float* s_d = smem;
+  float* s_x = smem + ((a.D + 3) & ~3);  // exchange planes (gradient modes); the epilogue's rows alias them
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
+  const CompDesc* __restrict__ comps = a.comps;
+  const float* __restrict__ gder = a.derived + (size_t)b * a.D;
+  for (int i = tid; i < a.D; i += WG) s_d[i] = gder[i];
+  __syncthreads();
+  constexpr int NACC_L = [] { int n = 0; for (int i = 0; i < NL; ++i) n += static_nacc(LK::kinds[i]); return n; }();
+  constexpr int NACC_C = [] { int n = 0; for (int i = 0; i < NLL; ++i) n += static_nacc(LLK::kinds[i]); return n; }();
+  V accL[NACC_L > 0 ? NACC_L : 1];
+  V accC[NACC_C > 0 ? NACC_C : 1];
+#pragma unroll
+  for (int k = 0; k < NACC_L; ++k) accL[k] = V(0.f);
+#pragma unroll
+  for (int k = 0; k < NACC_C; ++k) accC[k] = V(0.f);
+  V st0 = V(0.f), st1 = V(0.f);
+  V acc_cx = V(0.f), acc_cy = V(0.f), acc_ib = V(0.f);  // shapelet centre / 1/beta sums (pixel pair)
+  v4f G = {0.f, 0.f, 0.f, 0.f}, G2 = {0.f, 0.f, 0.f, 0.f};  // this wave's 16 x 16 tile of the amplitude gradient (even / odd pixel groups)
+  const float* dL[NL > 0 ? NL : 1];
+  const float* dC[NLL > 0 ? NLL : 1];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) dL[i] = s_d + comps[i].d_off;
+#pragma unroll
+  for (int i = 0; i < NLL; ++i) dC[i] = s_d + comps[NL + i].d_off;
+  const CompDesc shp = comps[NL + NLL];
+  const float* dS = s_d + shp.d_off;
+  const v2f* __restrict__ gA = reinterpret_cast<const v2f*>(gder + shp.d_off + SHP_SQ);
+  const bool has_err = a.err != nullptr, has_mask = a.mask != nullptr, has_pix = a.pix != nullptr;
+  // exchange planes of this wave: gX at [0, NP), Y at [NP, 2 NP); a lane parks pixel slot w at pixel index 64 w + lane
+  float* xw = s_x + wave * (2 * NP * SHX_PLANE);
+  float* wr_gx = xw + 2 * lane;
+  float* wr_y = xw + NP * SHX_PLANE + 2 * lane;
+  // transposed read: lane (m, k) = (lane & 15, lane >> 4) takes order m of pixel 4 kb + k; orders beyond 2 NP - 1 re-read the last
+  // (their rows / columns of the tile are never stored)
+  const int mm = min(lane & 15, 2 * NP - 1);
+  const float* rd_gx = xw + (mm >> 1) * SHX_PLANE + (mm & 1) + 2 * (lane >> 4);
+  const float* rd_y = rd_gx + NP * SHX_PLANE;
+
+  const int p0 = chunk * a.chunk;
+  const int p1 = min(p0 + a.chunk, a.N);
+  auto tile = [&](int base, auto check_tag) {
+    constexpr bool CHECK = decltype(check_tag)::value;
+    unsigned jj[2], pidx[2];
+    bool valid[2];
+    V vmask = V(1.f);
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      int j = base + w * WG + tid;
+      valid[w] = CHECK ? (j < p1) : true;
+      jj[w] = (unsigned)(valid[w] ? j : p1 - 1);
+      pidx[w] = has_pix ? (unsigned)a.pix[jj[w]] : jj[w];
+    }
+    const V x = V{a.gx[jj[0]], a.gx[jj[1]]}, y = V{a.gy[jj[0]], a.gy[jj[1]]};
+    if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
+    V bx = x, by = y, m = V(0.f);
+    EplStateV<V> est[NL > 0 ? NL : 1];
+    SerStateV<V> sst[NLL > 0 ? NLL : 1];
+    static_for([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int kind = LK::kinds[i];
+      if constexpr (kind == K_EPL) epl_fwd_v<V, GRAD>(dL[i], gder + comps[i].d_off, x, y, bx, by, est[i]);
+      else if constexpr (kind == K_SIE) sie_fwd_v<V>(dL[i], x, y, bx, by);
+      else if constexpr (kind == K_SHEAR) shear_fwd_v<V>(dL[i], x, y, bx, by);
+      else sis_fwd_v<V>(dL[i], x, y, bx, by);
+    }, std::make_integer_sequence<int, NL>{});
+    static_for([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      m += sersic_fwd_v<V, true>(dC[i], x, y, sst[i]);
+    }, std::make_integer_sequence<int, NLL>{});
+    ShpPix<NP> ps0, ps1;
+    {
+      ShpRows<NP> r0, r1;
+      shp_pixel_gather<NP, INTERP>(dS, a.shp_tab2, bx.x, by.x, ps0, r0);
+      shp_pixel_gather<NP, INTERP>(dS, a.shp_tab2, bx.y, by.y, ps1, r1);
+      const float l0 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, r0, wr_y, ps0);
+      const float l1 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, r1, wr_y + 128, ps1);
+      m += V{l0, l1};
+    }
+    auto nanp = m != m;
+    m = (nanp ? V(0.f) : m) * a.out_scale;  // NaN -> 0 (tf/simulator.py:140), then x det(T) (:156)
+    if (MODE == IMG_FWD) {
+      float* row = a.img + (size_t)b * a.img_stride;
+      if (valid[0]) row[pidx[0]] = m.x;
+      if (valid[1]) row[pidx[1]] = m.y;
+      return;
+    }
+    V gm;
+    if (MODE == IMG_BWD) {
+      const float* row = a.gimg + (size_t)b * a.img_stride;
+      const V g = V{row[pidx[0]], row[pidx[1]]};
+      gm = nanp ? V(0.f) : (CHECK ? g * vmask : g) * a.out_scale;
+    } else {
+      V o = V{a.obs[pidx[0]], a.obs[pidx[1]]}, w = vmask, e = V(1.f);
+      if (CHECK && has_mask) w = w * V{a.mask[pidx[0]], a.mask[pidx[1]]};
+      if (has_err) e = V{a.err[pidx[0]], a.err[pidx[1]]};
+      V dmo = m - o;  // tf/model.py:92-99; sigma^2 = bg^2 + m/t (no clip: negative -> NaN like the sqrt of a negative)
+      V s2 = has_err ? e * e : m * a.inv_t + a.bg2;
+      V is2 = rcp(s2);
+      V nm = vlog<V>(s2 * (float)(2 * kPi));
+      V c2 = __builtin_elementwise_fma(nm, V(0.f), dmo * dmo * is2);  // + 0 * nm: carries that NaN into chi^2
+      if (CHECK) {
+        auto use = w != V(0.f);
+        st0 += use ? c2 * w : V(0.f);
+        st1 += use ? nm * w : V(0.f);
+      } else {
+        st0 += c2;
+        st1 += nm;
+      }
+      if (MODE == LL_GRAD) {
+        V g = has_err ? -(dmo * is2) : (dmo * dmo * is2 - 1.f) * (is2 * (0.5f * a.inv_t)) - dmo * is2;
+        gm = nanp ? V(0.f) : (CHECK ? g * w : g) * a.out_scale;
+      }
+    }
+    if constexpr (GRAD) {
+      V gbx = V(0.f), gby = V(0.f);
+      static_for([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int off = [] { int n = 0; for (int j = 0; j < i; ++j) n += static_nacc(LLK::kinds[j]); return n; }();
+        sersic_vjp_v<V, false, true>(dC[i], sst[i], gm, accC + off, gbx, gby);
+      }, std::make_integer_sequence<int, NLL>{});
+      // ---- shapelet VJP of the pair: positions in packed form, amplitudes through the matrix pipe ----
+      const float ib = dS[SHP_IB];
+      const V fac = V{ps0.fac, ps1.fac};
+      const V gS = gm * fac;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        *reinterpret_cast<v2f*>(wr_gx + j * SHX_PLANE) = ps0.X[j] * gS.x;
+        *reinterpret_cast<v2f*>(wr_gx + 128 + j * SHX_PLANE) = ps1.X[j] * gS.y;
+      }
+      const float ds = INTERP ? (float)(SH_NODES - 1) / 10.f : 1.f;  // table mode: the differences are per node spacing
+      V gu = gS * (V{ps0.Su, ps1.Su} * ds), gv = gS * (V{ps0.Sv, ps1.Sv} * ds);
+      if constexpr (!INTERP) {  // d fac / du = -u fac
+        const V gIf = gm * (fac * V{ps0.S, ps1.S});
+        gu -= gIf * V{ps0.u, ps1.u};
+        gv -= gIf * V{ps0.v, ps1.v};
+      }
+      const V gdx = gu * ib, gdy = gv * ib;
+      acc_cx -= gdx;
+      acc_cy -= gdy;
+      acc_ib += gu * V{ps0.dx, ps1.dx} + gv * V{ps0.dy, ps1.dy};
+      gbx = -(gbx + gdx);
+      gby = -(gby + gdy);
+      static_for([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int kind = LK::kinds[i];
+        constexpr int off = [] { int n = 0; for (int j = 0; j < i; ++j) n += static_nacc(LK::kinds[j]); return n; }();
+        if constexpr (kind == K_EPL) epl_vjp_v<V>(dL[i], gbx, gby, est[i], accL + off);
+        else if constexpr (kind == K_SIE) sie_vjp_v<V>(dL[i], x, y, gbx, gby, accL + off);
+        else if constexpr (kind == K_SHEAR) shear_vjp_v<V>(x, y, gbx, gby, accL + off);
+        else sis_vjp_v<V>(dL[i], x, y, gbx, gby, accL + off);
+      }, std::make_integer_sequence<int, NL>{});
+      // ---- G += (gS X)(Y)^T over the wave's 128 pixels: 32 MFMAs of four pixels each.  The planes are private to the wave and
+      // LDS serves a wave's requests in order, so stores -> transposed loads need no barrier, only the compiler's ordering. ----
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // operands in batches of eight pixel groups (all sixteen reads of a batch in flight before its first MFMA; the next
+      // batch's reads are issued ahead of this batch's MFMAs), two accumulator tiles in turn: the chain of dependent MFMAs
+      // (40 cycles each) is half as long and no MFMA waits for its own LDS read
+      float opa[2][8], opb[2][8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { opa[0][i] = rd_gx[8 * i]; opb[0][i] = rd_y[8 * i]; }
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt) {
+        if (bt < 3) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { opa[(bt + 1) & 1][i] = rd_gx[8 * (8 * (bt + 1) + i)]; opb[(bt + 1) & 1][i] = rd_y[8 * (8 * (bt + 1) + i)]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+          G = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[bt & 1][i], opb[bt & 1][i], G, 0, 0, 0);
+          G2 = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[bt & 1][i + 1], opb[bt & 1][i + 1], G2, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's stores stay behind these loads
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  {
+    const bool plain = !has_mask;
+    int base = p0;
+    if (plain)
+      for (; base + WG * 2 <= p1; base += WG * 2) tile(base, std::false_type{});
+    for (; base < p1; base += WG * 2) tile(base, std::true_type{});
+  }
+  if (MODE == IMG_FWD) return;
+  float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
+  __syncthreads();  // every wave is done with its exchange planes: the epilogue rows alias them
+  float* s_acc = s_x;                  // [16 rows][Apad] (gradient modes) / [4 rows][Apad]
+  float* s_g = s_x + 16 * a.Apad;      // [4 waves][16][17] amplitude tiles
+  if constexpr (!GRAD) {
+    for (int i = tid; i < 4 * a.Apad; i += WG) s_acc[i] = 0.f;
+    __syncthreads();
+    float* s_row = s_acc + wave * a.Apad;
+    const float c2 = wave_sum63(hsum(st0)), nm = wave_sum63(hsum(st1));
+    if (lane == 63) { s_row[0] = c2; s_row[1] = nm; }
+    __syncthreads();
+    for (int k = tid; k < a.A; k += WG) out[k] = (s_acc[k] + s_acc[a.Apad + k]) + (s_acc[2 * a.Apad + k] + s_acc[3 * a.Apad + k]);
+    return;
+  } else {
+    // [chi2, norm, 0, 0 | lenses | lens lights | shapelet cx, cy, 1/beta] four values per register (gl_pair.hip.h), then the tile
+    constexpr int NV = NSTAT + NACC_L + NACC_C + SHPA_AMP, NVP = (NV + 3) & ~3;
+    float vals[NVP];
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) vals[k] = 0.f;
+    vals[0] = (MODE == LL_GRAD) ? hsum(st0) : 0.f;
+    vals[1] = (MODE == LL_GRAD) ? hsum(st1) : 0.f;
+    static_for([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int kind = LK::kinds[i];
+      constexpr int off = [] { int n = 0; for (int j = 0; j < i; ++j) n += static_nacc(LK::kinds[j]); return n; }();
+      constexpr int Gn = static_nacc(kind);
+      float tmp[Gn];
+#pragma unroll
+      for (int k = 0; k < Gn; ++k) tmp[k] = hsum(accL[off + k]);
+      if constexpr (kind == K_EPL) {  // deferred per-sample factors of epl_vjp_v (see gl_pair.hip.h)
+        tmp[EPLA_B] = tmp[EPLA_P0] * (dL[i][EPL_TM1] * dL[i][EPL_INVB]);
+        tmp[EPLA_P0] *= rcp(dL[i][EPL_P0]);
+        const float gxr = tmp[EPLA_CX], gyr = tmp[EPLA_CY], cc = dL[i][EPL_C], ss = dL[i][EPL_S];
+        tmp[EPLA_CX] = -(gxr * cc - gyr * ss);
+        tmp[EPLA_CY] = -(gxr * ss + gyr * cc);
+      }
+#pragma unroll
+      for (int k = 0; k < Gn; ++k) vals[NSTAT + off + k] = tmp[k];
+    }, std::make_integer_sequence<int, NL>{});
+    static_for([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int off = [] { int n = 0; for (int j = 0; j < i; ++j) n += static_nacc(LLK::kinds[j]); return n; }();
+#pragma unroll
+      for (int k = 0; k < SER_NACC; ++k) vals[NSTAT + NACC_L + off + k] = hsum(accC[off + k]) * (k == SERA_INVN ? (float)kLn2 : 1.f);
+    }, std::make_integer_sequence<int, NLL>{});
+    vals[NSTAT + NACC_L + NACC_C + SHPA_CX] = hsum(acc_cx);
+    vals[NSTAT + NACC_L + NACC_C + SHPA_CY] = hsum(acc_cy);
+    vals[NSTAT + NACC_L + NACC_C + SHPA_IB] = hsum(acc_ib);
+    const bool odd = tid & 1, hi = tid & 2;
+    float* s_row16 = s_acc + (tid >> 4) * a.Apad;
+#pragma unroll
+    for (int g = 0; g < NVP / 4; ++g) {
+      float r = quad_transpose_sum(vals[4 * g], vals[4 * g + 1], vals[4 * g + 2], vals[4 * g + 3], odd, hi);
+      r = dpp_add(r, 0x114, 0xF);  // row_shr:4
+      r = dpp_add(r, 0x118, 0xF);  // row_shr:8 -> lanes 12..15 of the row: the row's sums of values 4g .. 4g + 3
+      if ((tid & 15) >= 12 && 4 * g + (tid & 3) < NV) s_row16[4 * g + (tid & 3)] = r;
+    }
+    // the wave's tile: lane holds rows 4 (lane / 16) + i, column lane % 16 (v_mfma_f32_16x16x4_f32 accumulator layout)
+    float* s_gw = s_g + wave * (16 * 17);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_gw[(4 * (lane >> 4) + i) * 17 + (lane & 15)] = G[i] + G2[i];
+    __syncthreads();
+    for (int k = tid; k < NV; k += WG) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v += s_acc[j * a.Apad + k];
+      out[k] = v;
+    }
+    // amplitude i = n (n + 1) / 2 + n2 with n = n1 + n2 (shapelets.py:41-46)
+    const int n_amp = shp.n_acc - SHPA_AMP;
+    for (int i = tid; i < n_amp; i += WG) {
+      int n = 0;
+      while ((n + 1) * (n + 2) / 2 <= i) ++n;
+      const int n2 = i - n * (n + 1) / 2, n1 = n - n2;
+      const float* t = s_g + n1 * 17 + n2;
+      out[shp.a_off + SHPA_AMP + i] = (t[0] + t[16 * 17]) + (t[2 * 16 * 17] + t[3 * 16 * 17]);
+    }
+  }
+}
+
+}  // namespace glk

@@ -49,14 +49,28 @@ def rank_generator(seed: int, rank: int, device="cpu") -> torch.Generator:
     return g
 
 
+_AVG_OK = [True]  # ReduceOp.AVG is an RCCL feature; a build that rejects it is served by SUM + one division (same result)
+
+
 def allreduce_mean_(buf: torch.Tensor) -> torch.Tensor:
     """In-place mean over ranks (== lax.pmean). One collective for the whole fused buffer."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        if buf.is_cuda and dist.get_backend() == "nccl":
-            dist.all_reduce(buf, op=dist.ReduceOp.AVG)  # RCCL averages inside the collective kernel: no second launch
-        else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-            buf.div_(dist.get_world_size())
+        if buf.is_cuda and dist.get_backend() == "nccl" and _AVG_OK[0]:
+            try:
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG)  # RCCL averages inside the collective kernel: no second launch
+                return buf
+            except RuntimeError:  # raised before anything is enqueued (unsupported reduction op): buf is untouched
+                _AVG_OK[0] = False
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        buf.div_(dist.get_world_size())
+    return buf
+
+
+def broadcast_(buf: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """In-place broadcast from rank `src` (the SVI driver re-synchronises the surrogate's parameters with it every few hundred
+    steps, so that ranks cannot drift apart even if a collective implementation is not bitwise identical on every rank)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(buf, src=src)
     return buf
 
 

@@ -4,7 +4,7 @@ src/gigalens/tf/simulator.py:60-70 with ``odd=True``; README.rst:35 pins lenstro
 lenstronomy is not in this image and not under /root/reference, so this is the PUBLISHED algorithm restated, **parity
 unpinned**: bilinear interpolation of the kernel onto the finer grid (cell centres on the unit interval, nearest-edge outside
 the input centres, as ``scipy.interpolate.interp2d(kind='linear')`` evaluates), normalised to unit sum, then ``num_iter``
-rounds of: re-bin the fine kernel to the input pixel scale and normalise it, add the mismatch to the working
+rounds of: re-bin the fine kernel to the input pixel scale, add the mismatch to the working
 low-resolution kernel, re-interpolate, re-normalise.  With ``odd=True`` an even fine size loses one row / column so the kernel keeps a centre pixel;
 re-binning an odd fine kernel at an even ``subgrid_res`` shares the rows / columns that straddle two coarse pixels half and
 half (``averaging_even_kernel``).
@@ -14,6 +14,8 @@ oracle restates the same routine with explicit loops (oracle/ref_torch.py), and 
 tests/test_kernel_util.py together with the properties the algorithm guarantees (unit sum, symmetry, re-binning back to the
 input kernel).
 """
+import warnings
+
 import numpy as np
 
 
@@ -79,10 +81,7 @@ def subgrid_kernel(kernel, subgrid_res, odd=False, num_iter=100):
         ny_new -= 1 - ny_new % 2
     Wr, Wc = _interp_matrix(nx, nx_new), _interp_matrix(ny, ny_new)  # rows (first axis), columns
     even = subgrid_res % 2 == 0
-    if even:
-        Ar, Ac = _rebin_matrix(nx_new, subgrid_res), _rebin_matrix(ny_new, subgrid_res)
-    else:
-        Ar, Ac = _rebin_matrix(nx_new, subgrid_res), _rebin_matrix(ny_new, subgrid_res)
+    Ar, Ac = _rebin_matrix(nx_new, subgrid_res), _rebin_matrix(ny_new, subgrid_res)
     if Ar.shape[0] != nx or Ac.shape[0] != ny:
         raise ValueError(f"a {nx}x{ny} kernel at subgrid_res={subgrid_res}, odd={odd} does not re-bin to its own size "
                          "(lenstronomy has the same restriction: use an odd-sized kernel)")
@@ -90,6 +89,14 @@ def subgrid_kernel(kernel, subgrid_res, odd=False, num_iter=100):
     work = kernel.copy()
     fine = norm(Wr @ work @ Wc.T)
     for _ in range(max(int(num_iter), 1)):
-        work = work + (kernel - norm(Ar @ fine @ Ac.T))  # the re-binned proposal is normalised before the comparison
+        # even: the re-binning is a sum (unit sum kept); odd: lenstronomy's block MEAN, which it does not re-normalise here
+        work = work + (kernel - Ar @ fine @ Ac.T)
         fine = norm(Wr @ work @ Wc.T)
-    return fine if even else norm(fine)
+    if even:
+        return fine
+    # odd subgrid_res: what the iteration has not matched goes back at zeroth order, spread over each coarse pixel's block
+    warnings.warn("subgrid_kernel at an odd subgrid_res follows lenstronomy 1.9.x as restated from the published source without "
+                  "a lenstronomy-generated fixture: parity unpinned (even subgrid_res is pinned statistically by the "
+                  "reference's demo image)", RuntimeWarning, stacklevel=2)
+    delta = norm(Ar @ fine @ Ac.T) - norm(kernel)
+    return norm(fine - np.kron(delta, np.ones((subgrid_res, subgrid_res))) / subgrid_res ** 2)

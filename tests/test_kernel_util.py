@@ -38,9 +38,13 @@ def test_identity_and_iteration_fixed_point():
     once = ref._averaging_even_kernel(ku.subgrid_kernel(PSF / PSF.sum(), 2, odd=True, num_iter=1), 2)
     assert np.abs(back - PSF / PSF.sum()).max() < 0.2 * np.abs(once - PSF / PSF.sum()).max()
     assert np.abs(back - PSF / PSF.sum()).max() < 2e-3 * PSF.max() / PSF.sum()
-    fine3 = ku.subgrid_kernel(PSF / PSF.sum(), 3, odd=True)
+    with pytest.warns(RuntimeWarning, match="parity unpinned"):  # odd subgrid_res: restated without a lenstronomy fixture
+        fine3 = ku.subgrid_kernel(PSF / PSF.sum(), 3, odd=True)
     back3 = fine3.reshape(13, 3, 13, 3).sum(3).sum(1)
-    assert np.abs(back3 - PSF / PSF.sum()).max() < 2e-3 * PSF.max() / PSF.sum()
+    # the odd branch ends by returning the unmatched residual block-wise: the re-binned kernel IS the input kernel
+    k64 = (PSF / PSF.sum()).astype(np.float64)
+    k64 /= k64.sum()
+    assert np.abs(back3 - k64).max() < 1e-13
 
 
 def test_symmetry_is_kept():
