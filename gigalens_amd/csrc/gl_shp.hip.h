@@ -29,12 +29,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // dwords per order-pair plane of a wave's exchange buffer: 128 pixels (two per lane) x 2 + 4 pad: stride = 4 (mod 32 banks)
 constexpr int SHX_PLANE = 128 * 2 + 4;
-__host__ __device__ constexpr size_t shp_exchange_bytes(int np) { return (size_t)4 /*waves*/ * 2 /*gX, Y*/ * np * SHX_PLANE * sizeof(float); }
+__host__ __device__ constexpr int shp_exchange_floats(int np) { return 2 /*X, Y*/ * np * SHX_PLANE + 128 /*gS*/; }  // per wave
+__host__ __device__ constexpr size_t shp_exchange_bytes(int np) { return (size_t)4 /*waves*/ * shp_exchange_floats(np) * sizeof(float); }
 
-template <int NP> struct ShpPix {
-  v2f X[NP];  // basis along u, order pairs; multiplied by gS before it is parked for the MFMA pass
-  float S, Su, Sv, u, v, dx, dy, fac;
-};
+template <int NP> struct ShpPix { float S, Su, Sv, u, v, dx, dy, fac; };  // what a pixel's VJP needs of its forward pass
 
 // table row of one coordinate: NP pairs of values at the node below and NP pairs of differences to the next node
 template <int NP>
@@ -80,14 +78,20 @@ __device__ __forceinline__ void shp_hermite(float u, int n_max, v2f (&val)[NP], 
 // either chain starts (a gather is a full trip to the L2; issued one row at a time the chains are latency-bound) ------------------
 template <int NP> struct ShpRows { v2f xv[NP], xd[NP], yv[NP], yd[NP]; float tu, tv; };
 
-template <int NP, bool INTERP>
-__device__ __forceinline__ void shp_pixel_gather(const float* d, const float* __restrict__ tab, float px, float py, ShpPix<NP>& st,
-                                                 ShpRows<NP>& r) {
+template <int NP> __device__ __forceinline__ void shp_pixel_coords(const float* d, float px, float py, ShpPix<NP>& st) {
   const float ib = d[SHP_IB];
   st.dx = px - d[SHP_CX];
   st.dy = py - d[SHP_CY];
   st.u = st.dx * ib;
   st.v = st.dy * ib;
+}
+// the table's support, with the expression shp_row itself uses: outside it a basis and its slope are exactly zero
+__device__ __forceinline__ bool shp_in_table(float u) {
+  const float fi = (u + 5.f) * ((float)(SH_NODES - 1) / 10.f);
+  return (fi >= 0.f) && (fi <= (float)(SH_NODES - 1));
+}
+template <int NP, bool INTERP>
+__device__ __forceinline__ void shp_pixel_gather(const float* __restrict__ tab, const ShpPix<NP>& st, ShpRows<NP>& r) {
   if constexpr (INTERP) {
     shp_row<NP>(tab, st.u, r.xv, r.xd, r.tu);
     shp_row<NP>(tab, st.v, r.yv, r.yd, r.tv);
@@ -97,21 +101,23 @@ __device__ __forceinline__ void shp_pixel_gather(const float* d, const float* __
 //   gA : the sample's zero-padded square amplitude matrix [2NP][2NP] in GLOBAL memory (wave-uniform address: scalar loads)
 //   ybuf: this lane's slot of the wave's Y planes (dword address of plane 0): Y is parked there for the MFMA pass
 template <int NP, bool INTERP, bool GRAD>
-__device__ __forceinline__ float shp_pixel_fwd(const float* d, const v2f* __restrict__ gA, ShpRows<NP>& r, float* __restrict__ ybuf,
-                                               ShpPix<NP>& st) {
+__device__ __forceinline__ float shp_pixel_fwd(const float* d, const v2f* __restrict__ gA, ShpRows<NP>& r, float* __restrict__ xbuf,
+                                               float* __restrict__ ybuf, ShpPix<NP>& st) {
   if constexpr (INTERP) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) st.X[j] = __builtin_elementwise_fma(v2f(r.tu), r.xd[j], r.xv[j]);
+    for (int j = 0; j < NP; ++j) r.xv[j] = __builtin_elementwise_fma(v2f(r.tu), r.xd[j], r.xv[j]);
 #pragma unroll
     for (int j = 0; j < NP; ++j) r.yv[j] = __builtin_elementwise_fma(v2f(r.tv), r.yd[j], r.yv[j]);
     st.fac = 1.f;
   } else {
     const int n_max = (int)d[SHP_NMAX];
-    shp_hermite<NP>(st.u, n_max, st.X, r.xd);
+    shp_hermite<NP>(st.u, n_max, r.xv, r.xd);
     shp_hermite<NP>(st.v, n_max, r.yv, r.yd);
     st.fac = exp_(-(st.u * st.u + st.v * st.v) * 0.5f);  // shapelets.py:70
   }
-  if constexpr (GRAD) {
+  if constexpr (GRAD) {  // both bases are parked for the MFMA pass right away: no basis register outlives this function
+#pragma unroll
+    for (int j = 0; j < NP; ++j) *reinterpret_cast<v2f*>(xbuf + j * SHX_PLANE) = r.xv[j];
 #pragma unroll
     for (int j = 0; j < NP; ++j) *reinterpret_cast<v2f*>(ybuf + j * SHX_PLANE) = r.yv[j];
   }
@@ -124,7 +130,7 @@ __device__ __forceinline__ float shp_pixel_fwd(const float* d, const v2f* __rest
   // scheduling barrier, or a laundered pointer all made the allocation worse: measured, see DESIGN.md.)
 #pragma unroll
   for (int n1 = 0; n1 < 2 * NP - 1; ++n1) {
-    const float xn = (n1 & 1) ? st.X[n1 >> 1].y : st.X[n1 >> 1].x;
+    const float xn = (n1 & 1) ? r.xv[n1 >> 1].y : r.xv[n1 >> 1].x;
     const float dn = (n1 & 1) ? r.xd[n1 >> 1].y : r.xd[n1 >> 1].x;
 #pragma unroll
     for (int j = 0; 2 * j + n1 < 2 * NP - 1; ++j) {  // n2 = 2j, 2j+1 with n1 + n2 <= 2 NP - 2 (the largest n_max this NP serves)
@@ -186,7 +192,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
   const v2f* __restrict__ gA = reinterpret_cast<const v2f*>(gder + shp.d_off + SHP_SQ);
   const bool has_err = a.err != nullptr, has_mask = a.mask != nullptr, has_pix = a.pix != nullptr;
   // exchange planes of this wave: gX at [0, NP), Y at [NP, 2 NP); a lane parks pixel slot w at pixel index 64 w + lane
-  float* xw = s_x + wave * (2 * NP * SHX_PLANE);
+  float* xw = s_x + wave * shp_exchange_floats(NP);
   float* wr_gx = xw + 2 * lane;
   float* wr_y = xw + NP * SHX_PLANE + 2 * lane;
   // transposed read: lane (m, k) = (lane & 15, lane >> 4) takes order m of pixel 4 kb + k; orders beyond 2 NP - 1 re-read the last
@@ -194,6 +200,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
   const int mm = min(lane & 15, 2 * NP - 1);
   const float* rd_gx = xw + (mm >> 1) * SHX_PLANE + (mm & 1) + 2 * (lane >> 4);
   const float* rd_y = rd_gx + NP * SHX_PLANE;
+  float* wr_gs = xw + 2 * NP * SHX_PLANE + lane;            // gS of pixel slot w at 64 w + lane
+  const float* rd_gs = xw + 2 * NP * SHX_PLANE + (lane >> 4);  // pixel 4 kb + k of the operand lane (m, k)
 
   const int p0 = chunk * a.chunk;
   const int p1 = min(p0 + a.chunk, a.N);
@@ -213,7 +221,6 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
     V bx = x, by = y, m = V(0.f);
     EplStateV<V> est[NL > 0 ? NL : 1];
-    SerStateV<V> sst[NLL > 0 ? NLL : 1];
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int kind = LK::kinds[i];
@@ -224,15 +231,27 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     }, std::make_integer_sequence<int, NL>{});
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
-      m += sersic_fwd_v<V, true>(dC[i], x, y, sst[i]);
+      SerStateV<V> sst_i;
+      m += sersic_fwd_v<V, true>(dC[i], x, y, sst_i);
     }, std::make_integer_sequence<int, NLL>{});
     ShpPix<NP> ps0, ps1;
-    {
-      ShpRows<NP> r0, r1;
-      shp_pixel_gather<NP, INTERP>(dS, a.shp_tab2, bx.x, by.x, ps0, r0);
-      shp_pixel_gather<NP, INTERP>(dS, a.shp_tab2, bx.y, by.y, ps1, r1);
-      const float l0 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, r0, wr_y, ps0);
-      const float l1 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, r1, wr_y + 128, ps1);
+    shp_pixel_coords<NP>(dS, bx.x, by.x, ps0);
+    shp_pixel_coords<NP>(dS, bx.y, by.y, ps1);
+    // Table mode: a pixel whose u OR v lies outside the table's support renders exactly zero with zero slopes (fill 0 / 0,
+    // shapelets.py:58-60), so a wave none of whose 128 pixels is inside skips the gathers, both chains, the LDS traffic and
+    // the MFMAs -- on a lensed field that is every tile away from the arcs (wave-uniform branch; the values are the same zeros).
+    bool shp_live = true;
+    if constexpr (INTERP) {
+      const bool inr = (shp_in_table(ps0.u) && shp_in_table(ps0.v)) || (shp_in_table(ps1.u) && shp_in_table(ps1.v));
+      shp_live = __builtin_amdgcn_ballot_w64(inr) != 0;
+    }
+    if (shp_live) {
+      ShpRows<NP> r0;
+      shp_pixel_gather<NP, INTERP>(a.shp_tab2, ps0, r0);
+      const float l0 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, r0, wr_gx, wr_y, ps0);
+      ShpRows<NP> r1;
+      shp_pixel_gather<NP, INTERP>(a.shp_tab2, ps1, r1);
+      const float l1 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, r1, wr_gx + 128, wr_y + 128, ps1);
       m += V{l0, l1};
     }
     auto nanp = m != m;
@@ -275,30 +294,38 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       static_for([&](auto I) {
         constexpr int i = decltype(I)::value;
         constexpr int off = [] { int n = 0; for (int j = 0; j < i; ++j) n += static_nacc(LLK::kinds[j]); return n; }();
-        sersic_vjp_v<V, false, true>(dC[i], sst[i], gm, accC + off, gbx, gby);
+        // the lens light's forward state is re-evaluated here (three transcendentals per pixel) rather than carried across the
+        // shapelet chains: with it the kernel needs more than 256 VGPRs
+        SerStateV<V> sst_i;
+        (void)sersic_fwd_v<V, true>(dC[i], x, y, sst_i);
+        sersic_vjp_v<V, false, true>(dC[i], sst_i, gm, accC + off, gbx, gby);
       }, std::make_integer_sequence<int, NLL>{});
       // ---- shapelet VJP of the pair: positions in packed form, amplitudes through the matrix pipe ----
-      const float ib = dS[SHP_IB];
-      const V fac = V{ps0.fac, ps1.fac};
-      const V gS = gm * fac;
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        *reinterpret_cast<v2f*>(wr_gx + j * SHX_PLANE) = ps0.X[j] * gS.x;
-        *reinterpret_cast<v2f*>(wr_gx + 128 + j * SHX_PLANE) = ps1.X[j] * gS.y;
+      if (shp_live) {
+        const float ib = dS[SHP_IB];
+        // the source-plane offsets and (u, v) are recomputed from beta (two packed instructions each) instead of kept
+        // through the likelihood terms; table mode has no Gaussian factor to keep either
+        const V pdx = bx - dS[SHP_CX], pdy = by - dS[SHP_CY];
+        const V fac = INTERP ? V(1.f) : V{ps0.fac, ps1.fac};
+        const V gS = INTERP ? gm : gm * fac;
+        wr_gs[0] = gS.x;   // the pixel's cotangent of S: applied to the Y operand after the transposed read
+        wr_gs[64] = gS.y;
+        const float ds = INTERP ? (float)(SH_NODES - 1) / 10.f : 1.f;  // table mode: the differences are per node spacing
+        V gu = gS * (V{ps0.Su, ps1.Su} * ds), gv = gS * (V{ps0.Sv, ps1.Sv} * ds);
+        if constexpr (!INTERP) {  // d fac / du = -u fac
+          const V gIf = gm * (fac * V{ps0.S, ps1.S});
+          gu -= gIf * (pdx * ib);
+          gv -= gIf * (pdy * ib);
+        }
+        const V gdx = gu * ib, gdy = gv * ib;
+        acc_cx -= gdx;
+        acc_cy -= gdy;
+        acc_ib += gu * pdx + gv * pdy;
+        gbx += gdx;
+        gby += gdy;
       }
-      const float ds = INTERP ? (float)(SH_NODES - 1) / 10.f : 1.f;  // table mode: the differences are per node spacing
-      V gu = gS * (V{ps0.Su, ps1.Su} * ds), gv = gS * (V{ps0.Sv, ps1.Sv} * ds);
-      if constexpr (!INTERP) {  // d fac / du = -u fac
-        const V gIf = gm * (fac * V{ps0.S, ps1.S});
-        gu -= gIf * V{ps0.u, ps1.u};
-        gv -= gIf * V{ps0.v, ps1.v};
-      }
-      const V gdx = gu * ib, gdy = gv * ib;
-      acc_cx -= gdx;
-      acc_cy -= gdy;
-      acc_ib += gu * V{ps0.dx, ps1.dx} + gv * V{ps0.dy, ps1.dy};
-      gbx = -(gbx + gdx);
-      gby = -(gby + gdy);
+      gbx = -gbx;
+      gby = -gby;
       static_for([&](auto I) {
         constexpr int i = decltype(I)::value;
         constexpr int kind = LK::kinds[i];
@@ -310,29 +337,35 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       }, std::make_integer_sequence<int, NL>{});
       // ---- G += (gS X)(Y)^T over the wave's 128 pixels: 32 MFMAs of four pixels each.  The planes are private to the wave and
       // LDS serves a wave's requests in order, so stores -> transposed loads need no barrier, only the compiler's ordering. ----
+      if (shp_live) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // operands in batches of eight pixel groups (all sixteen reads of a batch in flight before its first MFMA; the next
+      // operands in batches of MB pixel groups (all reads of a batch in flight before its first MFMA; the next
       // batch's reads are issued ahead of this batch's MFMAs), two accumulator tiles in turn: the chain of dependent MFMAs
       // (40 cycles each) is half as long and no MFMA waits for its own LDS read
-      float opa[2][8], opb[2][8];
+      constexpr int MB = 4;  // pixel groups per batch (a batch's 2 MB operand registers are double-buffered)
+      float opa[2][MB], opb[2][MB];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { opa[0][i] = rd_gx[8 * i]; opb[0][i] = rd_y[8 * i]; }
+      for (int i = 0; i < MB; ++i) { opa[0][i] = rd_gx[8 * i]; opb[0][i] = rd_y[8 * i] * rd_gs[4 * i]; }
 #pragma unroll
-      for (int bt = 0; bt < 4; ++bt) {
-        if (bt < 3) {
+      for (int bt = 0; bt < 32 / MB; ++bt) {
+        if (bt + 1 < 32 / MB) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { opa[(bt + 1) & 1][i] = rd_gx[8 * (8 * (bt + 1) + i)]; opb[(bt + 1) & 1][i] = rd_y[8 * (8 * (bt + 1) + i)]; }
+          for (int i = 0; i < MB; ++i) {
+            opa[(bt + 1) & 1][i] = rd_gx[8 * (MB * (bt + 1) + i)];
+            opb[(bt + 1) & 1][i] = rd_y[8 * (MB * (bt + 1) + i)] * rd_gs[4 * (MB * (bt + 1) + i)];
+          }
         }
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
+        for (int i = 0; i < MB; i += 2) {
           G = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[bt & 1][i], opb[bt & 1][i], G, 0, 0, 0);
           G2 = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[bt & 1][i + 1], opb[bt & 1][i + 1], G2, 0, 0, 0);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's stores stay behind these loads
       __builtin_amdgcn_wave_barrier();
+      }
     }
   };
   {
