@@ -22,6 +22,12 @@ One "step" = one pass of the hot path over one batch.
 Defaults: 1000 timed steps after 100 warm-up steps.  The chip needs a few tens of milliseconds of sustained load to settle
 at its working clock, so an untimed pre-roll of 0.15 s of steps precedes the W warm-up steps whatever W and K are.
 
+Refuses to run (exit 3) with any GIGALENS_HIP_* kernel override in the environment, checks four samples of the batch it is
+about to time against the float64 oracle (exit 4 on a mismatch or a non-finite result), and at N = 1 adds a `configs` array:
+the other BASELINE.json configs (C1 at batch 1 and 1024, C3 table and direct, C4, C5's per-rank shard), each timed for a
+fraction of a second with the same event ring and priced with the same two fractions (B1 bytes against HBM peak, ISA-counted
+flops of the dispatched kernel against the fp32 vector peak).
+
 Prints ONE JSON line on rank 0 (contract in the round prompt) with two extra objects:
   roofline     -- the dominant kernel, timed INSIDE the timed loop by a ring of HIP-event pairs the library records on the
                   launch stream around every main-kernel launch (no host sync; read back after the loop), plus the
@@ -206,21 +212,167 @@ def epl_series_stats(wl, x_struct):
     return {"mean_terms": ks / n, "mean_four_term_groups": groups / n, "mean_pair_trips": 0.5 * groups / n, "frac_odd": 0.0}
 
 
-def isa_account(kernel_symbol, series):
+_ISA_CACHE = {}
+
+
+def isa_account(kernel_symbol, series, p_live=None):
     """ISA-counted fp32 flops and VALU wave-instructions per pixel of the dispatched kernel (tools/isa_flops.py)."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    if os.path.join(ROOT, "tools") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_flops as isa
-    co = isa.code_object()
-    meta = isa.kernel_metadata(co)
+    if "co" not in _ISA_CACHE:
+        _ISA_CACHE["co"] = isa.code_object()
+        _ISA_CACHE["meta"] = isa.kernel_metadata(_ISA_CACHE["co"])
+    co, meta = _ISA_CACHE["co"], _ISA_CACHE["meta"]
     name = next((k for k, v in meta.items() if v["symbol"] == kernel_symbol), None)
     if name is None:
         return None
     md = meta[name]
     out = {"kernel": name, "vgpr_count": md["vgpr_count"], "vgpr_spill_count": md["vgpr_spill_count"],
            "sgpr_spill_count": md["sgpr_spill_count"], "scratch_bytes": md["scratch_bytes"]}
-    model = isa.execution_model(co, name, md, series)
+    model = isa.execution_model(co, name, md, series, p_live)
     if model is not None:
         out.update(model)
+    return out
+
+
+def oracle_spot_check(wl, pm, sim, z, obs, err, n=4):
+    """Before anything is timed: the first `n` samples of the very batch the loop will run, HIP log-likelihood against the
+    float64 oracle on the same pixel grid (rtol 1e-5, BASELINE.json north_star), and a finite gradient.  The oracle is the
+    checker here, never the thing measured."""
+    from oracle import ref_torch as ref
+    from tests.helpers import struct_from_packed
+    import numpy as np
+    ll = pm.log_like(sim, z).detach().double().cpu().numpy()[:n]
+    lp, _, g = pm.log_prob_and_grad(sim, z)
+    finite = bool(torch.isfinite(lp).all() and torch.isfinite(g).all())
+    packed = sim._layout.pack(pm.bij.forward(z[:n].detach()), n, z.device).double().cpu()
+    rs = ref.RefSimulator(wl.phys_model, wl.sim_config, n, dtype=torch.float64)
+    with torch.no_grad():
+        ll_o, _ = ref.stats_pixels(rs, struct_from_packed(wl.phys_model, packed), obs.cpu().numpy(), wl.background_rms, wl.exp_time,
+                                   error_map=None if err is None else err.cpu().numpy())
+    rel = float(np.max(np.abs(ll - ll_o.numpy()) / np.abs(ll_o.numpy())))
+    return {"samples": n, "loglike_max_rel_err_vs_f64_oracle": float(f"{rel:.3e}"), "rtol": 1e-5,
+            "logprob_and_grad_finite": finite, "ok": bool(rel <= 1e-5 and finite)}
+
+
+def build_case(name, kw, workloads, ForwardProbModel, LensSimulator, dev, rank=0):
+    wl = workloads.make(name, **kw)
+    obs, err, _ = workloads.synthetic_observation(wl, LensSimulator)
+    pm = ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time,
+                          error_map=None if err is None else err.cpu().numpy(), include_positions=False)
+    sim = LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    from gigalens_amd import dist as gdist
+    x = wl.prior.sample(wl.batch, generator=gdist.rank_generator(0, rank))
+    z = pm.bij.inverse(x).to(dev).contiguous()
+    return wl, obs, err, pm, sim, x, z
+
+
+def roofline_of(model, wl, sim, x, kernel_ms, ms_per_step, err, stride):
+    """B1 (HBM, nominal) and ISA-counted VALU fractions of the dispatched main kernel from its event-ring durations."""
+    B, N, P = wl.batch, model.N, model.P
+    n_planes = 1 + (1 if err is not None else 0)
+    bytes_b1 = 2 * 4 * N + 2 * 4 * P
+    bytes_b2 = 4 * (2 * P + 2) + 4 * N * n_planes / B
+    k_mean = sum(kernel_ms) / len(kernel_ms)
+    achieved = bytes_b1 * B / (k_mean * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "kernel_ms": round(k_mean, 5), "kernel_ms_p10": round(_pct(kernel_ms, 0.1), 5),
+            "kernel_ms_p50": round(_pct(kernel_ms, 0.5), 5), "kernel_ms_p90": round(_pct(kernel_ms, 0.9), 5),
+            "kernel_launches_timed": len(kernel_ms), "kernel_event_stride": stride,
+            "kernel_share_of_step": round(k_mean / ms_per_step, 4),
+            "algorithmic_bytes_per_sim_B1": bytes_b1, "algorithmic_bytes_per_sim_B2": round(bytes_b2, 1),
+            "kernel_sims_per_s": round(B / (k_mean * 1e-3), 1)}
+    series = epl_series_stats(wl, x)
+    p_live = None
+    symbol = model.last_main_kernel()
+    if "gl_shp_kernel" in symbol:  # the share of wave-tiles that ran the shapelet chains, counted by the kernel itself
+        rows = model.partial_rows(B)
+        seen = float(rows[:, :, 3].sum())
+        p_live = float(rows[:, :, 2].sum()) / seen if seen > 0 else 1.0
+        roof["shapelet_live_wave_tile_share"] = round(p_live, 4)
+    try:
+        acct = isa_account(symbol, series, p_live)
+    except Exception as exc:  # the accounting is evidence, never a reason to lose the line
+        acct = {"error": repr(exc)}
+    if acct:
+        roof["isa"] = acct
+        fpp = acct.get("flops_per_pixel")
+        if fpp:
+            tflops = fpp * N * B / (k_mean * 1e-3) / 1e12
+            roof["valu_flop_frac"] = round(tflops / VALU_PEAK_TFLOPS, 4)
+            roof["valu_tflops"] = round(tflops, 2)
+            roof["valu_peak_tflops"] = VALU_PEAK_TFLOPS
+            mf = acct.get("mfma_flops_per_pixel")
+            if mf:  # exact-fp32 MFMA work rides the matrix pipe (same 157.3 TFLOP/s peak), reported beside the VALU figure
+                roof["mfma_tflops"] = round(mf * N * B / (k_mean * 1e-3) / 1e12, 2)
+    return roof, series
+
+
+def timed_steps(step, model, steps, warmup, preroll_s, stride, sync_barrier=None):
+    """W warm-up steps, then K timed steps with the library's event ring around every stride-th main launch."""
+    t_pre, n_pre = time.perf_counter(), 0
+    while time.perf_counter() - t_pre < preroll_s:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        n_pre += 20
+    for _ in range(warmup):
+        step()
+    n_ev = (steps + stride - 1) // stride
+    model.set_timing(n_ev, stride)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sorted(model.timing_drain())
+    model.set_timing(0)
+    return elapsed, kernel_ms, n_pre
+
+
+EXTRA_CONFIGS = [  # the other BASELINE.json configs, measured after the headline line's loop (N = 1 only), a fraction of a second each
+    ("C1", dict(), "BASELINE.json configs[0]: SIE lens + Sersic source, 64x64 px, batch 1"),
+    ("C1", dict(batch=1024), "configs[0] model at batch 1024"),
+    ("C3", dict(interpolate=True), "BASELINE.json configs[2]: Shapelets n_max=10 source, 128x128 px, batch 1024 (table mode, the reference's default)"),
+    ("C3", dict(interpolate=False), "configs[2], direct (Hermite recurrence) mode"),
+    ("C4", dict(), "BASELINE.json configs[3]: 8 NFW halos + 20 Sersic sources, 256x256 px, batch 512"),
+    ("C5", dict(), "BASELINE.json configs[4]: per-rank shard (256 particles) of the 2048-particle cluster-model SVI, forward+gradient"),
+]
+
+
+def measure_extra_configs(dev, steps_cap=200):
+    from gigalens_amd import workloads
+    from gigalens_amd.model import ForwardProbModel
+    from gigalens_amd.simulator import LensSimulator
+    out = []
+    for name, kw, what in EXTRA_CONFIGS:
+        try:
+            wl, obs, err, pm, sim, x, z = build_case(name, kw, workloads, ForwardProbModel, LensSimulator, dev)
+            check = oracle_spot_check(wl, pm, sim, z, obs, err, n=2 if sim._model.N > 16384 else 4)
+            probe_t = time.perf_counter()
+            for _ in range(3):
+                pm.log_prob_and_grad(sim, z)
+            torch.cuda.synchronize()
+            per = max((time.perf_counter() - probe_t) / 3, 1e-5)
+            steps = int(min(steps_cap, max(20, 0.25 / per)))
+            elapsed, kernel_ms, _ = timed_steps(lambda: pm.log_prob_and_grad(sim, z), sim._model, steps, max(5, steps // 10), 0.05, 4)
+            ms = 1e3 * elapsed / steps
+            roof, series = roofline_of(sim._model, wl, sim, x, kernel_ms, ms, err, 4)
+            out.append({"config": what, "workload": f"{wl.name}: {wl.description}", "batch": wl.batch, "pixels": sim._model.N,
+                        "params_per_sample": sim._model.P, "steps": steps, "ms_per_step": round(ms, 4),
+                        "sims_per_s": round(wl.batch * steps / elapsed, 1), "kernel": roof.get("isa", {}).get("kernel"),
+                        "kernel_ms": roof["kernel_ms"], "hbm_frac_B1": roof["frac"], "valu_flop_frac": roof.get("valu_flop_frac"),
+                        "valu_insts_per_pixel": roof.get("isa", {}).get("valu_insts_per_pixel"),
+                        "flops_per_pixel": roof.get("isa", {}).get("flops_per_pixel"),
+                        "shapelet_live_wave_tile_share": roof.get("shapelet_live_wave_tile_share"),
+                        "epl_series": series, "oracle_spot_check": check})
+            del pm, sim, z
+            torch.cuda.empty_cache()
+        except Exception as exc:  # a config that fails must not cost the headline line
+            out.append({"config": what, "error": repr(exc)})
     return out
 
 
@@ -235,6 +387,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the workload's)")
     ap.add_argument("--num-pix", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (the `configs` array of the line)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record the per-launch event pairs inside the timed loop (roofline is then null)")
     ap.add_argument("--kernel-event-stride", type=int, default=8,
@@ -278,18 +431,19 @@ def main():
         gdist.barrier()
         torch.cuda.synchronize()
     mode = args.mode if args.mode != "auto" else ("svi" if world > 1 else "fwdgrad")
-    wl = workloads.make(args.workload, num_pix=args.num_pix, batch=args.batch)
-    obs, err, _ = workloads.synthetic_observation(wl, LensSimulator)
-    pm = ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time,
-                          error_map=None if err is None else err.cpu().numpy(), include_positions=False)
-    sim = LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    wl, obs, err, pm, sim, x, z = build_case(args.workload, dict(num_pix=args.num_pix, batch=args.batch), workloads,
+                                             ForwardProbModel, LensSimulator, dev, rank)
     model = sim._model
     B, N, P = wl.batch, model.N, model.P
-    x = wl.prior.sample(B, generator=gdist.rank_generator(0, rank))
     series = epl_series_stats(wl, x)
-    z = pm.bij.inverse(x).to(dev).contiguous()
     d = z.shape[1]
     n_coll = 1 + d + d * (d + 1) // 2
+    # the batch the loop will run, checked against the float64 oracle BEFORE anything is timed (4 samples; a wrong or
+    # non-finite result ends the run: a line is never printed for numbers nobody looked at)
+    check = oracle_spot_check(wl, pm, sim, z, obs, err, n=2 if N > 16384 else 4) if rank == 0 else None
+    if check is not None and not check["ok"]:
+        sys.stderr.write(f"bench.py: the timed batch does not match the oracle: {check}\n")
+        sys.exit(4)
 
     if mode == "svi":
         # surrogate state: the reference's SVI start (tf/inference.py:47-72: mean = a MAP-like point, scale 1e-3 I).  The mean
@@ -355,7 +509,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        last = step()
     torch.cuda.synchronize()
     gdist.barrier()
     elapsed = time.perf_counter() - t0
@@ -365,7 +519,9 @@ def main():
     kernel_ms = sorted(model.timing_drain()) if events else []  # the most recent n_ev recorded launches
     if events:
         model.set_timing(0)
-    kernel_symbol = model.last_main_kernel()
+    # the last timed step's outputs must be finite numbers (a NaN or an untouched buffer would print the same line)
+    outs = last if isinstance(last, (tuple, list)) else (last,)
+    finite_after = all(bool(torch.isfinite(t).all()) for t in outs if torch.is_tensor(t))
     # beside the line's value (not part of it): with several ranks, the same K steps of the plain forward+gradient call on
     # each rank's shard and NO collective -- how MAP and HMC shard (jax/inference.py:32-80,157-208) -- so that the cost of the
     # SVI step's extra launches and of its all-reduce can be read off the line
@@ -387,41 +543,19 @@ def main():
                    "what": "ForwardProbModel.log_prob_and_grad on every rank's shard, no collective (MAP / HMC sharding)"}
 
     if rank == 0:
+        if not finite_after:
+            sys.stderr.write("bench.py: the timed loop's last step returned non-finite values\n")
+            sys.exit(4)
         ms_per_step = 1e3 * elapsed / args.steps
         sims = B * world * args.steps / elapsed
-        # algorithmic bytes per sim: B1 = simulate() boundary (image out + cotangent in + params/grads),
-        # B2 = fused log_prob boundary (what this kernel actually has to move)
-        n_planes = 1 + (1 if err is not None else 0)
-        bytes_b1 = 2 * 4 * N + 2 * 4 * P
-        bytes_b2 = 4 * (2 * P + 2) + 4 * N * n_planes / B
         roofline = None
         if kernel_ms:
-            k_mean = sum(kernel_ms) / len(kernel_ms)
-            achieved = bytes_b1 * B / (k_mean * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 6),
-                        "traffic": None,  # HBM bytes are a PMC figure; the profiled value lives in profiles/ (see traffic_profiled)
-                        "kernel_ms": round(k_mean, 5), "kernel_ms_p10": round(_pct(kernel_ms, 0.1), 5),
-                        "kernel_ms_p50": round(_pct(kernel_ms, 0.5), 5), "kernel_ms_p90": round(_pct(kernel_ms, 0.9), 5),
-                        "kernel_launches_timed": len(kernel_ms), "kernel_event_stride": stride,
-                        "kernel_share_of_step": round(k_mean / ms_per_step, 4),
-                        "algorithmic_bytes_per_sim_B1": bytes_b1, "algorithmic_bytes_per_sim_B2": round(bytes_b2, 1),
-                        "kernel_sims_per_s": round(B / (k_mean * 1e-3), 1),
-                        "note": "path is VALU/transcendental-bound (SURVEY 8d): the HBM fraction is priced with the "
+            roofline, series_fg = roofline_of(model, wl, sim, x, kernel_ms, ms_per_step, err, stride)
+            if mode != "svi":
+                series = series_fg
+            roofline["note"] = ("path is VALU/transcendental-bound (SURVEY 8d): the HBM fraction is priced with the "
                                 "simulate()-boundary bytes B1 as the metric asks; the binding bound is the fp32 vector rate "
-                                "(valu_flop_frac)"}
-            try:
-                acct = isa_account(kernel_symbol, series)
-            except Exception as exc:  # the accounting is evidence, never a reason to lose the line
-                acct = {"error": repr(exc)}
-            if acct:
-                roofline["isa"] = acct
-                fpp = acct.get("flops_per_pixel")
-                if fpp:
-                    tflops = fpp * N * B / (k_mean * 1e-3) / 1e12
-                    roofline["valu_flop_frac"] = round(tflops / VALU_PEAK_TFLOPS, 4)
-                    roofline["valu_tflops"] = round(tflops, 2)
-                    roofline["valu_peak_tflops"] = VALU_PEAK_TFLOPS
+                                "(valu_flop_frac)")
             try:  # PMC traffic of an earlier profiled run of the same kernel, named as such (not a measurement of this run)
                 prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
                 if prof and args.workload.upper() == "C2" and B == 1024:
@@ -449,9 +583,14 @@ def main():
                                 "ForwardProbModel.log_prob_and_grad: log_prob forward + gradient w.r.t. z (bijector, "
                                 "kernels, prior) in one native launch sequence")},
             "roofline": roofline,
+            "oracle_spot_check": check,
         }
         if sharded is not None:
             out["sharded_fwdgrad_without_collective"] = sharded
+        if world == 1 and not args.no_configs and args.workload.upper() == "C2":
+            del pm, sim, z
+            torch.cuda.empty_cache()
+            out["configs"] = measure_extra_configs(dev)  # the other BASELINE configs, each with both fractions
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             n_cpu = args.cpu_samples or (256 if N <= 16384 else 32)
             out["cpu_baseline"] = cpu_baseline(wl, obs, seconds=args.cpu_seconds, sample_batch=min(n_cpu, B))

@@ -100,6 +100,7 @@ SYMBOLS = {
     "gl_model_set_timing_stride": (c_int, [c_void_p, c_int]),
     "gl_model_timing_drain": (c_int, [c_void_p, POINTER(c_float), c_int, POINTER(c_int)]),
     "gl_model_last_main_kernel": (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
+    "gl_model_launch_shape": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),
     "gl_last_error": (c_char_p, []),
     "gl_version": (c_char_p, []),
 }
@@ -548,6 +549,15 @@ class Model:
         buf = ctypes.create_string_buffer(1024)
         _check(lib().gl_model_last_main_kernel(self._h, buf, len(buf)))
         return buf.value.decode()
+
+    def partial_rows(self, B):
+        """The per-(sample, chunk) partial rows ``[B, n_chunks, A]`` the most recent gradient call on ``B`` samples left in the
+        workspace (a view; measurement aid, see ``gl_model_launch_shape``)."""
+        chunk, nc, row, off = c_int(), c_int(), c_int(), c_size_t()
+        _check(lib().gl_model_launch_shape(self._h, B, ctypes.byref(chunk), ctypes.byref(nc), ctypes.byref(row), ctypes.byref(off)))
+        ws = self._workspace(B)
+        n = B * nc.value * row.value
+        return ws[off.value:off.value + 4 * n].view(torch.float32).view(B, nc.value, row.value)
 
     def last_main_ms(self):
         ms = c_float()

@@ -822,6 +822,18 @@ int gl_model_last_main_kernel(const gl_model* m, char* buf, size_t cap) {
   return GL_OK;
 }
 
+int gl_model_launch_shape(const gl_model* m, int B, int* chunk_px, int* n_chunks, int* row_floats, size_t* partial_offset_bytes) {
+  if (!m || B < 1) return fail(GL_EINVAL, "bad argument");
+  int chunk = 0, nc = 0;
+  chunking(m, B, &chunk, &nc);
+  const Workspace w = carve(m, B, nullptr);
+  if (chunk_px) *chunk_px = chunk;
+  if (n_chunks) *n_chunks = nc;
+  if (row_floats) *row_floats = m->A;
+  if (partial_offset_bytes) *partial_offset_bytes = (size_t)((const char*)w.partial - (const char*)nullptr);
+  return GL_OK;
+}
+
 void gl_model_destroy(gl_model* m) {
   if (!m) return;
   for (hipEvent_t e : m->evs) (void)hipEventDestroy(e);

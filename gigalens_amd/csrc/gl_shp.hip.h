@@ -205,6 +205,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
 
   const int p0 = chunk * a.chunk;
   const int p1 = min(p0 + a.chunk, a.N);
+  int n_tiles = 0, n_live = 0;  // wave-tiles seen / not skipped (wave-uniform): a measurement aid in the row's two pad slots
   auto tile = [&](int base, auto check_tag) {
     constexpr bool CHECK = decltype(check_tag)::value;
     unsigned jj[2], pidx[2];
@@ -241,11 +242,13 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     // shapelets.py:58-60), so a wave none of whose 128 pixels is inside skips the gathers, both chains, the LDS traffic and
     // the MFMAs -- on a lensed field that is every tile away from the arcs (wave-uniform branch; the values are the same zeros).
     bool shp_live = true;
+    ++n_tiles;
     if constexpr (INTERP) {
       const bool inr = (shp_in_table(ps0.u) && shp_in_table(ps0.v)) || (shp_in_table(ps1.u) && shp_in_table(ps1.v));
       shp_live = __builtin_amdgcn_ballot_w64(inr) != 0;
     }
     if (shp_live) {
+      ++n_live;
       ShpRows<NP> r0;
       shp_pixel_gather<NP, INTERP>(a.shp_tab2, ps0, r0);
       const float l0 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, r0, wr_gx, wr_y, ps0);
@@ -397,6 +400,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     for (int k = 0; k < NVP; ++k) vals[k] = 0.f;
     vals[0] = (MODE == LL_GRAD) ? hsum(st0) : 0.f;
     vals[1] = (MODE == LL_GRAD) ? hsum(st1) : 0.f;
+    vals[2] = lane == 0 ? (float)n_live : 0.f;   // pad slots of the row (finalize does not read them): how many of the
+    vals[3] = lane == 0 ? (float)n_tiles : 0.f;  // workgroup's wave-tiles ran the shapelet chains -- bench.py's work model
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int kind = LK::kinds[i];

@@ -20,9 +20,11 @@ PMC counter SQ_INSTS_VALU of the same launch (profiles/r2_isa_flops.md).
     python3 tools/isa_flops.py --list            # every kernel: VGPRs, spills, scratch
 """
 import argparse
+import atexit
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -45,7 +47,9 @@ PACKED = re.compile(r"^v_pk_(fma|mul|add)_f32")
 def code_object(lib=LIB, workdir=None):
     """Paths of the gfx950 code objects extracted from `lib`: the library is several translation units, each contributing one
     offload bundle to the .hip_fatbin section."""
-    workdir = workdir or tempfile.mkdtemp(prefix="gl_isa_")
+    if workdir is None:
+        workdir = tempfile.mkdtemp(prefix="gl_isa_")
+        atexit.register(shutil.rmtree, workdir, True)  # the extracted code objects are scratch: gone when the caller exits
     fat = os.path.join(workdir, "fatbin")
     subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
     blob = open(fat, "rb").read()
@@ -298,10 +302,101 @@ def pair_model(cfg, mean_series_pairs, frac_odd, W=2, frac_short=0.0):
     return per_pixel, detail
 
 
-def execution_model(co, name, md, series):
+def _hot_loops(cfg, min_valu=100):
+    """Top-level loops with a substantial body, in address order (the CHECK=false steady-state tile loop comes first)."""
+    return sorted([l for l in cfg.loops if l.parent is None and cfg.tally(l.blocks)["valu"] >= min_valu], key=lambda l: l.header)
+
+
+def shp_model(cfg, mean_series_pairs, p_live, W=2):
+    """gl_shp_kernel (csrc/gl_shp.hip.h), gradient / likelihood modes.  The steady-state tile loop is the first hot top-level
+    loop; per trip (two pixels per lane):
+      * blocks that dominate the latch run once,
+      * the EPL series loop runs `mean_series_pairs` times,
+      * the blocks behind the wave-uniform "any pixel inside the shapelet table" branch -- recognised by what only they hold:
+        the table gathers' packed interpolation / contraction (>= 8 packed instructions) or the MFMAs -- run with probability
+        `p_live`, the share of wave-tiles the kernel itself counted as live (pad slots of its partial rows),
+      * the remaining conditional blocks (optional plane loads, the few moves of the skip path) are counted as executed."""
+    tile = _hot_loops(cfg)[0]
+    inner = sorted(tile.children, key=lambda l: l.header)
+    inner_blocks = set().union(*[c.blocks for c in inner]) if inner else set()
+    own = tile.blocks - inner_blocks
+    latches = [b for b in tile.blocks if tile.header in cfg.succ[b]]
+    mandatory = set(own)
+    for lt in latches:
+        mandatory &= cfg.dom[lt]
+    out = {k: float(v) for k, v in cfg.tally(mandatory).items()}
+    detail = dict(tile_loop_header=hex(tile.header), pixels_per_lane_per_trip=W, mandatory=cfg.tally(mandatory), inner=[],
+                  conditional=[], p_live=p_live)
+    for c in inner:
+        t = cfg.tally(c.blocks)
+        for k in out:
+            out[k] += t[k] * mean_series_pairs
+        detail["inner"].append(dict(header=hex(c.header), per_trip=t, trips=mean_series_pairs))
+    for b in sorted(own - mandatory):
+        t = cfg.tally([b])
+        live = t["packed"] >= 8 or t["mfma"] > 0
+        prob = p_live if live else 1.0
+        for k in out:
+            out[k] += t[k] * prob
+        if t["valu"] or t["mfma"]:
+            detail["conditional"].append(dict(block=hex(b), per_trip={k: v for k, v in t.items() if v}, probability=prob,
+                                              what="shapelet chains of a live wave-tile" if live else "counted as executed"))
+    per_pixel = {k: v / W for k, v in out.items()}
+    detail["per_pixel"] = per_pixel
+    return per_pixel, detail
+
+
+def cluster_model(cfg, W=2):
+    """gl_cluster_kernel (csrc/gl_cluster.hip.h) at full capacity (every compile-time component slot in use: BASELINE configs 4
+    and 5).  The steady-state tile loop is the first hot top-level loop; its component bodies sit behind wave-uniform count
+    guards (always taken at capacity).  The only blocks that do not run every trip are the lane-by-lane closed-form NFW
+    fallback (X outside the h(X) table or exactly 1: a handful of lanes per launch): conditional blocks of scalar-per-lane code
+    -- no scalar loads, no memory, at most two packed instructions, unlike every component body -- weighted 0.  Checked against
+    SQ_INSTS_VALU in profiles/ (C4: 1248 modelled vs 1242-1253 counted per pixel)."""
+    tile = _hot_loops(cfg, 1000)[0]
+    latches = [b for b in tile.blocks if tile.header in cfg.succ[b]]
+    mandatory = set(tile.blocks)
+    for lt in latches:
+        mandatory &= cfg.dom[lt]
+    out = {k: float(v) for k, v in cfg.tally(mandatory).items()}
+    n_fallback = 0
+    for b in sorted(tile.blocks - mandatory):
+        t = cfg.tally([b])
+        fallback = t["smem"] == 0 and t["vmem"] == 0 and t["lds"] == 0 and t["packed"] <= 2 and t["valu"] >= 3
+        if fallback:
+            n_fallback += 1
+            continue
+        for k in out:
+            out[k] += t[k]
+    per_pixel = {k: v / W for k, v in out.items()}
+    detail = dict(tile_loop_header=hex(tile.header), pixels_per_lane_per_trip=W, n_blocks=len(tile.blocks),
+                  fallback_blocks_weighted_zero=n_fallback, per_pixel=per_pixel)
+    return per_pixel, detail
+
+
+def execution_model(co, name, md, series, p_live=None):
     """Dynamic per-pixel counts of a kernel this tool has an execution model for (the specialised pair / static kernels in a
     likelihood or gradient mode), else None.  `series`: dict(mean_pair_trips, frac_odd[, frac_short]) of the batch, or None
     for models without EPL."""
+    weights = "v_pk_fma 4, v_pk_mul/add 2, v_fma 2, v_mul/add/sub 1, transcendental 1, other 0 (per lane)"
+    ms = re.search(r"gl_shp_kernel<(\d+),", name)
+    mc = re.search(r"gl_cluster_kernel<(\d+),", name)
+    if ms or mc:
+        if int((ms or mc).group(1)) in (0,):
+            return None
+        cfg = CFG(disassemble(md["co"], md["symbol"]))
+        s_ = series or {}
+        if ms:
+            per_pixel, detail = shp_model(cfg, float(s_.get("mean_pair_trips", 0.0)), 1.0 if p_live is None else float(p_live))
+        else:
+            per_pixel, detail = cluster_model(cfg)
+        out = dict(flops_per_pixel=round(per_pixel["flops"], 2), valu_insts_per_pixel=round(per_pixel["valu"], 2),
+                   trans_per_pixel=round(per_pixel["trans"], 2), packed_insts_per_pixel=round(per_pixel["packed"], 2),
+                   mfma_per_pixel=round(per_pixel["mfma"], 3), flop_weights=weights,
+                   model={k: v for k, v in detail.items() if k != "per_pixel"})
+        if per_pixel["mfma"]:  # exact-fp32 16x16x4 MFMA: 2 * 16 * 16 * 4 flops per wave-instruction = 32 per lane
+            out["mfma_flops_per_pixel"] = round(per_pixel["mfma"] * 32, 2)
+        return out
     m = re.search(r"gl_pair_kernel<(\d+), (float __vector\(2\)|float),", name)
     W = None
     if m:
