@@ -58,3 +58,14 @@ def oracle_loglike_chunked(wl, packed64, obs, err, n, step=16):
             ll, _ = ref.stats_pixels(rs, params, obs, wl.background_rms, wl.exp_time, error_map=err)
             out.append(ll.numpy())
     return np.concatenate(out)
+
+
+def grad_col_err(g, g_o):
+    """Gradient error per element relative to the scale of its own parameter COLUMN, ``S_k = max_b |g_o[b, k]|``: the gate of the
+    pixel-likelihood parity tests (a column whose values are orders of magnitude below the row's largest entry is held to
+    its own scale, not the row's).  Columns that vanish identically on this batch are held to 1e-3 of the batch-wide
+    maximum (table-mode shapelets: a source that misses the field has an all-zero row)."""
+    g, g_o = np.asarray(g, dtype=np.float64), np.asarray(g_o, dtype=np.float64)
+    finite = np.where(np.isfinite(g_o), np.abs(g_o), 0.0)
+    S = np.maximum(finite.max(axis=0, keepdims=True), 1e-3 * finite.max())
+    return np.abs(g - g_o) / np.maximum(S, 1e-300)

@@ -3,7 +3,12 @@
 Tolerances (fp32 kernels vs the float64 restatement of the reference, BASELINE.json north_star):
   * image pixels        rtol 2e-5 of the image maximum
   * chi^2 / log-like    rtol 1e-5
-  * parameter gradients rtol 2e-3 of the per-sample gradient maximum (fp32 sums of ~N terms with cancellation)
+  * parameter gradients: every element within GRAD_RTOL_COL of the scale of its own parameter COLUMN (max over the batch of
+    the oracle's |d/d theta_k|) at the reduced sizes, GRAD_RTOL_COL_FULL at the full BASELINE sizes.  Measured worst cases
+    (tools/dev/grad_accuracy_scan.py, profiles/README.md): 2.2e-4 over the reduced cases; full size C2 6e-5, C3 1.4e-4,
+    C3D 9e-4, C4 1e-3 -- where the reference's own algorithm evaluated in float32 (the oracle at dtype float32) sits at
+    2e-4, 1e-4, 2.5e-4 and 1.5 (sic: NFW scale-radius columns) of the same scale.  Round 2 held gradients to 2e-3 of the
+    ROW maximum, which let a small column be wrong by its own size.
 """
 import math
 
@@ -17,7 +22,9 @@ pytestmark = pytest.mark.gpu
 
 IMG_RTOL = 2e-5
 LL_RTOL = 1e-5
-GRAD_RTOL = 2e-3
+GRAD_RTOL = 2e-3          # per element, relative to max(|g|, 1e-2 column scale): the dPIE / extra-profile suites
+GRAD_RTOL_COL = 3e-4      # per element, relative to its column's scale: reduced-size cases
+GRAD_RTOL_COL_FULL = 1.5e-3  # the same at the full BASELINE sizes (65 536-term sums with cancellation)
 
 
 @pytest.fixture(scope="module")
@@ -161,11 +168,9 @@ def test_simulate_loglike_grad_vs_oracle(gl, name, kw):
     assert np.allclose(ll.detach().cpu().numpy(), ll_o, rtol=LL_RTOL)
     assert np.allclose(red.detach().cpu().numpy(), red_o, rtol=LL_RTOL)
     g = p.grad.cpu().numpy()
-    # per-sample gradient scale; a sample whose source misses the field entirely has an all-zero oracle
-    # gradient, so the floor is tied to the batch-wide scale (table-mode shapelets are discontinuous at |u|=5)
-    scale = np.maximum(np.abs(g_o).max(axis=1, keepdims=True), 1e-3 * np.abs(g_o).max())
-    bad = np.abs(g - g_o) > GRAD_RTOL * scale + 1e-6
-    assert not bad.any(), (np.argwhere(bad)[:5], g[bad][:5], g_o[bad][:5], scale.ravel())
+    # every element against the scale of its own parameter column (H.grad_col_err)
+    bad = H.grad_col_err(g, g_o) > GRAD_RTOL_COL
+    assert not bad.any(), (np.argwhere(bad)[:5], g[bad][:5], g_o[bad][:5], H.grad_col_err(g, g_o).max())
 
     # forward-only entry (grad_params == NULL, a different kernel instantiation) agrees to rounding
     ll2, _ = pm._pixel_stats_packed(sim, packed)
@@ -181,8 +186,8 @@ def test_simulate_loglike_grad_vs_oracle(gl, name, kw):
     ll3 = -0.5 * (((im - obs) ** 2 / sig2).sum((-2, -1)) + torch.log(2 * math.pi * sig2).sum((-2, -1)))
     ll3.sum().backward()
     g3 = p2.grad.cpu().numpy()
-    bad = np.abs(g3 - g_o) > GRAD_RTOL * scale + 1e-6
-    assert not bad.any(), (np.argwhere(bad)[:5], g3[bad][:5], g_o[bad][:5])
+    bad = H.grad_col_err(g3, g_o) > GRAD_RTOL_COL
+    assert not bad.any(), (np.argwhere(bad)[:5], g3[bad][:5], g_o[bad][:5], H.grad_col_err(g3, g_o).max())
     assert np.allclose(ll3.detach().cpu().numpy(), ll_o, rtol=5e-5)
 
 
@@ -396,7 +401,13 @@ def test_full_size_properties(gl, name, kw):
                                                 None if err is None else err.cpu().numpy(), n_o)
     assert np.allclose(ll.detach()[:n_o].cpu().numpy(), ll_o, rtol=LL_RTOL)
     assert np.allclose(ll_img[:n_o].cpu().numpy(), ll_o, rtol=LL_RTOL)
-    assert np.abs(p.grad[:n_o].cpu().numpy() - g_o).max() <= GRAD_RTOL * np.abs(g_o).max(1, keepdims=True).max()
+    # every element of the checked rows against the scale of its own parameter column; at full size the column scale is taken
+    # over the WHOLE batch (the product's own gradient serves as the scale only: four oracle rows alone make a noisy maximum)
+    g_all = p.grad.cpu().numpy()
+    S_col = np.maximum(np.abs(g_all).max(axis=0, keepdims=True), 1e-3 * np.abs(g_all).max())
+    col_err = np.abs(g_all[:n_o] - g_o) / S_col
+    print(f"{name} {kw}: worst gradient error relative to the column scale {col_err.max():.2e}")
+    assert col_err.max() <= GRAD_RTOL_COL_FULL, (col_err.max(), np.unravel_index(col_err.argmax(), col_err.shape))
     # (2) batch independence: a sub-batch gives the same rows (another batch size means another pixel chunking, i.e. another
     # fixed summation order of the fp32 partial sums: a few ulps of the 65 536-term sum)
     sim_small = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=7)
@@ -536,10 +547,9 @@ def test_nfw_table_ranges_vs_oracle(gl, cluster, monkeypatch):
     ll.sum().backward()
     assert ("gl_cluster_kernel" if cluster == "1" else "gl_main_kernel") in sim._model.last_main_kernel()
     assert np.allclose(ll.detach().cpu().numpy(), ll_o, rtol=LL_RTOL)
-    scale = np.abs(g_o).max(axis=1, keepdims=True)
     g = p.grad.cpu().numpy()
-    bad = ~(np.abs(g - g_o) <= GRAD_RTOL * scale + 1e-6)
-    assert not bad.any(), (np.argwhere(bad)[:8], g[bad][:8], g_o[bad][:8], scale.ravel())
+    bad = ~(H.grad_col_err(g, g_o) <= GRAD_RTOL_COL)
+    assert not bad.any(), (np.argwhere(bad)[:8], g[bad][:8], g_o[bad][:8], H.grad_col_err(g, g_o).max())
 
 
 def test_dispatched_kernels_do_not_spill(gl):
@@ -628,15 +638,26 @@ def test_psf_supersample_vs_oracle(gl, ss, ksize, n, B, monkeypatch):
     assert np.allclose(ll.detach().cpu().numpy(), ll_o.detach().numpy(), rtol=LL_RTOL)
     assert np.allclose(red.detach().cpu().numpy(), red_o.detach().numpy(), rtol=LL_RTOL)
     g, go = p.grad.cpu().numpy(), g_o.numpy()
-    scale = np.abs(go).max(axis=1, keepdims=True)
-    assert np.all(np.abs(g - go) <= GRAD_RTOL * scale + 1e-6), (np.abs(g - go) / scale).max()
+    # Per row, the gate is the column-scale bound -- unless the reference's own algorithm evaluated in float32 (the oracle at
+    # dtype float32) is itself further than that from the float64 truth on this row: a sample whose source centre sits on a
+    # pixel sums terms ~ R^(1/n - 2) of both signs, and float32 evaluation of ANY formulation loses digits there (seed 4,
+    # row 1 of the 60 x 60 cases: float32 oracle 3.4e-4, HIP 3.8e-3, every other row 3e-7).  Such a row is held to 15 x the
+    # float32 oracle's own distance (tools/dev/psf_grad_probe.py).
+    rs32 = ref.RefSimulator(phys, cfg, B, dtype=torch.float32, supersampled_kernel=psf)
+    p32 = packed.cpu().float().requires_grad_(True)
+    ll_32, _ = ref.stats_pixels(rs32, H.struct_from_packed(phys, p32), obs, 0.2, 100.0)
+    (g_32,) = torch.autograd.grad(ll_32.sum(), p32)
+    e_hip, e_32 = H.grad_col_err(g, go), H.grad_col_err(g_32.numpy(), go)
+    tol_row = np.maximum(GRAD_RTOL_COL, 15.0 * e_32.max(axis=1, keepdims=True))
+    assert np.all(e_hip <= tol_row), (e_hip.max(axis=1), e_32.max(axis=1))
     # image-boundary pair through autograd (gl_simulate_bwd with the transposed PSF / pooling)
     p2 = packed.clone().requires_grad_(True)
     w = torch.as_tensor(r.normal(size=(B, n, n)).astype(np.float32), device=p2.device)
     (sim.simulate(p2) * w).sum().backward()
     (g2_o,) = torch.autograd.grad((rs.simulate(H.struct_from_packed(phys, p64)) * w.cpu().double()).sum(), p64)
-    sc2 = np.abs(g2_o.numpy()).max(axis=1, keepdims=True)
-    assert np.all(np.abs(p2.grad.cpu().numpy() - g2_o.numpy()) <= GRAD_RTOL * sc2 + 1e-6)
+    (g2_32,) = torch.autograd.grad((rs32.simulate(H.struct_from_packed(phys, p32)) * w.cpu()).sum(), p32)
+    e2_hip, e2_32 = H.grad_col_err(p2.grad.cpu().numpy(), g2_o.numpy()), H.grad_col_err(g2_32.numpy(), g2_o.numpy())
+    assert np.all(e2_hip <= np.maximum(GRAD_RTOL_COL, 15.0 * e2_32.max(axis=1, keepdims=True))), (e2_hip.max(axis=1), e2_32.max(axis=1))
     # the z-space entry uses the same path
     z = pm.bij.inverse(prior.sample(B, seed=9)).to("cuda")
     lp, red2, gz = pm.log_prob_and_grad(sim, z)
@@ -666,9 +687,8 @@ def _edge_case(gl, phys, prior, n, B, seed=3):
     ll.sum().backward()
     assert np.allclose(ll.detach().cpu().numpy().reshape(-1), ll_o.reshape(-1), rtol=LL_RTOL)
     g = p.grad.cpu().numpy()
-    scale = np.maximum(np.abs(g_o).max(axis=1, keepdims=True), 1e-3 * np.abs(g_o).max())
-    bad = np.abs(g - g_o) > GRAD_RTOL * scale + 1e-6
-    assert not bad.any(), (np.argwhere(bad)[:5], g[bad][:5], g_o[bad][:5])
+    bad = H.grad_col_err(g, g_o) > GRAD_RTOL_COL
+    assert not bad.any(), (np.argwhere(bad)[:5], g[bad][:5], g_o[bad][:5], H.grad_col_err(g, g_o).max())
 
 
 def test_edge_compositions(gl):
@@ -719,8 +739,7 @@ def test_epl_circular_and_large_batch(gl):
     assert np.all(np.isnan(g_o[:7, 2:4])) and np.all(g[:7, 2:4] == 0)
     keep = np.ones_like(g, dtype=bool)
     keep[:7, 2:4] = False
-    scale = np.nanmax(np.abs(np.where(keep, g_o, np.nan)), axis=1, keepdims=True)
-    assert np.all(np.abs(g - g_o)[keep] <= (GRAD_RTOL * scale + 1e-6).repeat(g.shape[1], 1)[keep])
+    assert H.grad_col_err(np.where(keep, g, 0.0), np.where(keep, g_o, 0.0)).max() <= GRAD_RTOL_COL
     with pytest.raises(__import__("gigalens_amd._native", fromlist=["x"]).NativeLibraryError):
         sim._model.simulate_fwd(torch.zeros((70000, sim._model.P), device="cuda"))  # B > 65535: refused, not truncated
 

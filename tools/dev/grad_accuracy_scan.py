@@ -55,9 +55,22 @@ def scan(name, n_check, floor, **kw):
         _, _, go, _ = H.oracle_loglike_and_grad(wl_o, packed[i0:i0 + m].double().cpu(), obs.cpu().numpy(), err_np, m)
         g_o.append(go)
     g_o = np.concatenate(g_o)
+    # the reference algorithm itself in float32 (the oracle's op-for-op restatement of the TF graph, torch autograd): how far
+    # float32 evaluation alone moves the gradient from the float64 truth -- the yardstick for the HIP path's own distance
+    g_32 = []
+    for i0 in range(0, n_check, step):
+        m = min(step, n_check - i0)
+        wl_o = workloads.make(name, **{**kw, "batch": m})
+        _, _, g32, _ = H.oracle_loglike_and_grad(wl_o, packed[i0:i0 + m].float().cpu(), obs.cpu().numpy(), err_np, m, dtype=torch.float32)
+        g_32.append(g32.astype(np.float64))
+    g_32 = np.concatenate(g_32)
     S = np.abs(g_o).max(axis=0, keepdims=True)
     rel = np.abs(g - g_o) / np.maximum(np.abs(g_o), floor * S + 1e-300)
     per_col = rel.max(axis=0)
+    rel32 = np.abs(g_32 - g_o) / np.maximum(np.abs(g_o), floor * S + 1e-300)
+    per_col32 = rel32.max(axis=0)
+    cs_hip = (np.abs(g - g_o) / np.maximum(S, 1e-300)).max(axis=0)    # error relative to the COLUMN scale S_k
+    cs_f32 = (np.abs(g_32 - g_o) / np.maximum(S, 1e-300)).max(axis=0)
     rowmax = np.abs(g_o).max(axis=1, keepdims=True)
     old_form = (np.abs(g - g_o) / rowmax).max()
     names = column_names(wl.phys_model)
@@ -65,7 +78,14 @@ def scan(name, n_check, floor, **kw):
     out = {"config": name, "kw": {k: v for k, v in kw.items()}, "batch": wl.batch, "pixels": sim._model.N, "n_checked": n_check,
            "floor": floor, "worst_rel": float(per_col[worst]), "worst_column": names[worst] if worst < len(names) else worst,
            "p50_column_rel": float(np.median(per_col)), "err_over_row_max": float(old_form),
-           "columns": {names[k] if k < len(names) else str(k): float(f"{per_col[k]:.3e}") for k in range(len(per_col))}}
+           "col_scale_rel_worst": float(cs_hip.max()), "col_scale_rel_worst_column": names[int(cs_hip.argmax())],
+           "f32_oracle_col_scale_rel_worst": float(cs_f32.max()),
+           "f32_oracle_col_scale_rel_in_that_column": float(cs_f32[int(cs_hip.argmax())]),
+           "f32_oracle_worst_rel": float(per_col32.max()), "f32_oracle_worst_column": names[int(per_col32.argmax())],
+           "f32_oracle_rel_in_hip_worst_column": float(per_col32[worst]),
+           "hip_over_f32_oracle_worst_ratio": float((per_col / np.maximum(per_col32, 1e-12)).max()),
+           "columns": {names[k] if k < len(names) else str(k): [float(f"{per_col[k]:.3e}"), float(f"{per_col32[k]:.3e}")]
+                       for k in range(len(per_col))}}
     print(json.dumps(out), flush=True)
     return out
 
@@ -76,6 +96,12 @@ if __name__ == "__main__":
     ap.add_argument("--n", type=int, default=8)
     ap.add_argument("--floor", type=float, default=1e-2)
     a = ap.parse_args()
+    if a.configs == "cases":  # the reduced-size cases of tests/test_gpu_parity.py::CASES (what the test gate has to hold on)
+        sys.path.insert(0, ROOT)
+        from tests.test_gpu_parity import CASES
+        for name, kw in CASES:
+            scan(name, 64, a.floor, **kw)
+        sys.exit(0)
     for c in a.configs.split(","):
         if c == "C1":
             scan("C1", a.n, a.floor, batch=64)
