@@ -31,6 +31,10 @@ class Adam:
         self.m = self.v = None
         self.t = 0
 
+    def state_tensors(self):
+        """The moment estimates (empty before the first step): what a multi-rank driver re-synchronises with the parameters."""
+        return [t for t in (self.m, self.v) if t is not None]
+
     def _native_ok(self, x, grad):
         return (x.is_cuda and grad.is_cuda and x.dtype == torch.float32 and grad.dtype == torch.float32
                 and x.is_contiguous() and grad.is_contiguous() and x.shape == grad.shape)
@@ -98,6 +102,15 @@ def tril_pack(L: torch.Tensor, diag_shift: float = 1e-6) -> torch.Tensor:
 _TRIL_IDX = {}
 
 
+def _warn_remainder(stage, what, n, world):
+    """The JAX substrate gives every device ``n // dev_cnt`` samples and says nothing about the rest (jax/inference.py:33-38,
+    93-98,159-165); same split here, but the count that is actually run is stated."""
+    if world > 1 and n % world:
+        import warnings
+        warnings.warn(f"{stage}: {what}={n} is not a multiple of the {world} ranks; each rank runs {n // world}, "
+                      f"{n - world * (n // world)} fewer in total (like the reference's n // dev_cnt)", RuntimeWarning, stacklevel=3)
+
+
 def _tril_idx(d, device):
     key = (d, str(device))
     if key not in _TRIL_IDX:
@@ -135,8 +148,9 @@ def svi_step_buffer(mu: torch.Tensor, l_packed: torch.Tensor,
                     log_prob_fn: Optional[Callable[[torch.Tensor], torch.Tensor]],
                     n_local: int, generator: Optional[torch.Generator] = None,
                     value_and_grad_fn: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None,
-                    full_rank: Optional[bool] = None, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """One ELBO evaluation on this rank's particle shard, all-reduced over ranks: the fused buffer
+                    full_rank: Optional[bool] = None, eps: Optional[torch.Tensor] = None, reduce: bool = True) -> torch.Tensor:
+    """One ELBO evaluation on this rank's particle shard, all-reduced over ranks (``reduce=False``: this shard's buffer as it
+    stands, no collective -- what the multi-rank tests average by hand): the fused buffer
     ``[loss, grad_mu (d), grad_l_packed]`` -- ``buf[1:]`` is the gradient of ``cat([mu, l_packed])`` as it stands.
 
     The buffer is identical on every rank: the mean over ranks of the per-rank
@@ -170,7 +184,7 @@ def svi_step_buffer(mu: torch.Tensor, l_packed: torch.Tensor,
         z = _native.svi_sample(mu_c, lp_c, eps, not diag_mode)
         lp, G = value_and_grad_fn(z)
         buf = _native.svi_grad(lp_c, eps, lp.contiguous(), G.contiguous(), not diag_mode)
-        return gdist.allreduce_mean_(buf)
+        return gdist.allreduce_mean_(buf) if reduce else buf
     if diag_mode:
         sdiag = torch.exp(l_packed)
         z = mu + eps * sdiag
@@ -200,7 +214,7 @@ def svi_step_buffer(mu: torch.Tensor, l_packed: torch.Tensor,
         e = torch.exp(l_packed)  # only its diagonal entries are used: L_ii = exp(p_ii) + shift
         g_lp = torch.where(on_diag, gl * e - e / ldiag[idx[0]], gl)
     buf = torch.cat([elbo.reshape(1), g_mu, g_lp])  # ONE fused buffer -> ONE collective
-    return gdist.allreduce_mean_(buf)
+    return gdist.allreduce_mean_(buf) if reduce else buf
 
 
 def _halton2(i: int) -> float:
@@ -274,6 +288,7 @@ class ModellingSequence:
         128x128 x 1024.  ``None`` (default) therefore picks the graph below 3e5 pixel-samples per step; ``True`` /
         ``False`` force it.  Learning-rate schedules and the autograd path always launch step by step."""
         rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
+        _warn_remainder("MAP", "n_samples", n_samples, world)
         lo, hi = gdist.shard_bounds(n_samples, rank, world)
         n_local = hi - lo
         pm = self.prob_model
@@ -323,9 +338,15 @@ class ModellingSequence:
         return gdist.gather_rows(trial)
 
     def SVI(self, optimizer: Adam, start_mean, n_vi=250, init_scales=1e-3, num_steps=500, seed=2, full_rank=True,
-            progress=None):
-        """tf/inference.py:47-93 (full-rank or mean-field surrogate), sharded like jax/inference.py:91-144."""
+            progress=None, sync_every=200):
+        """tf/inference.py:47-93 (full-rank or mean-field surrogate), sharded like jax/inference.py:91-144.
+
+        Every rank applies the same all-reduced gradient to the same parameters, so the surrogates stay identical as long as
+        the collective returns the same bits on every rank (RCCL's ring / tree all-reduce does; checked bitwise in the
+        two-rank tests).  As a guard that costs one 35 KB broadcast per ``sync_every`` steps, rank 0's parameters and Adam
+        moments overwrite the others' (SURVEY 8e); ``sync_every=0`` turns it off."""
         rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
+        _warn_remainder("SVI", "n_vi", n_vi, world)
         n_local = max(1, n_vi // world)
         pm = self.prob_model
         lens_sim = LensSimulator(self.phys_model, self.sim_config, bs=n_local)
@@ -349,6 +370,10 @@ class ModellingSequence:
                                   full_rank=full_rank, eps=pool.next())
             loss = buf[0]
             optimizer.step(params, buf[1:])  # the fused buffer's tail IS the gradient of cat([mu, l_packed])
+            if world > 1 and sync_every and (step + 1) % sync_every == 0:
+                gdist.broadcast_(params)
+                for t in optimizer.state_tensors():
+                    gdist.broadcast_(t)
             losses.append(loss)  # stays on the device: no host round trip per step
             if progress is not None:
                 progress(step, loss)
@@ -376,6 +401,7 @@ class ModellingSequence:
         if adapt_mode not in ("dual", "simple"):
             raise ValueError(f"Invalid adaptation mode {adapt_mode}, the options are 'simple' and 'dual'")  # :163-164
         rank, world = (torch.distributed.get_rank(), gdist.world_size()) if gdist.world_size() > 1 else (0, 1)
+        _warn_remainder("HMC", "n_hmc", n_hmc, world)
         n_local = max(1, n_hmc // world)
         pm = self.prob_model
         lens_sim = LensSimulator(self.phys_model, self.sim_config, bs=n_local)
