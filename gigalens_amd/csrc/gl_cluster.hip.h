@@ -35,6 +35,9 @@ namespace glk {
 
 template <class V> struct NfwStateC { V h, w, uu; };
 template <class V> struct SerStateC { V E, u; };  // log2(R/Rs) is recomputed in the VJP (1 transcendental): 40 VGPRs for 20 sources
+// ... except for the first NKEEP spherical sources of a model, whose log2(R/Rs) is kept as well (the five-sum VJP left the
+// registers free): their VJP takes 1/r2 = 2^(-2 L2) / Rs^2 from it instead of recomputing r2, its logarithm and reciprocal
+template <class V> struct SerStateL { V L2; };
 
 // NFW forward on a pixel pair, leaving what the VJP needs (nfw_vjp_v written once, split at the state):
 //   a = K0 h;  cot(K0) = ga h;  gX0 = ga p, p = [X0 > 1e-6] K0 h';  t = gR0 / R0 = ga w, w = [R0 > 1e-7] p / (Rs R0);
@@ -75,7 +78,7 @@ __device__ __forceinline__ void nfw_vjp_c(const float* __restrict__ d, V x, V y,
 // Sersic forward / VJP with the state split (sersic_fwd_v / sersic_vjp_v of gl_vec.hip.h); ELL = false is the spherical
 // profile (sersic.py:23-66 passes e1 = e2 = 0: no rotation, no axis-ratio stretch, no ellipticity gradients)
 template <class V, bool ELL>
-__device__ __forceinline__ V sersic_fwd_c(const float* __restrict__ d, V x, V y, SerStateC<V>& st) {
+__device__ __forceinline__ V sersic_fwd_c(const float* __restrict__ d, V x, V y, SerStateC<V>& st, V* keepL2 = nullptr) {
   V dx = x - d[SER_CX], dy = y - d[SER_CY];
   V r2;
   if constexpr (ELL) {
@@ -85,7 +88,9 @@ __device__ __forceinline__ V sersic_fwd_c(const float* __restrict__ d, V x, V y,
   } else {
     r2 = dx * dx + dy * dy;
   }
+  if (keepL2) r2 = vmax(r2, V(1e-30f));    // (a pixel exactly on the source centre: keeps the kept logarithm finite, see sersic_vjp5_c)
   V L2 = log2_(r2) * 0.5f + d[SER_L2IRS];  // log2(R / R_sersic) without the square root
+  if (keepL2) *keepL2 = L2;
   st.u = exp2_(L2 * d[SER_INVN]);
   st.E = vexp<V>((st.u - 1.f) * -d[SER_BN]);
   return st.E * d[SER_IE];
@@ -134,6 +139,68 @@ __device__ __forceinline__ void sersic_vjp_c(const float* __restrict__ d, V x, V
   gpy += gdy;
 }
 
+// Spherical Sersic VJP reduced to FIVE raw sums per source.  Every accumulator of sersic_vjp_c is a per-sample constant times a
+// sum of  w = gI E  against (u, u L2, u dx / r2, u dy / r2, 1):
+//     CX = c Sx,  CY = c Sy,  L = -c A,  INVN = -Ie bn ln2 D,  BN = -Ie (A - B),  IE = B,       c = Ie bn / n,
+//     A = sum w u,  B = sum w,  D = sum w u L2,  Sx = sum w u dx / r2,  Sy = sum w u dy / r2,
+// so the pixel loop forms w, w u, their three products and one reciprocal -- 13 packed instructions per source and pixel pair
+// instead of 25 and no selects -- five values (not six) go through the transpose-reduction, and the constants are applied
+// once per workgroup when the partial row is written (cluster_sersic5_finish).  r2 is clamped at 1e-30 (a pixel exactly on a
+// source centre: the reference's own gradient is 0 * inf there) instead of selected on.
+enum { S5_SX = 0, S5_SY, S5_A, S5_D, S5_B, S5_N };
+template <class V>
+__device__ __forceinline__ void sersic_vjp5_c(const float* __restrict__ d, V x, V y, const SerStateC<V>& st, V gI, V (&va)[S5_N],
+                                              V& gpx, V& gpy) {
+  V dx = x - d[SER_CX], dy = y - d[SER_CY];
+  V r2 = vmax(dx * dx + dy * dy, V(1e-30f));
+  V L2 = log2_(r2) * 0.5f + d[SER_L2IRS];
+  V w = gI * st.E;
+  V wu = w * st.u;
+  V q = wu * rcp(r2);
+  V qx = q * dx, qy = q * dy;
+  va[S5_SX] = qx;
+  va[S5_SY] = qy;
+  va[S5_A] = wu;
+  va[S5_D] = wu * L2;
+  va[S5_B] = w;
+  const float c = d[SER_IE] * d[SER_BN] * d[SER_INVN];
+  gpx -= qx * c;  // d I / d beta = -c q (dx, dy)
+  gpy -= qy * c;
+}
+// the same with log2(R / Rs) kept from the forward pass: 1 / r2 = (1 / Rs^2) 2^(-2 L2)   (SER_INVRS = 1 / R_sersic)
+template <class V>
+__device__ __forceinline__ void sersic_vjp5_keep_c(const float* __restrict__ d, V x, V y, const SerStateC<V>& st, V L2, V gI,
+                                                   V (&va)[S5_N], V& gpx, V& gpy) {
+  V dx = x - d[SER_CX], dy = y - d[SER_CY];
+  const float irs = d[SER_INVRS];
+  V ir2 = exp2_(L2 * -2.f) * (irs * irs);  // finite: the forward pass of a kept source clamps r2 at 1e-30
+  V w = gI * st.E;
+  V wu = w * st.u;
+  V q = wu * ir2;
+  V qx = q * dx, qy = q * dy;
+  va[S5_SX] = qx;
+  va[S5_SY] = qy;
+  va[S5_A] = wu;
+  va[S5_D] = wu * L2;
+  va[S5_B] = w;
+  const float c = d[SER_IE] * d[SER_BN] * d[SER_INVN];
+  gpx -= qx * c;
+  gpy -= qy * c;
+}
+// raw sums of one source (already summed over the workgroup) -> the accumulator slots finalize expects
+__device__ __forceinline__ float cluster_sersic5_finish(const float* __restrict__ d, const float* raw, int k) {
+  const float Ie = d[SER_IE], bn = d[SER_BN], c = Ie * bn * d[SER_INVN];
+  switch (k) {
+    case SERA_CX: return c * raw[S5_SX];
+    case SERA_CY: return c * raw[S5_SY];
+    case SERA_L: return -c * raw[S5_A];
+    case SERA_INVN: return -(Ie * bn * (float)kLn2) * raw[S5_D];
+    case SERA_BN: return -Ie * (raw[S5_A] - raw[S5_B]);
+    case SERA_IE: return raw[S5_B];
+    default: return 0.f;
+  }
+}
+
 // accumulator slot (inside the sample's accumulator row) of lane q of running sum g -- the inverse of the packing in the loop
 template <int NH, bool ELL> __device__ __forceinline__ int cluster_slot(int g, int q, int n_h, int n_s) {
   if (g < NH) return g < n_h ? NSTAT + NFW_NACC * g + q : -1;
@@ -143,9 +210,9 @@ template <int NH, bool ELL> __device__ __forceinline__ int cluster_slot(int g, i
     const int s = g >> 1;
     return s < n_s ? aS + SER_NACC * s + 4 * (g & 1) + q : -1;
   }
-  const int flat = 4 * (g % 3) + q;  // 0..11 inside a pair of spherical sources: 6 values each
-  const int s = 2 * (g / 3) + flat / 6, k = flat % 6;
-  const int map[6] = {SERA_CX, SERA_CY, SERA_L, SERA_INVN, SERA_BN, SERA_IE};
+  const int flat = 4 * (g % 5) + q;  // 0..19 inside a group of four spherical sources: five raw sums each (sersic_vjp5_c)
+  const int s = 4 * (g / 5) + flat / 5, k = flat % 5;
+  const int map[5] = {SERA_CX, SERA_CY, SERA_L, SERA_INVN, SERA_IE};  // where the raw sums (Sx, Sy, A, D, B) are parked in the column
   return s < n_s ? aS + SER_NACC * s + map[k] : -1;
 }
 
@@ -171,7 +238,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_cluster_kernel(MainArgs a, int n
   const bool odd = lane & 1, hi = lane & 2;
   float* col = s_acc + (wave * 16 + (lane >> 2)) * a.Apad;
   // running sums: lane q of every quad owns value q of four accumulators per register (see quad_transpose_sum)
-  constexpr int NR = NH + (ELL ? 2 * NS : 3 * ((NS + 1) / 2));
+  constexpr int NR = NH + (ELL ? 2 * NS : 5 * ((NS + 3) / 4));
   float racc[NR];
 #pragma unroll
   for (int g = 0; g < NR; ++g) racc[g] = 0.f;
@@ -197,6 +264,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_cluster_kernel(MainArgs a, int n
     V bx = x, by = y, m = V(0.f);
     NfwStateC<V> hst[NH];
     SerStateC<V> sst[NS];
+    constexpr int NKEEP = ELL ? 0 : (NS > 8 ? 18 : NS);  // sources whose log2(R/Rs) stays in registers (budget: 256 VGPRs at 8 + 20)
+    V sL2[NKEEP > 0 ? NKEEP : 1];
     // ---- ray-shoot: beta = (x, y) - sum_h alpha_h   (tf/simulator.py:72-78) ----
 #pragma unroll
     for (int h = 0; h < NH; ++h)
@@ -208,7 +277,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_cluster_kernel(MainArgs a, int n
 #pragma unroll
     for (int s = 0; s < NS; ++s)
       if (s < n_s) {
-        m += sersic_fwd_c<V, ELL>(dS + SERP * s, bx, by, sst[s]);
+        m += sersic_fwd_c<V, ELL>(dS + SERP * s, bx, by, sst[s], s < NKEEP ? &sL2[s < NKEEP ? s : 0] : nullptr);
         GL_SCHED_FENCE();
       }
     auto nanp = m != m;
@@ -255,29 +324,25 @@ __global__ void __launch_bounds__(WG, WAVES) gl_cluster_kernel(MainArgs a, int n
         }
     } else {
 #pragma unroll
-      for (int p = 0; p < (NS + 1) / 2; ++p)
-        if (2 * p < n_s) {  // two spherical sources: 2 x (CX, CY, L, INVN, BN, IE) = three registers
-          float v[12];
+      for (int p = 0; p < (NS + 3) / 4; ++p)
+        if (4 * p < n_s) {  // four spherical sources: 4 x (Sx, Sy, A, D, B) = five registers
+          float v[20];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int s = 2 * p + j;
+          for (int j = 0; j < 4; ++j) {
+            const int s = 4 * p + j;
             if (s < NS && s < n_s) {
-              V va[SER_NACC];
-              sersic_vjp_c<V, false>(dS + SERP * s, bx, by, sst[s < NS ? s : 0], gm, va, gbx, gby);
-              v[6 * j + 0] = va[SERA_CX].x + va[SERA_CX].y;
-              v[6 * j + 1] = va[SERA_CY].x + va[SERA_CY].y;
-              v[6 * j + 2] = va[SERA_L].x + va[SERA_L].y;
-              v[6 * j + 3] = (va[SERA_INVN].x + va[SERA_INVN].y) * (float)kLn2;
-              v[6 * j + 4] = va[SERA_BN].x + va[SERA_BN].y;
-              v[6 * j + 5] = va[SERA_IE].x + va[SERA_IE].y;
+              V va[S5_N];
+              if (s < NKEEP) sersic_vjp5_keep_c<V>(dS + SERP * s, bx, by, sst[s < NS ? s : 0], sL2[s < NKEEP ? s : 0], gm, va, gbx, gby);
+              else sersic_vjp5_c<V>(dS + SERP * s, bx, by, sst[s < NS ? s : 0], gm, va, gbx, gby);
+#pragma unroll
+              for (int k = 0; k < S5_N; ++k) v[5 * j + k] = va[k].x + va[k].y;
             } else {
 #pragma unroll
-              for (int k = 0; k < 6; ++k) v[6 * j + k] = 0.f;
+              for (int k = 0; k < S5_N; ++k) v[5 * j + k] = 0.f;
             }
           }
-          racc[NH + 3 * p] += quad_transpose_sum(v[0], v[1], v[2], v[3], odd, hi);
-          racc[NH + 3 * p + 1] += quad_transpose_sum(v[4], v[5], v[6], v[7], odd, hi);
-          racc[NH + 3 * p + 2] += quad_transpose_sum(v[8], v[9], v[10], v[11], odd, hi);
+#pragma unroll
+          for (int r = 0; r < 5; ++r) racc[NH + 5 * p + r] += quad_transpose_sum(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3], odd, hi);
           GL_SCHED_FENCE();
         }
     }
@@ -312,10 +377,29 @@ __global__ void __launch_bounds__(WG, WAVES) gl_cluster_kernel(MainArgs a, int n
   }
   __syncthreads();
   float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
-  for (int k = tid; k < a.A; k += WG) {
-    float v = 0.f;
-    for (int j = 0; j < 64; ++j) v += s_acc[j * a.Apad + k];
-    out[k] = v;
+  if constexpr (ELL) {
+    for (int k = tid; k < a.A; k += WG) {
+      float v = 0.f;
+      for (int j = 0; j < 64; ++j) v += s_acc[j * a.Apad + k];
+      out[k] = v;
+    }
+  } else {
+    // spherical sources: the columns hold RAW sums (sersic_vjp5_c); sum the 64 columns in fixed order into column 0, then turn
+    // each source's five sums into its accumulator slots with the sample's constants
+    for (int k = tid; k < a.A; k += WG) {
+      float v = 0.f;
+      for (int j = 0; j < 64; ++j) v += s_acc[j * a.Apad + k];
+      s_acc[k] = v;  // column 0, slot k: only this thread reads column 0's slot k above
+    }
+    __syncthreads();
+    const int aS = NSTAT + NFW_NACC * n_h;
+    for (int k = tid; k < a.A; k += WG) {
+      if (k < aS) { out[k] = s_acc[k]; continue; }
+      const int sidx = (k - aS) / SER_NACC, kk = (k - aS) % SER_NACC;
+      const float* r = s_acc + aS + SER_NACC * sidx;
+      const float raw[S5_N] = {r[SERA_CX], r[SERA_CY], r[SERA_L], r[SERA_INVN], r[SERA_IE]};
+      out[k] = cluster_sersic5_finish(dS + SERP * sidx, raw, kk);
+    }
   }
 }
 
