@@ -511,6 +511,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
         return fail(GL_EUNSUPPORTED, "shapelets n_max=%d outside [0,%d]", iparam, GL_SHAPELETS_NMAX_CAP);
       }
       m->has_shapelets = true;
+      if (iparam > SH_CAP) m->shp_big = true;
       if (c.flags & GL_FLAG_SHAPELETS_INTERPOLATE) { m->has_table = true; sh_nmax = std::max(sh_nmax, iparam); }
     }
     CompDesc cd{};
@@ -555,6 +556,14 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     m->tile_grad = (tg == 4 || tg == 1 || tg == 2) ? tg : 0;
   }
   m->static_id = env_int("GIGALENS_HIP_STATIC", 1) ? match_static(m) : 0;
+  if (m->shp_big) {  // orders above SH_CAP: the runtime-order interpreter variant only (compiled for the basic profile families)
+    m->static_id = 0;
+    if (m->fam) {
+      delete m;
+      return fail(GL_EUNSUPPORTED, "shapelets with n_max > %d are served together with EPL / SIE / NFW / Shear / SIS lenses and Sersic "
+                                   "lights only (this model also holds dPIE-family, catalogue, series or extended profiles)", SH_CAP);
+    }
+  }
   m->static_variant = env_int("GIGALENS_HIP_STATIC_VARIANT", 0);
   m->pair = env_int("GIGALENS_HIP_PAIR", 1);
   if (m->pair && m->static_id) {
@@ -657,12 +666,15 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   }
   if (m->has_table) {
     std::vector<float> tab;
-    (void)sh_nmax;  // always the full n_max = 10 table: stride 12, two rows of a node pair = six aligned float4
-    glh::build_shapelet_table(GL_SHAPELETS_NMAX_CAP, tab, &m->shp_stride);
+    (void)sh_nmax;  // the full n_max = 10 table (stride 12, two rows of a node pair = six aligned float4), or -- for a model with
+                    // orders above 10, whose shapelet components all run the runtime-order path -- the n_max = 20 one (stride 24)
+    glh::build_shapelet_table(m->shp_big ? SH_CAPB : SH_CAP, tab, &m->shp_stride);
     ok = ok && up((void**)&m->d_shp_tab, tab.data(), tab.size() * sizeof(float));
     std::vector<float> tab2;  // gl_shp.hip.h: values | differences per node, order pairs in loaded register pairs
-    glh::build_shapelet_pair_table(tab, m->shp_stride, GL_SHAPELETS_NMAX_CAP, SH_SQ, tab2);
-    ok = ok && up((void**)&m->d_shp_tab2, tab2.data(), tab2.size() * sizeof(float));
+    if (!m->shp_big) {
+      glh::build_shapelet_pair_table(tab, m->shp_stride, SH_CAP, SH_SQ, tab2);
+      ok = ok && up((void**)&m->d_shp_tab2, tab2.data(), tab2.size() * sizeof(float));
+    }
   }
   m->has_post = grid->psf != nullptr || grid->supersample != 1;
   if (m->has_post) {

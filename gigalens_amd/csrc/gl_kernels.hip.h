@@ -633,9 +633,12 @@ template <int T> __device__ __forceinline__ void epl_vjp_T(const float* d, const
 // compiled only into the variants that need it, so the common compositions keep their occupancy.
 //   FAM 0: EPL, SIE, NFW, Shear, SIS | Sersic[Ellipse]     FAM 1: + dPIS / dPIE / dPIEP, catalogues, series lenses
 //   FAM 2: + NFW_ELLIPSE, TNFW, CoreSersic (gl_extra.h; the fp64 core of TNFW alone costs ~80 VGPRs)
-template <int MODE, int T, bool SHP, int FAM>
+//   BIG: some shapelet component has n_max above SH_CAP (up to SH_CAPB = 20): every shapelet component of the model runs the
+//   runtime-order code of gl_profiles.h on the model's wide table, amplitude gradients leave shell by shell into the LDS columns
+template <int MODE, int T, bool SHP, int FAM, bool BIG = false>
 __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainArgs a) {
   constexpr bool DP = FAM >= 1, XF = FAM >= 2;
+  static_assert(!BIG || SHP, "BIG is a shapelet variant");
   extern __shared__ float smem[];
   float* s_d = smem;
   float* s_acc = smem + ((a.D + 3) & ~3);
@@ -781,7 +784,7 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
               if (!valid[t]) continue;
               const int pi = pidx[t];
               const long long st = a.img_stride;
-              shapelets_basis<float, SH_CAP>(d, a.shp_tab, a.shp_stride, cd.flags & 1u, src ? bx[t] : x[t],
+              shapelets_basis<float, BIG ? SH_CAPB : SH_CAP>(d, a.shp_tab, a.shp_stride, cd.flags & 1u, src ? bx[t] : x[t],
                                              src ? by[t] : y[t], [&](int k, float v) { row[(size_t)k * st + pi] = isnan_(v) ? 0.f : v; });
             }
           }
@@ -810,8 +813,12 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
           const float* __restrict__ gamp = a.derived + (size_t)b * a.D + cd.d_off + SHP_AMP;
 #pragma unroll 1
           for (int t = 0; t < T; ++t) {
-            ShpState<SH_CAP> hs;
-            m[t] += shp_fwd_state<SH_CAP>(d, gamp, a.shp_tab, interp, src ? bx[t] : x[t], src ? by[t] : y[t], hs);
+            if constexpr (BIG) {
+              m[t] += shapelets_fwd<float, SH_CAPB>(d, a.shp_tab, a.shp_stride, interp, src ? bx[t] : x[t], src ? by[t] : y[t]);
+            } else {
+              ShpState<SH_CAP> hs;
+              m[t] += shp_fwd_state<SH_CAP>(d, gamp, a.shp_tab, interp, src ? bx[t] : x[t], src ? by[t] : y[t], hs);
+            }
           }
         }
       } else if (cd.kind == K_CORE_SERSIC) {
@@ -875,7 +882,25 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
         const float* d = s_d + cd.d_off;
         const bool src = ci >= n_ll;
         if (cd.kind == K_SHAPELETS) {
-          if (SHP) {
+          if constexpr (SHP && BIG) {
+            // runtime-order path: one pixel at a time, every shell n = n1 + n2 of the amplitude gradient reduced over the lane
+            // group and added to the LDS columns as soon as it is formed (at most SH_CAPB + 1 values live)
+            const bool interp = cd.flags & 1u;
+            float acc3[SHPA_AMP] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int t = 0; t < T; ++t) {
+              float dgx = 0.f, dgy = 0.f;
+              (void)shapelets_vjp_shells<float, SH_CAPB>(d, a.shp_tab, a.shp_stride, interp, src ? bx[t] : x[t], src ? by[t] : y[t],
+                                                         gm[t], acc3, dgx, dgy, [&](int first, int count, float* vals) {
+                float tmp[SH_CAPB + 1];
+#pragma unroll
+                for (int k = 0; k <= SH_CAPB; ++k) tmp[k] = vals[k];
+                wave_acc<SH_CAPB + 1>(tmp, ac, cd.a_off + SHPA_AMP + first, count);
+              });
+              if (src) { gbx[t] += dgx; gby[t] += dgy; }
+            }
+            wave_acc<SHPA_AMP>(acc3, ac, cd.a_off, SHPA_AMP);
+          } else if (SHP) {
             const bool interp = cd.flags & 1u;
             float acc[SHPA_AMP + SH_MAXL];
 #pragma unroll
@@ -1417,9 +1442,15 @@ __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float*
     case K_SERSIC: { float d[SER_ND + 2]; sersic_prep<float>(p, false, d); o0 = sersic_fwd(d, px, py); } break;
     case K_SERSIC_ELLIPSE: { float d[SER_ND + 2]; sersic_prep<float>(p, true, d); o0 = sersic_fwd(d, px, py); } break;
     case K_SHAPELETS: {
-      float d[SHP_SQ + SH_SQ * SH_SQ];
-      shapelets_prep<float>(p, cd.iparam, d);
-      o0 = shapelets_fwd<float, SH_CAP>(d, shp_tab, shp_stride, cd.flags & 1u, px, py);
+      if (cd.iparam > SH_CAP) {  // runtime-order path; amplitudes straight from the parameter row (same triangle order)
+        float d[SHP_AMP];
+        d[SHP_CX] = p[1]; d[SHP_CY] = p[2]; d[SHP_IB] = 1.f / p[0]; d[SHP_NMAX] = (float)cd.iparam;
+        o0 = shapelets_fwd_amp<float, SH_CAPB>(d, p + 3, shp_tab, shp_stride, cd.flags & 1u, px, py);
+      } else {
+        float d[SHP_SQ + SH_SQ * SH_SQ];
+        shapelets_prep<float>(p, cd.iparam, d);
+        o0 = shapelets_fwd<float, SH_CAP>(d, shp_tab, shp_stride, cd.flags & 1u, px, py);
+      }
     } break;
   }
   out0[i] = o0;
@@ -1446,8 +1477,12 @@ __global__ void __launch_bounds__(256) gl_basis_point_kernel(CompDesc cd, const 
     d[SHP_CY] = p[2];
     d[SHP_IB] = 1.f / p[0];
     d[SHP_NMAX] = (float)cd.iparam;
-    shapelets_basis<float, SH_CAP>(d, shp_tab, shp_stride, cd.flags & 1u, px, py,
-                                   [&](int k, float v) { out[(size_t)k * total + i] = v; });
+    if (cd.iparam > SH_CAP)
+      shapelets_basis<float, SH_CAPB>(d, shp_tab, shp_stride, cd.flags & 1u, px, py,
+                                      [&](int k, float v) { out[(size_t)k * total + i] = v; });
+    else
+      shapelets_basis<float, SH_CAP>(d, shp_tab, shp_stride, cd.flags & 1u, px, py,
+                                     [&](int k, float v) { out[(size_t)k * total + i] = v; });
     return;
   }
   float q[10];

@@ -122,8 +122,13 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
 #define GL_MAIN_FAM(TT, S_) \
   do { if (m->fam == 2) GL_MAIN(TT, S_, 2); else if (m->fam == 1) GL_MAIN(TT, S_, 1); else GL_MAIN(TT, S_, 0); } while (0)
   bool done = false;
+  if (m->shp_big) {  // shapelets above n_max = 10: the runtime-order interpreter variant (basic profile families, T = 2)
+    m->last_main_fn = (const void*)&gl_main_kernel<MODE, 2, true, 0, true>;
+    hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true, 0, true>), grid, block, shmem, stream, a);
+    done = true;
+  }
   if constexpr (MODE == IMG_BWD || MODE == LL_GRAD) {
-    if (m->cluster && a.parts == 7u) {  // N x same-kind cluster model: forward state of every component kept in registers
+    if (!done && m->cluster && a.parts == 7u) {  // N x same-kind cluster model: forward state of every component kept in registers
       const size_t sh = (size_t)64 * m->Apad * sizeof(float) + sizeof(float) * 2 * NFW_TAB_NODES;  // gradient columns + the h(X) table
 #define GL_CLUSTER(NH_, NS_, E_, W_)                                                                     \
   do {                                                                                                 \

@@ -51,6 +51,7 @@ struct gl_model {
   int n_lens = 0, n_ll = 0, n_src = 0;
   int P = 0, D = 0, A = 0, Apad = 0, ncols = 64;
   bool has_shapelets = false, has_table = false;
+  bool shp_big = false;  // some shapelet component has n_max > SH_CAP: wide table, runtime-order interpreter variant for all of them
   int height = 0, width = 0, supersample = 1, N = 0;
   float conversion_factor = 1.f;
   // device-resident, immutable

@@ -31,8 +31,10 @@ enum Kind : int {
   K_CORE_SERSIC = 19                    // gl_extra.h
 };
 
-constexpr int SH_CAP = 10;                              // GL_SHAPELETS_NMAX_CAP
+constexpr int SH_CAP = 10;                              // largest n_max the register-resident / matrix-pipe shapelet kernels serve
 constexpr int SH_MAXL = (SH_CAP + 1) * (SH_CAP + 2) / 2;  // 66
+constexpr int SH_CAPB = 20;                             // GL_SHAPELETS_NMAX_CAP: orders above SH_CAP run the runtime-order path
+constexpr int SH_MAXLB = (SH_CAPB + 1) * (SH_CAPB + 2) / 2;  // 231
 constexpr int SH_NODES = 6000;                          // shapelets.py:39-40
 
 // ---------------------------------------------------------------------------------------------
@@ -104,7 +106,8 @@ GL_HD int kind_num_derived(int kind, int iparam) {
     case K_CORE_SERSIC: return 16;
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_ND + 2;
-    case K_SHAPELETS: return SHP_SQ + SH_SQ * SH_SQ;  // amplitude triangle zero-padded to n_max = 10, then the square matrix
+    case K_SHAPELETS:  // n_max <= 10: amplitude triangle zero-padded to n_max = 10, then the square matrix; above: the triangle only
+      return iparam <= SH_CAP ? SHP_SQ + SH_SQ * SH_SQ : SHP_AMP + ((SH_MAXLB + 3) & ~3);
   }
   return -1;
 }
@@ -759,6 +762,10 @@ template <class R> GL_HD void shapelets_prep(const R* p, int n_max, R* d) {
   d[SHP_NMAX] = (R)n_max;
   int L = sh_layers(n_max);
   for (int i = 0; i < L; ++i) d[SHP_AMP + i] = p[3 + i];
+  if (n_max > SH_CAP) {  // runtime-order path: the triangle alone (zero-padded to its block)
+    for (int i = L; i < ((SH_MAXLB + 3) & ~3); ++i) d[SHP_AMP + i] = (R)0;
+    return;
+  }
   for (int i = L; i < ((SH_MAXL + 3) & ~3); ++i) d[SHP_AMP + i] = (R)0;  // the separable kernels run the full triangle
   for (int n1 = 0; n1 < SH_SQ; ++n1)
     for (int n2 = 0; n2 < SH_SQ; ++n2) {
@@ -880,6 +887,28 @@ GL_HD R shapelets_fwd(const R* d, const float* tab, int stride, bool interp, R x
   return fac * S;
 }
 
+// the same with the amplitude triangle somewhere else than behind the four constants (plugin-level evaluation of orders
+// above SH_CAP reads it straight from the parameter row)
+template <class R, int CAP>
+GL_HD R shapelets_fwd_amp(const R* d, const R* amp, const float* tab, int stride, bool interp, R x, R y) {
+  const int n_max = (int)d[SHP_NMAX];
+  R ib = d[SHP_IB];
+  R u = (x - d[SHP_CX]) * ib, v = (y - d[SHP_CY]) * ib;
+  R Xv[CAP + 1], dXv[CAP + 1], Yv[CAP + 1], dYv[CAP + 1];
+  R fac = (R)1;
+  if (interp) {
+    table_basis<R, CAP>(tab, stride, u, n_max, Xv, dXv);
+    table_basis<R, CAP>(tab, stride, v, n_max, Yv, dYv);
+  } else {
+    hermite_basis<R, CAP>(u, n_max, Xv, dXv);
+    hermite_basis<R, CAP>(v, n_max, Yv, dYv);
+    fac = exp_(-(u * u + v * v) * (R)0.5);
+  }
+  R S, Su, Sv;
+  shapelets_sum<R, CAP, false>(amp, n_max, Xv, dXv, Yv, dYv, S, Su, Sv);
+  return fac * S;
+}
+
 // acc layout: [cx, cy, ib, amp_0..]; amplitudes accumulate straight into acc (registers)
 template <class R, int CAP>
 GL_HD R shapelets_vjp(const R* d, const float* tab, int stride, bool interp, R x, R y, R gI, R* acc,
@@ -919,6 +948,53 @@ GL_HD R shapelets_vjp(const R* d, const float* tab, int stride, bool interp, R x
   acc[SHPA_CX] -= gdx;
   acc[SHPA_CY] -= gdy;
   acc[SHPA_IB] += gu * dx + gv * dy;
+  gpx += gdx;
+  gpy += gdy;
+  return I;
+}
+// The same VJP for orders that do not fit a register-resident accumulator block (n_max up to SH_CAPB: 231 amplitudes): the
+// amplitude gradient leaves shell by shell -- `flush(first amplitude index, count, values)` after every n = n1 + n2 -- so a
+// caller keeps at most CAP + 1 values live; `acc3` takes the centre / 1/beta terms.
+template <class R, int CAP, class F>
+GL_HD R shapelets_vjp_shells(const R* d, const float* tab, int stride, bool interp, R x, R y, R gI, R* acc3, R& gpx, R& gpy,
+                             F&& flush) {
+  const int n_max = (int)d[SHP_NMAX];
+  R ib = d[SHP_IB];
+  R dx = x - d[SHP_CX], dy = y - d[SHP_CY];
+  R u = dx * ib, v = dy * ib;
+  R Xv[CAP + 1], dXv[CAP + 1], Yv[CAP + 1], dYv[CAP + 1];
+  R fac = (R)1;
+  if (interp) {
+    table_basis<R, CAP>(tab, stride, u, n_max, Xv, dXv);
+    table_basis<R, CAP>(tab, stride, v, n_max, Yv, dYv);
+  } else {
+    hermite_basis<R, CAP>(u, n_max, Xv, dXv);
+    hermite_basis<R, CAP>(v, n_max, Yv, dYv);
+    fac = exp_(-(u * u + v * v) * (R)0.5);
+  }
+  R S, Su, Sv;
+  shapelets_sum<R, CAP, true>(d + SHP_AMP, n_max, Xv, dXv, Yv, dYv, S, Su, Sv);
+  R I = fac * S;
+  R gS = gI * fac;
+#pragma unroll
+  for (int n = 0; n <= CAP; ++n) {
+    if (n <= n_max) {
+      R vals[CAP + 1];
+#pragma unroll
+      for (int n2 = 0; n2 <= CAP; ++n2) vals[n2] = n2 <= n ? gS * Xv[n2 <= n ? n - n2 : 0] * Yv[n2] : (R)0;
+      flush(n * (n + 1) / 2, n + 1, vals);
+    }
+  }
+  R gu = gS * Su, gv = gS * Sv;
+  if (!interp) {
+    R gIf = gI * I;
+    gu -= gIf * u;
+    gv -= gIf * v;
+  }
+  R gdx = gu * ib, gdy = gv * ib;
+  acc3[SHPA_CX] -= gdx;
+  acc3[SHPA_CY] -= gdy;
+  acc3[SHPA_IB] += gu * dx + gv * dy;
   gpx += gdx;
   gpy += gdy;
   return I;

@@ -66,7 +66,7 @@ typedef enum gl_kind {
   GL_CORE_SERSIC = 19     /* sersic.py:85-96 [R_sersic,n_sersic,Rb,alpha,gamma,e1,e2,center_x,center_y,Ie] */
 } gl_kind;
 
-#define GL_SHAPELETS_NMAX_CAP 10 /* largest n_max the register-resident shapelet path serves */
+#define GL_SHAPELETS_NMAX_CAP 20 /* largest n_max served (231 amplitudes); above 10 the runtime-order path of the interpreter kernel runs */
 #define GL_SHAPELETS_TABLE_NODES 6000
 #define GL_FLAG_SHAPELETS_INTERPOLATE 1u /* shapelets.py:20 interpolate=True (table mode) */
 

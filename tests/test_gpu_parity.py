@@ -115,17 +115,18 @@ def test_sis_shear_nfw_recipes(gl):
     assert np.allclose(fy.cpu().numpy(), oy.numpy(), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("n_max", [5, 14])  # 14: above the register-resident orders, the runtime-order point kernels
 @pytest.mark.parametrize("interpolate", [True, False])
-def test_shapelets_recipe(gl, interpolate):
+def test_shapelets_recipe(gl, interpolate, n_max):
     from gigalens_amd.profiles.light.shapelets import Shapelets
     from oracle import published as pub
-    shp = Shapelets(n_max=5, use_lstsq=False, interpolate=interpolate)
+    shp = Shapelets(n_max=n_max, use_lstsq=False, interpolate=interpolate)
     r = np.random.default_rng(3)
     amplitudes = r.normal(size=(shp.n_layers, 1)).astype(np.float32)
     amp = {n: a for n, a in zip(shp._amp_names, amplitudes)}
     x, y = r.normal(size=(5, 5, 1)).astype(np.float32), r.normal(size=(5, 5, 1)).astype(np.float32)
     a = shp.light(x=x, y=y, center_x=0, center_y=0, beta=1, **amp).cpu().numpy()
-    b = pub.shapelet_set(x.ravel(), y.ravel(), amplitudes.ravel().astype(np.float64), 5, 1.0)
+    b = pub.shapelet_set(x.ravel(), y.ravel(), amplitudes.ravel().astype(np.float64), n_max, 1.0)
     assert a.shape == (5, 5, 1)
     assert np.allclose(a.ravel(), b, rtol=1e-5, atol=1e-4)  # tests/test_profiles.py:47
 
@@ -145,6 +146,9 @@ CASES = [
     ("C4", dict(num_pix=32, batch=2)),
     ("C3D", dict(num_pix=30, batch=3, interpolate=True, n_max=8)),   # shapelets-demo.ipynb model
     ("C3D", dict(num_pix=30, batch=3, interpolate=False, n_max=5)),
+    ("C3", dict(num_pix=24, batch=3, interpolate=True, n_max=12)),    # above n_max = 10: the runtime-order interpreter variant
+    ("C3", dict(num_pix=20, batch=2, interpolate=False, n_max=16)),
+    ("C3D", dict(num_pix=22, batch=2, interpolate=True, n_max=20)),   # 231 amplitudes beside a lens light
 ]
 
 

@@ -20,8 +20,8 @@ DISPATCHED = {
     "C1 SIE | Sersic": [f"gl_pair_kernel<{m}, {V2}, {w}, {SIE}, {NONE}, {SERSIC} >" for m, w in ((0, 4), (1, 3), (2, 4), (3, 3))],
     "C2 EPL+Shear | Sersic": [f"gl_pair_kernel<{m}, {V2}, {w}, {EPLSHEAR}, {NONE}, {SERSIC} >" for m, w in ((0, 4), (1, 3), (2, 4), (3, 3))],
     "C3 EPL+Shear | Shapelets": [f"gl_shp_kernel<{m}, 2, {EPLSHEAR}, {NONE}, 6, true>" for m in (0, 1, 2, 3)],  # table mode (the default)
-    "C4 / C5 8 NFW | 20 Sersic": ["gl_main_kernel<0, 4, false, 0>", "gl_cluster_kernel<1, 8, 20, false, 2>",
-                                  "gl_main_kernel<2, 4, false, 0>", "gl_cluster_kernel<3, 8, 20, false, 2>"],
+    "C4 / C5 8 NFW | 20 Sersic": ["gl_main_kernel<0, 4, false, 0, false>", "gl_cluster_kernel<1, 8, 20, false, 2>",
+                                  "gl_main_kernel<2, 4, false, 0, false>", "gl_cluster_kernel<3, 8, 20, false, 2>"],
 }
 
 
@@ -50,8 +50,8 @@ def test_dispatched_instantiations_do_not_spill(metadata, config):
 # Instantiations that are allowed to spill, and why none of them is on a default dispatch path of a BASELINE config
 # (everything else in the library must compile without VGPR spills):
 ALLOWED_SPILLS = [
-    (r"gl_main_kernel<\d, \d, (true|false), 2>", "FAM 2: the profile families beyond SURVEY section 8 (NFW_ELLIPSE, TNFW with its float64 core, CoreSersic)"),
-    (r"gl_main_kernel<[13], 2, true, [01]>", "shapelets through the interpreter, gradient modes (models outside the specialised compositions)"),
+    (r"gl_main_kernel<\d, \d, (true|false), 2, false>", "FAM 2: the profile families beyond SURVEY section 8 (NFW_ELLIPSE, TNFW with its float64 core, CoreSersic)"),
+    (r"gl_main_kernel<[13], 2, true, [01], false>", "shapelets through the interpreter, gradient modes (models outside the specialised compositions)"),
     (r"gl_static_kernel<[13], [24], ", "pre-pair tile variants of the specialised kernels in gradient modes: reached only with GIGALENS_HIP_PAIR=0 / GIGALENS_HIP_TILE*"),
     (r"gl_series_hessian_precompute_kernel<", "one-off float64 jet precompute of the Hessian series (not on the per-step path)"),
     (r"gl_shp_kernel<[13], 2, glk::KindList<1, 4>, glk::KindList<17>, \d, true>",
