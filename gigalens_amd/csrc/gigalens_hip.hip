@@ -416,6 +416,7 @@ int run_likelihood(const gl_model* m, int B, const Workspace& w, int chunk, int 
 namespace {
 struct LstsqWs {
   float *stack_ss, *stack, *partial, *coeffs;
+  float* mats;  // [B][2][D][D | 1]: A and V of the eigen solve for systems above LS_LDS_MAXN unknowns (else null)
   int chunk, n_chunks, Dp;
   size_t bytes;
 };
@@ -436,6 +437,7 @@ LstsqWs carve_lstsq(const gl_model* m, int B, void* base, size_t off) {
   w.stack = take((size_t)B * D * HW);
   w.partial = take((size_t)B * w.n_chunks * w.Dp * w.Dp);
   w.coeffs = take((size_t)B * D);
+  w.mats = D > LS_LDS_MAXN ? take((size_t)B * 2 * D * (D | 1)) : nullptr;
   w.bytes = off;
   return w;
 }
@@ -997,8 +999,8 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   if ((int)m->cats.size() != m->n_scaled) return fail(GL_EINVAL, "GL_SCALED component without a catalogue");
   if (m->n_series_set != m->n_series) return fail(GL_EINVAL, "GL_SERIES component without a coefficient field");
   const bool solve = coeffs_or_null || image_or_null;
-  if (solve && D + 1 > LS_MAXD)  // the basis stack alone (return_stacked) is served at any depth
-    return fail(GL_EUNSUPPORTED, "%d linear coefficients exceed the %d the in-LDS solve serves", D, LS_MAXD - 1);
+  if (solve && D > LS_MAXN)  // the basis stack alone (return_stacked) is served at any depth
+    return fail(GL_EUNSUPPORTED, "%d linear coefficients exceed the %d the solve serves", D, LS_MAXN);
   if (solve && (!obs || !err)) return fail(GL_EINVAL, "obs / err_map are required to solve for the coefficients");
   if (!solve && !stacked_or_null) return fail(GL_EINVAL, "nothing to compute");
   if (!(parts & (GL_PART_LENS_LIGHT | GL_PART_SOURCE_LIGHT)) || parts > 7u) return fail(GL_EINVAL, "bad parts");
@@ -1039,7 +1041,13 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   na.partial = lw.partial;
   if (D + 1 <= LS_SMALL)
     hipLaunchKernelGGL((gl_normal_small_kernel<LS_SMALL>), dim3(lw.n_chunks, B), dim3(256), 0, stream, na);
-  else {
+  else if (D + 1 > LS_MAXD) {  // more than five tile rows: super-block pairs (gl_normal_pair_kernel)
+    const int vec_ok = (HW % 4 == 0) && ((uintptr_t)obs % 16 == 0) && ((uintptr_t)err % 16 == 0) && ((uintptr_t)lw.stack % 16 == 0);
+    const int n_sb = (D + 1 + 16 * LS_SB - 1) / (16 * LS_SB);
+    const dim3 grid(lw.n_chunks, B, n_sb * (n_sb + 1) / 2), block(256);
+    if (vec_ok) hipLaunchKernelGGL((gl_normal_pair_kernel<true>), grid, block, 0, stream, na);
+    else hipLaunchKernelGGL((gl_normal_pair_kernel<false>), grid, block, 0, stream, na);
+  } else {
     // 16-byte loads need every channel row, obs and err on a 16-byte pitch
     const int vec_ok = (HW % 4 == 0) && ((uintptr_t)obs % 16 == 0) && ((uintptr_t)err % 16 == 0) && ((uintptr_t)lw.stack % 16 == 0);
     const dim3 grid(lw.n_chunks, B), block(256);
@@ -1064,9 +1072,22 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
     GL_HIP(hipGetLastError());
     n_sum = 1;
   }
-  const size_t sm = sizeof(float) * ((size_t)2 * D * (D | 1) + 8 * D + 8);
-  hipLaunchKernelGGL(gl_eigh_solve_kernel, dim3(B), dim3(64), sm, stream, lw.partial, lw.n_chunks, n_sum, D, lw.Dp, 1e-6f,
-                     coeffs);
+  if (D <= LS_LDS_MAXN) {  // A and V in LDS: up to 129 KB of the CU's 160 (above 64 KB the kernel has to be told once)
+    const size_t sm = sizeof(float) * ((size_t)2 * D * (D | 1) + 8 * D + 8);
+    if (sm > 64 * 1024) {
+      static bool raised = false;
+      if (!raised) {
+        GL_HIP(hipFuncSetAttribute((const void*)&gl_eigh_solve_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+      }
+    }
+    hipLaunchKernelGGL((gl_eigh_solve_kernel<2, false>), dim3(B), dim3(64), sm, stream, lw.partial, lw.n_chunks, n_sum, D, lw.Dp,
+                       1e-6f, coeffs, (float*)nullptr);
+  } else {  // the two matrices in the workspace (L2), the vectors in LDS; four registers hold the tridiagonal
+    const size_t sm = sizeof(float) * ((size_t)8 * D + 8);
+    hipLaunchKernelGGL((gl_eigh_solve_kernel<4, true>), dim3(B), dim3(64), sm, stream, lw.partial, lw.n_chunks, n_sum, D, lw.Dp,
+                       1e-6f, coeffs, lw.mats);
+  }
   GL_HIP(hipGetLastError());
   if (image_or_null) {
     hipLaunchKernelGGL(gl_combine_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, stream, lw.stack, coeffs, D, HW,

@@ -20,7 +20,10 @@ namespace glk { __device__ long long g_eigh_stamps[8]; }
 
 namespace glk {
 
-constexpr int LS_MAXD = 80;   // channels incl. the observation column (LDS: A and V of the eigen solve)
+constexpr int LS_MAXD = 80;   // channels incl. the observation column up to which the single-launch SYRK (<= 5 tile rows) runs
+constexpr int LS_LDS_MAXN = 127;  // unknowns whose eigen solve keeps A and V in LDS (2 n (n | 1) floats: 129 KB of the CU's 160)
+constexpr int LS_MAXN = 255;      // unknowns served at all: above LS_LDS_MAXN the two matrices live in the workspace (L2)
+constexpr int LS_SB = 4;          // tile rows (16 channels each) per super-block of the block-pair SYRK
 constexpr int LS_TPP = 32;    // chunk granularity: 2 * LS_TPP = 64 pixels (4 waves x 16-pixel MFMA groups)
 constexpr int LS_SMALL = 8;   // <= this many channels (incl. Y): pixel-parallel kernel with register accumulators
 
@@ -190,6 +193,108 @@ __global__ void __launch_bounds__(256) gl_normal_mfma_kernel(NormalArgs a) {
   }
 }
 
+// ---- more than LS_MAXD channels: the same SYRK by PAIRS of super-blocks (LS_SB tile rows = 64 channels each) -----------------
+// grid.z enumerates the pairs (I, J <= I); a workgroup multiplies super-block I's channels with super-block J's over its pixel
+// chunk -- 16 accumulator tiles (10 on the diagonal) instead of NT (NT + 1) / 2, which no longer fits the register file from
+// NT = 9 on.  The stack is read once per pair a super-block takes part in (2.5 x on average at four super-blocks).
+template <bool VEC>
+__global__ void __launch_bounds__(256) gl_normal_pair_kernel(NormalArgs a) {
+  constexpr int SB = LS_SB;
+  __shared__ float s_red[SB * SB * 256];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, l = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int I = 0;
+  while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.z) ++I;
+  const int J = (int)blockIdx.z - I * (I + 1) / 2;
+  const bool diag = I == J;
+  const int c = l & 15, q = l >> 4;
+  const int p0 = chunk * a.chunk, p1 = min(p0 + a.chunk, a.HW);
+  const float* S = a.stack + (size_t)b * a.D * a.HW;
+  const float* rowA[SB];
+  const float* rowB[SB];
+  float keepA[SB], keepB[SB];
+#pragma unroll
+  for (int t = 0; t < SB; ++t) {
+    const int ca = 16 * (SB * I + t) + c, cb = 16 * (SB * J + t) + c;
+    rowA[t] = ca < a.D ? S + (size_t)ca * a.HW : a.obs;
+    keepA[t] = ca <= a.D ? 1.f : 0.f;
+    rowB[t] = cb < a.D ? S + (size_t)cb * a.HW : a.obs;
+    keepB[t] = cb <= a.D ? 1.f : 0.f;
+  }
+  f32x4 acc[SB][SB];
+#pragma unroll
+  for (int i = 0; i < SB; ++i)
+#pragma unroll
+    for (int j = 0; j < SB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](const float* src, int pb) -> float4 {
+    if (VEC && pb + 4 <= p1) return *reinterpret_cast<const float4*>(src + pb);
+    float4 v;
+    v.x = pb < p1 ? src[pb] : 0.f;
+    v.y = pb + 1 < p1 ? src[pb + 1] : 0.f;
+    v.z = pb + 2 < p1 ? src[pb + 2] : 0.f;
+    v.w = pb + 3 < p1 ? src[pb + 3] : 0.f;
+    return v;
+  };
+  for (int pg = p0 + 16 * wave; pg < p1; pg += 64) {
+    const int pb = pg + 4 * q;
+    const float4 er = fetch(a.err, pb);
+    float4 xa[SB], xb[SB];
+#pragma unroll
+    for (int t = 0; t < SB; ++t) xa[t] = fetch(rowA[t], pb);
+    if (!diag) {
+#pragma unroll
+      for (int t = 0; t < SB; ++t) xb[t] = fetch(rowB[t], pb);
+    }
+    float w[4];
+    w[0] = pb < p1 ? __builtin_amdgcn_rcpf(er.x) : 0.f;
+    w[1] = pb + 1 < p1 ? __builtin_amdgcn_rcpf(er.y) : 0.f;
+    w[2] = pb + 2 < p1 ? __builtin_amdgcn_rcpf(er.z) : 0.f;
+    w[3] = pb + 3 < p1 ? __builtin_amdgcn_rcpf(er.w) : 0.f;
+    float va[SB][4], vb[SB][4];
+#pragma unroll
+    for (int t = 0; t < SB; ++t) {
+      va[t][0] = xa[t].x * (w[0] * keepA[t]); va[t][1] = xa[t].y * (w[1] * keepA[t]);
+      va[t][2] = xa[t].z * (w[2] * keepA[t]); va[t][3] = xa[t].w * (w[3] * keepA[t]);
+      if (diag) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vb[t][r] = va[t][r];
+      } else {
+        vb[t][0] = xb[t].x * (w[0] * keepB[t]); vb[t][1] = xb[t].y * (w[1] * keepB[t]);
+        vb[t][2] = xb[t].z * (w[2] * keepB[t]); vb[t][3] = xb[t].w * (w[3] * keepB[t]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ti = 0; ti < SB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < SB; ++tj)
+          if (!diag || tj <= ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[ti][r], vb[tj][r], acc[ti][tj], 0, 0, 0);
+  }
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int ti = 0; ti < SB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < SB; ++tj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int idx = ((ti * SB + tj) * 4 + r) * 64 + l;
+            s_red[idx] = (wv == 0 ? 0.f : s_red[idx]) + acc[ti][tj][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* out = a.partial + ((size_t)b * a.n_chunks + chunk) * a.Dp * a.Dp;
+  for (int e = tid; e < SB * SB * 256; e += 256) {
+    const int k = e >> 8, r = (e >> 6) & 3, ll = e & 63;
+    const int ti = k / SB, tj = k % SB;
+    if (diag && tj > ti) continue;
+    const int i = 16 * (SB * I + ti) + 4 * (ll >> 4) + r, j = 16 * (SB * J + tj) + (ll & 15);
+    if (i < a.Dp && j < a.Dp) out[i * a.Dp + j] = s_red[e];
+  }
+}
+
 // ---- per sample: A = sum of partials, eigendecomposition, coeffs = pinv(A_DD, rcond) A_DY -------------------------
 // One wavefront per system (gl_eigh.h): Householder tridiagonalisation in LDS; when Sturm counts prove that no
 // eigenvalue falls under tf.linalg.pinv's cutoff (singular values <= rcond * max, here |eigenvalues| of the symmetric
@@ -197,11 +302,12 @@ __global__ void __launch_bounds__(256) gl_normal_mfma_kernel(NormalArgs a) {
 // __syncthreads() is a single-wave barrier.  (The first version of this step was a parallel-ordered cyclic Jacobi
 // solve with 1024 threads per system: 3.8 ms for 1024 systems of 66 unknowns, barrier- and LDS-bound; this one does
 // ~1/10 of the arithmetic and has no barrier in its longest phase.)
-struct WaveCtx {
-  static constexpr int ROWS = 2;  // rows k and k + 64 of V (n <= 79)
+template <int R>  // R registers of 64 lanes hold the tridiagonal: n <= 64 R; a lane owns rows k, k + 64, ... of V
+struct WaveCtxN {
+  static constexpr int ROWS = R;
   // the tridiagonal, lane-distributed: entry i lives in lane i & 63 of register (i >> 6); uniform reads are
   // v_readlane (a few cycles) instead of an LDS round trip on the critical path of every rotation
-  float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;
+  float dr[R], er[R];
   int n_ = 0;
   __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
   __device__ __forceinline__ int lanes() const { return 64; }
@@ -225,55 +331,67 @@ struct WaveCtx {
   __device__ __forceinline__ void load_tridiagonal(const float* d, const float* es, int n) {
     const int k = (int)threadIdx.x;
     n_ = n;
-    d0 = k < n ? d[k] : 0.f;
-    e0 = k < n ? es[k] : 0.f;
-    d1 = k + 64 < n ? d[k + 64] : 0.f;
-    e1 = k + 64 < n ? es[k + 64] : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      dr[r] = k + 64 * r < n ? d[k + 64 * r] : 0.f;
+      er[r] = k + 64 * r < n ? es[k + 64 * r] : 0.f;
+    }
   }
   __device__ __forceinline__ void store_diagonal(float* d, int n) const {
     const int k = (int)threadIdx.x;
-    if (k < n) d[k] = d0;
-    if (k + 64 < n) d[k + 64] = d1;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (k + 64 * r < n) d[k + 64 * r] = dr[r];
   }
-  // branch-free: both halves are read / conditionally written, the index picks
+  // branch-free: every register is read / conditionally written, the index picks
   __device__ __forceinline__ float d(int i) const {
-    const float a = rl(d0, i & 63), b = rl(d1, i & 63);
-    return i < 64 ? a : b;
+    float v = rl(dr[0], i & 63);
+#pragma unroll
+    for (int r = 1; r < R; ++r) { const float t = rl(dr[r], i & 63); v = (i >> 6) == r ? t : v; }
+    return v;
   }
   __device__ __forceinline__ float e(int i) const {
-    const float a = rl(e0, i & 63), b = rl(e1, i & 63);
-    return i < 64 ? a : b;
+    float v = rl(er[0], i & 63);
+#pragma unroll
+    for (int r = 1; r < R; ++r) { const float t = rl(er[r], i & 63); v = (i >> 6) == r ? t : v; }
+    return v;
   }
   __device__ __forceinline__ void set_d(int i, float v) {
-    d0 = wl(d0, i, v);
-    d1 = wl(d1, i - 64, v);
+#pragma unroll
+    for (int r = 0; r < R; ++r) dr[r] = wl(dr[r], i - 64 * r, v);
   }
   __device__ __forceinline__ void set_e(int i, float v) {
-    e0 = wl(e0, i, v);
-    e1 = wl(e1, i - 64, v);
+#pragma unroll
+    for (int r = 0; r < R; ++r) er[r] = wl(er[r], i - 64 * r, v);
   }
-  // all couplings are tested at once: lane k looks at es[k] against |d[k]| + |d[k+1]|, a ballot finds the first split
+  // all couplings are tested at once: lane k of register r looks at es[64 r + k] against |d[.]| + |d[. + 1]|, ballots find
+  // the first split at or after l
   __device__ __forceinline__ int first_split(int l, int n) const {
     const int k = (int)threadIdx.x;
-    const float a0 = fabsf(d0), a1 = fabsf(d1);
-    float nx0 = __shfl_down(a0, 1, 64);       // |d[k+1]| for k < 63
-    const float a1_first = rl(a1, 0);
-    if (k == 63) nx0 = a1_first;               // |d[64]|
-    const float nx1 = __shfl_down(a1, 1, 64);  // |d[k+65]|
-    const float s0 = a0 + nx0, s1 = a1 + nx1;
-    const bool t0 = k < n - 1 && (fabsf(e0) + s0 == s0);
-    const bool t1 = k + 64 < n - 1 && (fabsf(e1) + s1 == s1);
-    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(t0), m1 = __builtin_amdgcn_ballot_w64(t1);
-    if (l < 64) {
-      const unsigned long long mm = m0 >> l;
-      if (mm) return l + __builtin_ctzll(mm);
-      if (m1) return 64 + __builtin_ctzll(m1);
-      return n - 1;
+    unsigned long long m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float a = fabsf(dr[r]);
+      float nx = __shfl_down(a, 1, 64);                     // |d[64 r + k + 1]| for k < 63
+      const float first_next = r + 1 < R ? rl(fabsf(dr[r + 1 < R ? r + 1 : r]), 0) : 0.f;
+      if (k == 63) nx = first_next;                          // |d[64 (r + 1)]|
+      const float sgm = a + nx;
+      const bool t = 64 * r + k < n - 1 && (fabsf(er[r]) + sgm == sgm);
+      m[r] = __builtin_amdgcn_ballot_w64(t);
     }
-    const unsigned long long mm = m1 >> (l - 64);
-    return mm ? l + __builtin_ctzll(mm) : n - 1;
+    int found = n - 1;
+    bool done = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (done || l >= 64 * (r + 1)) continue;               // l lies beyond this register
+      const int sh = l > 64 * r ? l - 64 * r : 0;
+      const unsigned long long mm = m[r] >> sh;
+      if (mm) { found = 64 * r + sh + __builtin_ctzll(mm); done = true; }
+    }
+    return found;
   }
 };
+using WaveCtx = WaveCtxN<2>;
 
 // partial[b][0] += partial[b][1..n_chunks-1]  (fixed order), so that the solve reads one matrix per sample
 __global__ void __launch_bounds__(256) gl_partial_sum_kernel(float* __restrict__ partial, int n_chunks, int DpDp) {
@@ -285,13 +403,17 @@ __global__ void __launch_bounds__(256) gl_partial_sum_kernel(float* __restrict__
   src[0] = v;
 }
 
+// R: registers of the lane-distributed tridiagonal (n <= 64 R).  GLOBAL: A and V live in `mats` ([B][2][n][ld] floats of the
+// workspace, L2-resident) instead of LDS -- systems above LS_LDS_MAXN unknowns; the vectors stay in LDS either way.
+template <int R, bool GLOBAL>
 __global__ void __launch_bounds__(64) gl_eigh_solve_kernel(const float* __restrict__ partial, int n_chunks, int n_sum,
-                                                           int D, int Dp, float rcond, float* __restrict__ coeffs) {
+                                                           int D, int Dp, float rcond, float* __restrict__ coeffs,
+                                                           float* __restrict__ mats) {
   extern __shared__ float sm[];
   const int n = D, ld = n | 1;
-  float* A = sm;               // [n][ld]
-  float* Z = A + n * ld;       // [n][ld]
-  float* d = Z + n * ld;       // [n]
+  float* A = GLOBAL ? mats + (size_t)blockIdx.x * 2 * n * ld : sm;  // [n][ld]
+  float* Z = A + n * ld;                                             // [n][ld]
+  float* d = GLOBAL ? sm : Z + n * ld;                               // [n]
   float* e = d + n;            // [n+1]
   float* v = e + n + 1;        // [n]
   float* p = v + n;            // [n]
@@ -317,7 +439,7 @@ __global__ void __launch_bounds__(64) gl_eigh_solve_kernel(const float* __restri
     bet[i] = 0.f;
   }
   __syncthreads();
-  WaveCtx cx;
+  WaveCtxN<R> cx;
   float scale = 0.f;
   for (int k = lane; k < n; k += 64) scale = fmaxf(scale, fabsf(A[k * ld + k]));
   scale = cx.max(scale);

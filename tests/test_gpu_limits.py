@@ -1,7 +1,7 @@
 """Every refusal of the native library is a clear, typed error -- never a silent fallback, never a crash.
 
 The closed-world limits (INTEGRATION.md "What does not transfer"): shapelets ``n_max > 20`` (the reference takes any
-``n_max``, shapelets.py:20-24), linear systems above 79 coefficients, ``ScalingRelation`` over profiles outside the dPIE
+``n_max``, shapelets.py:20-24), linear systems above 255 coefficients, ``ScalingRelation`` over profiles outside the dPIE
 family (scaling_relation.py:8-19 accepts any ``MassProfile``), user-defined ``deriv`` / ``light`` bodies (profile.py:58-82
 are abstract extension points in the reference; here a profile is a ``gl_kind`` the library implements)."""
 import ctypes
@@ -51,22 +51,23 @@ def test_shapelets_above_the_cap_are_refused():
         Shapelets(n_max=22, interpolate=False, use_lstsq=True).light(x, x, beta=1.0, center_x=0.0, center_y=0.0)
 
 
-def test_linear_systems_above_79_coefficients_are_refused():
-    """Two n_max = 8 shapelet sources solved linearly = 90 coefficients: the in-LDS solve serves 79."""
+def test_linear_systems_above_255_coefficients_are_refused():
+    """Two n_max = 15 shapelet sources solved linearly = 272 coefficients: the solve serves 255 (above 127 with its matrices in
+    the workspace instead of LDS); round 2 stopped at 79."""
     from gigalens_amd import _native
     from gigalens_amd.model import PhysicalModel
     from gigalens_amd.profiles.light.shapelets import Shapelets
     from gigalens_amd.profiles.mass.sis import SIS
     from gigalens_amd.simulator import LensSimulator, SimulatorConfig
-    phys = PhysicalModel([SIS()], [], [Shapelets(8, use_lstsq=True, interpolate=False), Shapelets(8, use_lstsq=True, interpolate=False)])
-    sim = LensSimulator(phys, SimulatorConfig(delta_pix=0.1, num_pix=16), bs=2)
+    phys = PhysicalModel([SIS()], [], [Shapelets(15, use_lstsq=True, interpolate=False), Shapelets(15, use_lstsq=True, interpolate=False)])
+    sim = LensSimulator(phys, SimulatorConfig(delta_pix=0.1, num_pix=20), bs=2)
     params = {"lens_mass": [dict(theta_E=1.0, center_x=0.0, center_y=0.0)],
               "source_light": [dict(beta=0.2, center_x=0.0, center_y=0.0), dict(beta=0.3, center_x=0.1, center_y=0.0)]}
-    obs, err = np.ones((16, 16), np.float32), np.ones((16, 16), np.float32)
-    with pytest.raises(_native.NativeLibraryError, match="90 linear coefficients"):
+    obs, err = np.ones((20, 20), np.float32), np.ones((20, 20), np.float32)
+    with pytest.raises(_native.NativeLibraryError, match="272 linear coefficients"):
         sim.lstsq_simulate(params, obs, err)
     # the stack itself (no solve) is still served
-    assert sim.lstsq_simulate(params, obs, err, return_stacked=True).shape == (2, 16, 16, 90)
+    assert sim.lstsq_simulate(params, obs, err, return_stacked=True).shape == (2, 20, 20, 272)
 
 
 def test_scaling_relation_outside_the_dpie_family_is_refused():
