@@ -28,6 +28,21 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_mix -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_mix.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmc_clk -- python3 $R/tools/prof_kernel.py --iters 8 > $OUT/pmc_clk.log 2>&1
+# round 3: the shapelet kernel (table and direct mode): issue / wait / memory-path counters, and the gradient accuracy scan
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_C3direct -- python3 $R/tools/prof_kernel.py --workload C3 --direct --iters 20 > $OUT/kernel_stats_C3direct.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_stats_C3D -- python3 $R/tools/prof_kernel.py --workload C3D --iters 20 > $OUT/kernel_stats_C3D.log 2>&1
+for G in "sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" \
+         "mix SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+         "clk GRBM_GUI_ACTIVE SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
+         "mem TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
+         "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+  set -- $G; N=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_C3_$N -- python3 $R/tools/prof_kernel.py --workload C3 --iters 6 > $OUT/pmc_C3_$N.log 2>&1
+done
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_C3direct -- python3 $R/tools/prof_kernel.py --workload C3 --direct --iters 6 > $OUT/pmc_C3direct.log 2>&1
+python3 $R/tools/dev/grad_accuracy_scan.py --n 8 > $OUT/grad_accuracy.jsonl 2> $OUT/grad_accuracy.err
+python3 $R/tools/dev/grad_accuracy_scan.py --configs cases > $OUT/grad_accuracy_cases.jsonl 2>> $OUT/grad_accuracy.err
+python3 -m pytest $R/tests/test_gpu_dist.py -m gpu -q > $OUT/two_rank_test.log 2>&1
 python3 $R/tools/map_step_time.py > $OUT/map_step_time.log 2>&1
 python3 $R/tools/svi_hmc_step_time.py > $OUT/svi_hmc_step_time.log 2>&1
 python3 $R/tools/bench_configs.py > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err

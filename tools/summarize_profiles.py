@@ -32,7 +32,7 @@ def stats_table(d, out, top=12):
     return rows
 
 
-def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_kernel<3", "gl_cluster_kernel<3")):
+def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_kernel<3", "gl_cluster_kernel<3", "gl_shp_kernel<3")):
     f = sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     if not f:
         return {}
@@ -49,7 +49,7 @@ def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_ker
 
 summary = {}
 rows = stats_table("bench_stats", f"{tag}_bench_kernel_stats.md")
-for w in ("C2", "C3", "C4", "C5", "C6", "C3L", "simpair", "demo"):
+for w in ("C2", "C3", "C3direct", "C3D", "C4", "C5", "C6", "C3L", "simpair", "demo"):
     stats_table(f"kernel_stats_{w}", f"{tag}_{w}_kernel_stats.md", top=6)
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mix", "pmc_clk"):
     summary[d] = pmc(d)
@@ -83,6 +83,40 @@ c3l = summary["pmc_C3L"] = pmc("pmc_C3L", kernel_filter=("gl_normal_mfma_kernel"
 if c3l.get("SQ_VALU_MFMA_BUSY_CYCLES") and c3l.get("GRBM_GUI_ACTIVE"):
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles over all SIMDs (MI355X_MICROARCH.md, PMC units); 1024 SIMDs
     c3l["mfma_busy_frac"] = c3l["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c3l["GRBM_GUI_ACTIVE"] / 8.0)
+# round 3: the shapelet kernel of C3 (table mode; per launch of 1024 samples x 128^2)
+c3 = {}
+for n in ("sq", "mix", "clk", "mem", "fetch", "write"):
+    c3.update({k: v for k, v in pmc(f"pmc_C3_{n}", kernel_filter=("gl_shp_kernel<3",)).items() if not k.startswith("_") or n == "clk"})
+if c3.get("SQ_INSTS_VALU"):
+    px = 1024 * 16384
+    cyc = c3.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    c3["valu_insts_per_pixel"] = c3["SQ_INSTS_VALU"] * 64 / px
+    if cyc:
+        c3["kernel_cycles"] = cyc
+        c3["valu_busy_frac"] = c3.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (1024 * cyc)
+        c3["mfma_busy_frac"] = c3.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * cyc)
+        c3["lds_active_frac"] = c3.get("SQ_LDS_IDX_ACTIVE", 0) / (256 * cyc)
+        c3["ta_busy_frac"] = c3.get("TA_BUSY_avr", 0) / cyc
+        c3["l1_accesses_per_cu_cycle"] = c3.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / (256 * cyc)
+    if c3.get("FETCH_SIZE") is not None and c3.get("WRITE_SIZE") is not None:
+        c3["hbm_bytes_per_launch"] = (2 * c3["FETCH_SIZE"] + c3["WRITE_SIZE"]) * 1024
+summary["pmc_C3_shapelet_kernel"] = c3
+c3d = pmc("pmc_C3direct", kernel_filter=("gl_shp_kernel<3",))
+if c3d.get("SQ_INSTS_VALU") and c3d.get("GRBM_GUI_ACTIVE"):
+    c3d["valu_insts_per_pixel"] = c3d["SQ_INSTS_VALU"] * 64 / (1024 * 16384)
+    c3d["valu_busy_frac"] = c3d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * c3d["GRBM_GUI_ACTIVE"] / 8.0)
+summary["pmc_C3_direct"] = c3d
+for gname in ("grad_accuracy.jsonl", "grad_accuracy_cases.jsonl"):
+    gp = os.path.join(src, gname)
+    if os.path.exists(gp):
+        rows_g = [json.loads(l) for l in open(gp) if l.startswith("{")]
+        summary[gname.replace(".jsonl", "")] = [{k: v for k, v in r.items() if k != "columns"} for r in rows_g]
+        with open(os.path.join(dst, f"{tag}_{gname}"), "w") as fh:
+            for r in rows_g:
+                fh.write(json.dumps(r) + "\n")
+tr = os.path.join(src, "two_rank_test.log")
+if os.path.exists(tr):
+    summary["two_rank_real_kernel_test"] = [l.strip() for l in open(tr) if "passed" in l or "failed" in l]
 for name in ("map_step_time", "svi_hmc_step_time"):
     f = os.path.join(src, name + ".log")
     if os.path.exists(f):

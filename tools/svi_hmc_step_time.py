@@ -23,6 +23,9 @@ for name, kw, n in (("C2", dict(num_pix=60, batch=250), 250), ("C2", dict(), 102
         print(f"SVI {name} {kw} n_vi={n} full_rank={full}: {dt/200*1e3:.3f} ms per step", flush=True)
     (mean, L), _ = seq.SVI(Adam(1e-3), start, n_vi=n, num_steps=20)
     nh = min(n, 256)
+    # warm-up: the first HMC call of a process pays one-off host start-up (torch.linalg initialisation, workspace sizing) -- in
+    # round 2 that start-up was divided by 60 transitions and reported as a step time
+    seq.HMC((mean, L), n_hmc=nh, init_eps=0.1, init_l=5, max_leapfrog_steps=5, num_burnin_steps=4, num_results=4)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     samples, stats = seq.HMC((mean, L), n_hmc=nh, init_eps=0.1, init_l=5, max_leapfrog_steps=5, num_burnin_steps=20, num_results=40)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
