@@ -74,15 +74,21 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
       int j = base + w * WG + tid;
       valid[w] = CHECK ? (j < p1) : true;
       jj[w] = (unsigned)(valid[w] ? j : p1 - 1);
-      pidx[w] = has_pix ? (unsigned)a.pix[jj[w]] : jj[w];
+      pidx[w] = (CHECK && has_pix) ? (unsigned)a.pix[jj[w]] : jj[w];  // CHECK=false tiles run only without a pixel list
     }
+    // 32-bit BYTE offsets from the (scalar) plane bases: one shift per pixel serves the grid, the observation and the error
+    // plane (global_load ... v_off, s[base]) instead of a 64-bit address computation per load
+    unsigned jo[W], po[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { jo[w] = jj[w] << 2; po[w] = pidx[w] << 2; }
+    auto ldf = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
     if constexpr (W == 2) {
-      x = V{a.gx[jj[0]], a.gx[jj[1]]};
-      y = V{a.gy[jj[0]], a.gy[jj[1]]};
+      x = V{ldf(a.gx, jo[0]), ldf(a.gx, jo[1])};
+      y = V{ldf(a.gy, jo[0]), ldf(a.gy, jo[1])};
       if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
     } else {
-      x = a.gx[jj[0]];
-      y = a.gy[jj[0]];
+      x = ldf(a.gx, jo[0]);
+      y = ldf(a.gy, jo[0]);
       if (CHECK) vmask = valid[0] ? 1.f : 0.f;
     }
     V bx = x, by = y, m = V(0.f);
@@ -123,13 +129,13 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
     } else {
       V o, w = vmask, e = V(1.f);
       if constexpr (W == 2) {
-        o = V{a.obs[pidx[0]], a.obs[pidx[1]]};
-        if (CHECK && has_mask) w = w * V{a.mask[pidx[0]], a.mask[pidx[1]]};
-        if (has_err) e = V{a.err[pidx[0]], a.err[pidx[1]]};
+        o = V{ldf(a.obs, po[0]), ldf(a.obs, po[1])};
+        if (CHECK && has_mask) w = w * V{ldf(a.mask, po[0]), ldf(a.mask, po[1])};
+        if (has_err) e = V{ldf(a.err, po[0]), ldf(a.err, po[1])};
       } else {
-        o = a.obs[pidx[0]];
-        if (CHECK && has_mask) w = w * a.mask[pidx[0]];
-        if (has_err) e = a.err[pidx[0]];
+        o = ldf(a.obs, po[0]);
+        if (CHECK && has_mask) w = w * ldf(a.mask, po[0]);
+        if (has_err) e = ldf(a.err, po[0]);
       }
       // tf/model.py:92-99; sigma^2 = bg^2 + m/t (no clip: negative -> NaN like sqrt of a negative)
       V dmo = m - o;
@@ -177,7 +183,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
     }
   };
   {
-    const bool plain = !has_mask;
+    const bool plain = !has_mask && !has_pix;
     int base = p0;
     if (GL_DBG(a.dbg, 1)) base = p1;
     if (plain)

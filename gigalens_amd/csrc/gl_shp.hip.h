@@ -216,9 +216,12 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       int j = base + w * WG + tid;
       valid[w] = CHECK ? (j < p1) : true;
       jj[w] = (unsigned)(valid[w] ? j : p1 - 1);
-      pidx[w] = has_pix ? (unsigned)a.pix[jj[w]] : jj[w];
+      pidx[w] = (CHECK && has_pix) ? (unsigned)a.pix[jj[w]] : jj[w];  // CHECK=false tiles run only without a pixel list
     }
-    const V x = V{a.gx[jj[0]], a.gx[jj[1]]}, y = V{a.gy[jj[0]], a.gy[jj[1]]};
+    // 32-bit byte offsets from the scalar plane bases (one shift per pixel serves grid, observation and error planes)
+    const unsigned jo0 = jj[0] << 2, jo1 = jj[1] << 2, po0 = pidx[0] << 2, po1 = pidx[1] << 2;
+    auto ldf = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+    const V x = V{ldf(a.gx, jo0), ldf(a.gx, jo1)}, y = V{ldf(a.gy, jo0), ldf(a.gy, jo1)};
     if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
     V bx = x, by = y, m = V(0.f);
     EplStateV<V> est[NL > 0 ? NL : 1];
@@ -271,9 +274,9 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       const V g = V{row[pidx[0]], row[pidx[1]]};
       gm = nanp ? V(0.f) : (CHECK ? g * vmask : g) * a.out_scale;
     } else {
-      V o = V{a.obs[pidx[0]], a.obs[pidx[1]]}, w = vmask, e = V(1.f);
-      if (CHECK && has_mask) w = w * V{a.mask[pidx[0]], a.mask[pidx[1]]};
-      if (has_err) e = V{a.err[pidx[0]], a.err[pidx[1]]};
+      V o = V{ldf(a.obs, po0), ldf(a.obs, po1)}, w = vmask, e = V(1.f);
+      if (CHECK && has_mask) w = w * V{ldf(a.mask, po0), ldf(a.mask, po1)};
+      if (has_err) e = V{ldf(a.err, po0), ldf(a.err, po1)};
       V dmo = m - o;  // tf/model.py:92-99; sigma^2 = bg^2 + m/t (no clip: negative -> NaN like the sqrt of a negative)
       V s2 = has_err ? e * e : m * a.inv_t + a.bg2;
       V is2 = rcp(s2);
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     }
   };
   {
-    const bool plain = !has_mask;
+    const bool plain = !has_mask && !has_pix;
     int base = p0;
     if (plain)
       for (; base + WG * 2 <= p1; base += WG * 2) tile(base, std::false_type{});
