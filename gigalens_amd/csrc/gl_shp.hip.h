@@ -35,11 +35,17 @@ __host__ __device__ constexpr size_t shp_exchange_bytes(int np) { return (size_t
 template <int NP> struct ShpPix { float S, Su, Sv, u, v, dx, dy, fac; };  // what a pixel's VJP needs of its forward pass
 
 // table row of one coordinate: NP pairs of values at the node below and NP pairs of differences to the next node
+// `live`: the pixel's OTHER coordinate is inside the table too.  Every output of a pixel is a product with a basis along v or
+// its slope (S = sum Y s, dS/du = sum Y s', dS/dv = sum Y' s, G = gS X Y^T), so a pixel with one coordinate outside renders
+// exactly zero whatever the other basis is: both of its rows are sent to the zero row, which all such lanes share (one L1
+// access per instruction instead of one per lane: the gather is what binds this kernel).  0.289 -> 0.272 ms at C3.
+// (Skipping per pixel SLOT instead of per tile -- the lane's two pixels tested separately -- was slower, 0.300 ms: behind its own
+// branch the second pixel's gather no longer overlaps the first pixel's contraction.)
 template <int NP>
-__device__ __forceinline__ void shp_row(const float* __restrict__ tab, float u, v2f (&val)[NP], v2f (&dif)[NP], float& tt) {
+__device__ __forceinline__ void shp_row(const float* __restrict__ tab, float u, bool live, v2f (&val)[NP], v2f (&dif)[NP], float& tt) {
   const float scale = (float)(SH_NODES - 1) / 10.f;
   const float fi = (u + 5.f) * scale;  // tfp.math.interp_regular_1d_grid on [-5, 5], fill 0 outside (shapelets.py:58-60)
-  const bool inside = (fi >= 0.f) && (fi <= (float)(SH_NODES - 1));
+  const bool inside = live && (fi >= 0.f) && (fi <= (float)(SH_NODES - 1));
   const float fic = clamp_(fi, 0.f, (float)(SH_NODES - 1));
   const float fb = fmin_(floor_(fic), (float)(SH_NODES - 2));  // the last node belongs to the last interval (t = 1)
   tt = fic - fb;
@@ -93,8 +99,9 @@ __device__ __forceinline__ bool shp_in_table(float u) {
 template <int NP, bool INTERP>
 __device__ __forceinline__ void shp_pixel_gather(const float* __restrict__ tab, const ShpPix<NP>& st, ShpRows<NP>& r) {
   if constexpr (INTERP) {
-    shp_row<NP>(tab, st.u, r.xv, r.xd, r.tu);
-    shp_row<NP>(tab, st.v, r.yv, r.yd, r.tv);
+    const bool live = shp_in_table(st.u) && shp_in_table(st.v);
+    shp_row<NP>(tab, st.u, live, r.xv, r.xd, r.tu);
+    shp_row<NP>(tab, st.v, live, r.yv, r.yd, r.tv);
   }
 }
 
