@@ -412,9 +412,25 @@ __global__ void __launch_bounds__(256) gl_prep_wave_kernel(const CompDesc* __res
       case K_CORE_SERSIC: core_sersic_prep<float>(p, d); break;
       case K_SERSIC: sersic_prep<float>(p, false, d); break;
       case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
-      case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, d); break;
+      case K_SHAPELETS:  // the four constants here; the amplitude blocks below, by the whole wavefront
+        d[SHP_CX] = p[1]; d[SHP_CY] = p[2]; d[SHP_IB] = 1.f / p[0]; d[SHP_NMAX] = (float)cd.iparam;
+        break;
     }
     if (cost && lane == cost_comp) cost[b] = K;
+  }
+  for (int c = 0; c < n_comp; ++c) {  // wave-uniform: every lane joins the amplitude blocks of every shapelet component
+    if (comps[c].kind != K_SHAPELETS) continue;  // (one lane copying 66 + 144 values one by one: 18.6 us of prep at C3)
+    const CompDesc cd = comps[c];
+    const float* p = (params_in ? params_in : params_out) + (size_t)b * P + cd.p_off;
+    float* d = derived + (size_t)b * D + cd.d_off;
+    const int n_max = cd.iparam, L = sh_layers(n_max);
+    const int tri = n_max > SH_CAP ? ((SH_MAXLB + 3) & ~3) : ((SH_MAXL + 3) & ~3);
+    for (int i = lane; i < tri; i += 64) d[SHP_AMP + i] = i < L ? p[3 + i] : 0.f;
+    if (n_max <= SH_CAP)
+      for (int e = lane; e < SH_SQ * SH_SQ; e += 64) {
+        const int n1 = e / SH_SQ, n2 = e - n1 * SH_SQ, n = n1 + n2;
+        d[SHP_SQ + e] = n <= n_max ? p[3 + n * (n + 1) / 2 + n2] : 0.f;
+      }
   }
   for (int c = 0; c < n_comp; ++c) {  // wave-uniform: every lane joins the table of every EPL lens
     if (comps[c].kind != K_EPL) continue;
