@@ -20,6 +20,7 @@
 #include "gl_post.hip.h"
 #include "gl_positions.hip.h"
 #include "gl_lstsq.hip.h"
+#include "gl_shp.hip.h"
 
 using namespace glk;
 
@@ -640,6 +641,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
 #endif
   m->corr_max_pairs = env_int("GIGALENS_HIP_CORR_MAXPAIRS", 0);  // tests: force the slicing of the PSF launches (read once)
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
+  m->lstsq_fused = env_int("GIGALENS_HIP_LSTSQ_FUSED", 1) != 0;  // tests: 0 = the linear solve through the basis stack (read once)
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
 
@@ -1021,13 +1023,45 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   a.parts = parts | GL_PART_LENS_LIGHT | GL_PART_SOURCE_LIGHT;
   a.n_lin = D;
   if ((rc = run_order(m, B, w, &a, stream))) return rc;
+  // One shapelet source as the only light component, no PSF / supersampling / pixel list, the stack not asked for: the normal
+  // matrix straight from the bases (gl_shp_normal_kernel), no stack in HBM; a fitted image is rendered from the solved amplitudes
+  const bool fused = solve && !stacked_or_null && !m->has_post && !m->d_pix && m->shp_kernel && m->static_id == ST_EPLSHEAR_SHAPELETS &&
+                     m->n_ll == 0 && m->comps.back().iparam <= SH_CAP && D == sh_layers(m->comps.back().iparam) &&
+                     (a.parts & (GL_PART_DEFLECT | GL_PART_SOURCE_LIGHT)) == (GL_PART_DEFLECT | GL_PART_SOURCE_LIGHT) &&
+                     m->lstsq_fused;
+  if (fused) {
+    const bool interp = (m->comps.back().flags & GL_FLAG_SHAPELETS_INTERPOLATE) != 0;
+    constexpr int NPS = SH_SQ / 2;
+    ShpNormalArgs sn{obs, err, lw.partial, D, lw.Dp};
+    MainArgs fa = a;
+    fa.chunk = lw.chunk;
+    const int nt = (D + 1 + 15) / 16;
+    const size_t red = (size_t)(nt * (nt + 1) / 2 * 256 + 8) * sizeof(float);
+    const size_t sh = (size_t)((m->D + 3) & ~3) * sizeof(float) +
+                      std::max((size_t)4 * (shp_exchange_floats(NPS) + SHX_PLANE) * sizeof(float), red);
+    const dim3 grid(lw.n_chunks, B), block(WG);
+#define GL_SHPN(NT_, I_)                                                                                        \
+  do {                                                                                                          \
+    m->last_main_fn = (const void*)&gl_shp_normal_kernel<NT_, 2, L_EplShear, NPS, I_>;                          \
+    hipLaunchKernelGGL((gl_shp_normal_kernel<NT_, 2, L_EplShear, NPS, I_>), grid, block, sh, stream, fa, sn);  \
+  } while (0)
+    if (nt == 1) { if (interp) GL_SHPN(1, true); else GL_SHPN(1, false); }
+    else if (nt == 2) { if (interp) GL_SHPN(2, true); else GL_SHPN(2, false); }
+    else if (nt == 3) { if (interp) GL_SHPN(3, true); else GL_SHPN(3, false); }
+    else if (nt == 4) { if (interp) GL_SHPN(4, true); else GL_SHPN(4, false); }
+    else { if (interp) GL_SHPN(5, true); else GL_SHPN(5, false); }
+#undef GL_SHPN
+    GL_HIP(hipGetLastError());
+  }
   float* target = m->has_post ? lw.stack_ss : lw.stack;
+  if (!fused) {
   if (m->d_pix) GL_HIP(hipMemsetAsync(target, 0, sizeof(float) * (size_t)B * D * m->height * m->width, stream));
   a.img = target;
   if ((rc = launch_main<IMG_BASIS>(m, a, B, n_chunks, stream))) return rc;
   if (m->has_post && (rc = post_fwd(m, B * D, lw.stack_ss, lw.stack, stream, 1.f))) return rc;  // no det(T) here (:226-240)
   if (stacked_or_null)
     GL_HIP(hipMemcpyAsync(stacked_or_null, lw.stack, sizeof(float) * (size_t)B * D * HW, hipMemcpyDeviceToDevice, stream));
+  }  // !fused
   if (!solve) return GL_OK;
   NormalArgs na{};
   na.stack = lw.stack;
@@ -1039,7 +1073,9 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   na.chunk = lw.chunk;
   na.n_chunks = lw.n_chunks;
   na.partial = lw.partial;
-  if (D + 1 <= LS_SMALL)
+  if (fused) {
+    // the partials are already there
+  } else if (D + 1 <= LS_SMALL)
     hipLaunchKernelGGL((gl_normal_small_kernel<LS_SMALL>), dim3(lw.n_chunks, B), dim3(256), 0, stream, na);
   else if (D + 1 > LS_MAXD) {  // more than five tile rows: super-block pairs (gl_normal_pair_kernel)
     const int vec_ok = (HW % 4 == 0) && ((uintptr_t)obs % 16 == 0) && ((uintptr_t)err % 16 == 0) && ((uintptr_t)lw.stack % 16 == 0);
@@ -1089,7 +1125,20 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
                        1e-6f, coeffs, lw.mats);
   }
   GL_HIP(hipGetLastError());
-  if (image_or_null) {
+  if (image_or_null && fused) {
+    // image = sum_d coeffs_d basis_d = the ordinary render with the solved amplitudes in their parameter columns (no det(T):
+    // the stack carries none, tf/simulator.py:226-240)
+    hipLaunchKernelGGL(gl_set_amplitudes_kernel, dim3((unsigned)(((long long)B * m->P + 255) / 256)), dim3(256), 0, stream,
+                       params, m->P, B, m->d_lin_cols, D, coeffs, w.params);
+    GL_HIP(hipGetLastError());
+    if ((rc = run_prep(m, w.params, B, w, stream))) return rc;
+    MainArgs ia = base_args(m, w, chunk);
+    ia.parts = a.parts;
+    ia.order = a.order;
+    ia.img = image_or_null;
+    ia.out_scale = 1.f;
+    if ((rc = launch_main<IMG_FWD>(m, ia, B, n_chunks, stream))) return rc;
+  } else if (image_or_null) {
     hipLaunchKernelGGL(gl_combine_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, stream, lw.stack, coeffs, D, HW,
                        image_or_null);
     GL_HIP(hipGetLastError());

@@ -14,17 +14,6 @@ namespace glk {
 // ---- compile-time-specialised compositions (gl_static.hip.h) ------------------------------------------
 // SERSIC and SERSIC_ELLIPSE share one device code path (the spherical profile is the e = 0 member), so
 // signatures are matched after folding SERSIC_ELLIPSE -> SERSIC.
-using L_EplShear = KindList<K_EPL, K_SHEAR>;
-using L_Sie = KindList<K_SIE>;
-using L_SieShear = KindList<K_SIE, K_SHEAR>;
-using C_None = KindList<>;
-using C_Sersic = KindList<K_SERSIC>;           // pair kernels: spherical fast path (every light profile of the model spherical)
-using C_SersicE = KindList<K_SERSIC_ELLIPSE>;  // pair kernels: the general elliptical code, serves spherical members too
-using C_Shapelets = KindList<K_SHAPELETS>;
-
-enum StaticId { ST_NONE = 0, ST_EPLSHEAR_SERSIC, ST_EPLSHEAR_SERSIC_SERSIC, ST_SIE_SERSIC, ST_EPLSHEAR_SHAPELETS,
-                ST_SIESHEAR_SERSIC_SERSIC, ST_EPLSHEAR_SERSIC_SHAPELETS /* shapelets-demo.ipynb: lens light + shapelet source */ };
-
 template <int MODE>
 bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
   const int T = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;

@@ -483,4 +483,17 @@ __global__ void __launch_bounds__(256) gl_unit_amplitudes_kernel(const float* __
   out[i] = v;
 }
 
+// params copy with amplitude column k set to the solved coefficient k (the fitted image of the stack-free path)
+__global__ void __launch_bounds__(256) gl_set_amplitudes_kernel(const float* __restrict__ params, int P, int B,
+                                                                const int* __restrict__ lin_cols, int D,
+                                                                const float* __restrict__ coeffs, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * P) return;
+  const int col = i % P, b = i / P;
+  float v = params[i];
+  for (int k = 0; k < D; ++k)
+    if (lin_cols[k] == col) v = coeffs[(size_t)b * D + k];
+  out[i] = v;
+}
+
 }  // namespace glk

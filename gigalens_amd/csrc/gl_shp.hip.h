@@ -471,4 +471,186 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
   }
 }
 
+
+// ---- lstsq_simulate without the basis stack (tf/simulator.py:158-240) -------------------------------------------------------
+// The normal matrix of the linear-amplitude solve,  N = [X | Y]^T W^2 [X | Y]  with X the unit-amplitude shapelet basis images,
+// is formed straight from the bases: the round-2 path rendered the (D, H W) stack of every sample to HBM (4.4 GB at C3L, 0.98
+// ms) and read it back in the SYRK (1.21 ms).  Here a wave keeps X_n(u) w and Y_n(v) of its 128 pixels in LDS planes (the
+// exchange layout of gl_shp_kernel), and lane (c, k) of the MFMA operand layout multiplies its channel's factors on the fly:
+// channel (n1, n2) of pixel P = X'[n1][P] Y[n2][P]; the observation column reads obs w against a plane of ones, padding channels
+// a plane of zeros -- no selects in the loop.  NT tile rows of 16 channels, lower tiles only, exact fp32 MFMA like the SYRK.
+// Tiles none of whose pixels lies inside the shapelet table only add their sum of (obs w)^2 to the (Y, Y) entry.
+struct ShpNormalArgs {
+  const float* obs;   // [N]
+  const float* err;   // [N]
+  float* partial;     // [B][n_chunks][Dp * Dp], lower triangle valid (the layout of gl_normal_mfma_kernel)
+  int Dl, Dp;         // linear channels (shapelet layers); Dp = Dl + 1 rounded up to a multiple of 4
+};
+
+template <int NT, int WAVES, class LK, int NP, bool INTERP>
+__global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, ShpNormalArgs na) {
+  using V = v2f;
+  constexpr int NL = LK::n;
+  constexpr int NTILES = NT * (NT + 1) / 2;
+  constexpr int XPL = shp_exchange_floats(NP) + SHX_PLANE;  // + one plane of (obs w, 1) pairs per pixel (per wave)
+  extern __shared__ float smem[];
+  float* s_d = smem;
+  float* s_x = smem + ((a.D + 3) & ~3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
+  const CompDesc* __restrict__ comps = a.comps;
+  const float* __restrict__ gder = a.derived + (size_t)b * a.D;
+  for (int i = tid; i < a.D; i += WG) s_d[i] = gder[i];
+  float* xw = s_x + wave * XPL;
+  float* pl_ow = xw + shp_exchange_floats(NP);  // [pixel][2] = (obs w, 1): the observation column's two "factors"
+  __syncthreads();
+  const float* dL[NL > 0 ? NL : 1];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) dL[i] = s_d + comps[i].d_off;
+  const CompDesc shp = comps[NL];
+  const float* dS = s_d + shp.d_off;
+  float* wr_x = xw + 2 * lane;
+  float* wr_y = xw + NP * SHX_PLANE + 2 * lane;
+  // the lane's channel of every tile row -- two factor addresses in the planes ([pixel][2] pairs, 8 floats per pixel group):
+  // amplitude (n1, n2): X'[n1] and Y[n2]; the observation column: (obs w, 1); padding: order 2 NP - 1 of X and Y, which is
+  // zero for every n_max this kernel serves (<= 2 NP - 2)
+  const int c = lane & 15, k = lane >> 4;
+  const float* rd_a[NT];
+  const float* rd_b[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ch = 16 * t + c;
+    int n1 = 2 * NP - 1, n2 = 2 * NP - 1;
+    if (ch < na.Dl) {
+      int n = 0;
+      while ((n + 1) * (n + 2) / 2 <= ch) ++n;
+      n2 = ch - n * (n + 1) / 2;
+      n1 = n - n2;
+    }
+    rd_a[t] = xw + (n1 >> 1) * SHX_PLANE + (n1 & 1) + 2 * k;
+    rd_b[t] = xw + NP * SHX_PLANE + (n2 >> 1) * SHX_PLANE + (n2 & 1) + 2 * k;
+    if (ch == na.Dl) { rd_a[t] = pl_ow + 2 * k; rd_b[t] = pl_ow + 1 + 2 * k; }
+  }
+  v4f acc[NTILES];
+#pragma unroll
+  for (int q = 0; q < NTILES; ++q) acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
+  V yy = V(0.f);  // sum of (obs w)^2 over the tiles that skip the MFMAs
+  const int p0 = chunk * a.chunk;
+  const int p1 = min(p0 + a.chunk, a.N);
+  for (int base = p0; base < p1; base += WG * 2) {
+    unsigned jj[2];
+    bool valid[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const int j = base + w * WG + tid;
+      valid[w] = j < p1;
+      jj[w] = (unsigned)(valid[w] ? j : p1 - 1);
+    }
+    const unsigned jo0 = jj[0] << 2, jo1 = jj[1] << 2;
+    auto ldf = [](const float* bp, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bp) + byte_off); };
+    const V x = V{ldf(a.gx, jo0), ldf(a.gx, jo1)}, y = V{ldf(a.gy, jo0), ldf(a.gy, jo1)};
+    const V er = V{ldf(na.err, jo0), ldf(na.err, jo1)}, ob = V{ldf(na.obs, jo0), ldf(na.obs, jo1)};
+    V wgt = rcp(er);  // weights 1/err by v_rcp_f32, like the SYRK
+    wgt = V{valid[0] ? wgt.x : 0.f, valid[1] ? wgt.y : 0.f};
+    const V ow = ob * wgt;
+    V bx = x, by = y;
+    EplStateV<V> est;
+    static_for([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int kind = LK::kinds[i];
+      if constexpr (kind == K_EPL) epl_fwd_v<V, false>(dL[i], gder + comps[i].d_off, x, y, bx, by, est);
+      else if constexpr (kind == K_SIE) sie_fwd_v<V>(dL[i], x, y, bx, by);
+      else if constexpr (kind == K_SHEAR) shear_fwd_v<V>(dL[i], x, y, bx, by);
+      else sis_fwd_v<V>(dL[i], x, y, bx, by);
+    }, std::make_integer_sequence<int, NL>{});
+    ShpPix<NP> ps0, ps1;
+    shp_pixel_coords<NP>(dS, bx.x, by.x, ps0);
+    shp_pixel_coords<NP>(dS, bx.y, by.y, ps1);
+    bool live = true;
+    if constexpr (INTERP) {
+      const bool inr = (shp_in_table(ps0.u) && shp_in_table(ps0.v)) || (shp_in_table(ps1.u) && shp_in_table(ps1.v));
+      live = __builtin_amdgcn_ballot_w64(inr) != 0;
+    }
+    if (!live) {  // every basis image vanishes on these pixels: only Y^T Y grows
+      yy += ow * ow;
+      continue;
+    }
+    auto bases = [&](ShpPix<NP>& ps, float w1, float* xb, float* yb) {
+      ShpRows<NP> r;
+      shp_pixel_gather<NP, INTERP>(a.shp_tab2, ps, r);
+      float fac = 1.f;
+      if constexpr (INTERP) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) r.xv[j] = __builtin_elementwise_fma(v2f(r.tu), r.xd[j], r.xv[j]);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) r.yv[j] = __builtin_elementwise_fma(v2f(r.tv), r.yd[j], r.yv[j]);
+      } else {
+        const int n_max = (int)dS[SHP_NMAX];
+        shp_hermite<NP>(ps.u, n_max, r.xv, r.xd);
+        shp_hermite<NP>(ps.v, n_max, r.yv, r.yd);
+        fac = exp_(-(ps.u * ps.u + ps.v * ps.v) * 0.5f);
+      }
+      const float xs = w1 * fac;  // weight (and the Gaussian of direct mode) folded into the X factor
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        v2f xv = r.xv[j] * xs;
+        xv = V{xv.x == xv.x ? xv.x : 0.f, xv.y == xv.y ? xv.y : 0.f};  // NaN -> 0 like the stack (tf/simulator.py:140 on each basis image)
+        *reinterpret_cast<v2f*>(xb + j * SHX_PLANE) = xv;
+        *reinterpret_cast<v2f*>(yb + j * SHX_PLANE) = r.yv[j];
+      }
+    };
+    bases(ps0, wgt.x, wr_x, wr_y);
+    bases(ps1, wgt.y, wr_x + 128, wr_y + 128);
+    *reinterpret_cast<v2f*>(pl_ow + 2 * lane) = v2f{ow.x, 1.f};
+    *reinterpret_cast<v2f*>(pl_ow + 128 + 2 * lane) = v2f{ow.y, 1.f};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 2
+    for (int kb = 0; kb < 32; ++kb) {
+      float v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = rd_a[t][8 * kb] * rd_b[t][8 * kb];
+      int q = 0;
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[ti], v[tj], acc[q], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- the four waves' tiles summed in fixed order through LDS (aliases the planes), then the lower tiles written ----
+  __syncthreads();
+  float* s_red = s_x;
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int q = 0; q < NTILES; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int idx = (q * 4 + r) * 64 + lane;
+          s_red[idx] = (wv == 0 ? 0.f : s_red[idx]) + acc[q][r];
+        }
+    }
+    __syncthreads();
+  }
+  float* s_yy = s_red + NTILES * 256;
+  {
+    const float t = wave_sum63(yy.x + yy.y);
+    if (lane == 63) s_yy[wave] = t;
+  }
+  __syncthreads();
+  const float yy_skipped = (s_yy[0] + s_yy[1]) + (s_yy[2] + s_yy[3]);
+  float* out = na.partial + ((size_t)b * gridDim.x + chunk) * na.Dp * na.Dp;
+  for (int e = tid; e < NTILES * 256; e += WG) {
+    const int q = e >> 8, r = (e >> 6) & 3, ll = e & 63;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+    const int tj = q - ti * (ti + 1) / 2;
+    const int i = 16 * ti + 4 * (ll >> 4) + r, j = 16 * tj + (ll & 15);
+    if (i < na.Dp && j < na.Dp) out[i * na.Dp + j] = s_red[e] + ((i == na.Dl && j == na.Dl) ? yy_skipped : 0.f);
+  }
+}
+
 }  // namespace glk

@@ -411,4 +411,17 @@ __global__ void __launch_bounds__(WG, WAVES) gl_static_kernel(MainArgs a) {
   }
 }
 
+// the compositions with a compile-time-specialised kernel (dispatch: gl_launch.hip.h)
+using L_EplShear = KindList<K_EPL, K_SHEAR>;
+using L_Sie = KindList<K_SIE>;
+using L_SieShear = KindList<K_SIE, K_SHEAR>;
+using C_None = KindList<>;
+using C_Sersic = KindList<K_SERSIC>;           // pair kernels: spherical fast path (every light profile of the model spherical)
+using C_SersicE = KindList<K_SERSIC_ELLIPSE>;  // pair kernels: the general elliptical code, serves spherical members too
+using C_Shapelets = KindList<K_SHAPELETS>;
+
+enum StaticId { ST_NONE = 0, ST_EPLSHEAR_SERSIC, ST_EPLSHEAR_SERSIC_SERSIC, ST_SIE_SERSIC, ST_EPLSHEAR_SHAPELETS,
+                ST_SIESHEAR_SERSIC_SERSIC, ST_EPLSHEAR_SERSIC_SHAPELETS /* shapelets-demo.ipynb: lens light + shapelet source */ };
+
+
 }  // namespace glk

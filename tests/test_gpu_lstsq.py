@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 F64 = torch.float64
 
 
-def _model(kind, num_pix, batch, psf=False, ss=1):
+def _model(kind, num_pix, batch, psf=False, ss=1, lens_light=True, interpolate=None):
     from gigalens_amd import prior as tfd
     from gigalens_amd import workloads
     from gigalens_amd.model import PhysicalModel
@@ -36,9 +36,10 @@ def _model(kind, num_pix, batch, psf=False, ss=1):
     else:                  # shapelets n_max=3 (10) + lens light (1): the register-tiled normal-matrix kernel
         shp = J(dict(beta=tfd.LogNormal(math.log(0.15), 0.1), center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05)))
         n_max = int(kind[len("shapelets"):]) if kind[len("shapelets"):].isdigit() else 3
-        phys = PhysicalModel([EPL(), Shear()], [SersicEllipse(use_lstsq=True)],
-                             [Shapelets(n_max, use_lstsq=True, interpolate=(kind != "shapelets_direct"))])
-        prior = J(dict(lens_mass=S([epl, shear]), lens_light=S([sere]), source_light=S([shp])))
+        interp = (kind != "shapelets_direct") if interpolate is None else interpolate
+        phys = PhysicalModel([EPL(), Shear()], [SersicEllipse(use_lstsq=True)] if lens_light else [],
+                             [Shapelets(n_max, use_lstsq=True, interpolate=interp)])
+        prior = J(dict(lens_mass=S([epl, shear]), lens_light=S([sere] if lens_light else []), source_light=S([shp])))
     cfg = SimulatorConfig(delta_pix=0.08, num_pix=num_pix, supersample=ss)
     return workloads.Workload("LSQ", phys, prior, cfg, batch)
 
@@ -106,6 +107,49 @@ def test_lstsq_simulate_vs_oracle(gl, kind, num_pix, batch, psf, ss):
     nd = sim.lstsq_simulate(x, obs, err, no_deflection=True)
     rel_nd = np.abs(nd.cpu().numpy() - nd_o.numpy()).max() / np.abs(nd_o.numpy()).max()
     assert rel_nd <= img_tol, rel_nd
+
+
+@pytest.mark.parametrize("n_max,interpolate,num_pix,batch", [(2, True, 32, 3),     # 6 channels + observation: one tile row
+                                                             (5, False, 37, 2),    # 22: two tile rows, ragged pixel count
+                                                             (7, True, 40, 2),     # 37: three
+                                                             (9, False, 44, 2),    # 56: four
+                                                             (10, True, 64, 3),    # 67: five tile rows, several chunks / sample
+                                                             (10, False, 40, 70)]) # more samples than one wave of workgroups
+def test_lstsq_without_the_stack(gl, monkeypatch, n_max, interpolate, num_pix, batch):
+    """EPL + shear lens, ONE shapelet source, nothing else linear, no PSF: the normal matrix comes straight from the bases
+    (csrc/gl_shp.hip.h gl_shp_normal_kernel) and the fitted image from the solved amplitudes -- the (D, H, W) stack of
+    tf/simulator.py:226-240 never exists.  Same answers as the oracle and as the library's own stack path."""
+    from oracle import ref_torch as ref
+    wl = _model(f"shapelets{n_max}", num_pix, batch, lens_light=False, interpolate=interpolate)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=batch)
+    monkeypatch.setenv("GIGALENS_HIP_LSTSQ_FUSED", "0")   # read once per model: this one goes through the stack
+    sim_stack = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=batch)
+    monkeypatch.delenv("GIGALENS_HIP_LSTSQ_FUSED")
+    x = wl.prior.sample(batch, seed=6)
+    obs, err = _observation(wl)
+    rs = ref.RefSimulator(wl.phys_model, wl.sim_config, batch, dtype=F64)
+    x64 = {g: [{k: v.double() for k, v in d.items()} for d in lst] for g, lst in x.items()}
+    img_o = ref.lstsq_simulate(rs, x64, obs, err).numpy()
+    img = sim.lstsq_simulate(x, obs, err).cpu().numpy()
+    c = sim.lstsq_simulate(x, obs, err, return_coeffs=True)
+    assert "gl_shp_normal_kernel" in sim._model.last_main_kernel()          # the stack-free path did serve the call
+    img_s = sim_stack.lstsq_simulate(x, obs, err).cpu().numpy()
+    c_s = sim_stack.lstsq_simulate(x, obs, err, return_coeffs=True)
+    assert "gl_shp_normal_kernel" not in sim_stack._model.last_main_kernel()
+    top = np.abs(img_o).max()
+    assert np.abs(img - img_o).max() <= 2e-4 * top, np.abs(img - img_o).max() / top
+    assert np.abs(img - img_s).max() <= 2e-4 * top, np.abs(img - img_s).max() / top
+    assert c.shape == c_s.shape == (batch, (n_max + 1) * (n_max + 2) // 2)
+    # the residual chi^2 of the two solutions agrees (single coefficients of a near-degenerate basis need not)
+    w = 1.0 / err
+    chi = lambda im: (((im - obs) * w) ** 2).sum(axis=(1, 2))
+    assert np.allclose(chi(img), chi(img_s), rtol=1e-4)
+    # the stack itself is still served on request, and no_deflection keeps the stack path
+    st = sim.lstsq_simulate(x, obs, err, return_stacked=True)
+    assert st.shape[-1] == c.shape[1]
+    nd = sim.lstsq_simulate(x, obs, err, no_deflection=True).cpu().numpy()
+    nd_o = ref.lstsq_simulate(rs, x64, obs, err, no_deflection=True).numpy()
+    assert np.abs(nd - nd_o).max() <= 2e-4 * np.abs(nd_o).max()
 
 
 @pytest.mark.parametrize("kind", ["sersic", "shapelets"])
