@@ -429,7 +429,7 @@ LstsqWs carve_lstsq(const gl_model* m, int B, void* base, size_t off) {
   auto take = [&](size_t n) { float* q = (float*)(p + off); off += align_up(n * sizeof(float), 256); return q; };
   w.Dp = (D + 1 + 3) & ~3;
   // pixel chunks per sample: ~2048 workgroups in flight, whole LDS tiles per chunk
-  long long want = std::max<long long>(1, (2048 + B - 1) / B);
+  long long want = std::max<long long>(1, (m->lstsq_wgs + B - 1) / B);
   long long per = ((long long)HW + want - 1) / want;
   per = std::max<long long>(2 * LS_TPP, (per + 2 * LS_TPP - 1) / (2 * LS_TPP) * (2 * LS_TPP));
   w.chunk = (int)per;
@@ -641,6 +641,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
 #endif
   m->corr_max_pairs = env_int("GIGALENS_HIP_CORR_MAXPAIRS", 0);  // tests: force the slicing of the PSF launches (read once)
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
+  m->lstsq_wgs = std::max(1, env_int("GIGALENS_HIP_LSTSQ_WGS", 2048));
   m->lstsq_fused = env_int("GIGALENS_HIP_LSTSQ_FUSED", 1) != 0;  // tests: 0 = the linear solve through the basis stack (read once)
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
@@ -1038,12 +1039,12 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
     const int nt = (D + 1 + 15) / 16;
     const size_t red = (size_t)(nt * (nt + 1) / 2 * 256 + 8) * sizeof(float);
     const size_t sh = (size_t)((m->D + 3) & ~3) * sizeof(float) +
-                      std::max((size_t)4 * (shp_exchange_floats(NPS) + SHX_PLANE) * sizeof(float), red);
+                      std::max((size_t)4 * shn_wave_floats(NPS) * sizeof(float), red);
     const dim3 grid(lw.n_chunks, B), block(WG);
 #define GL_SHPN(NT_, I_)                                                                                        \
   do {                                                                                                          \
-    m->last_main_fn = (const void*)&gl_shp_normal_kernel<NT_, 2, L_EplShear, NPS, I_>;                          \
-    hipLaunchKernelGGL((gl_shp_normal_kernel<NT_, 2, L_EplShear, NPS, I_>), grid, block, sh, stream, fa, sn);  \
+    m->last_main_fn = (const void*)&gl_shp_normal_kernel<NT_, 3, L_EplShear, NPS, I_>;                          \
+    hipLaunchKernelGGL((gl_shp_normal_kernel<NT_, 3, L_EplShear, NPS, I_>), grid, block, sh, stream, fa, sn);  \
   } while (0)
     if (nt == 1) { if (interp) GL_SHPN(1, true); else GL_SHPN(1, false); }
     else if (nt == 2) { if (interp) GL_SHPN(2, true); else GL_SHPN(2, false); }

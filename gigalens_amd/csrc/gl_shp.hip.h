@@ -487,12 +487,15 @@ struct ShpNormalArgs {
   int Dl, Dp;         // linear channels (shapelet layers); Dp = Dl + 1 rounded up to a multiple of 4
 };
 
+constexpr int SHN_PLANE = 132;  // floats per plane of the normal kernel: 64 pixels x 2 orders, + 4 (plane stride = 4 mod 32 banks)
+__host__ __device__ constexpr int shn_wave_floats(int np) { return (2 * np + 1) * SHN_PLANE; }  // X', Y planes + the (obs w, 1) plane
+
 template <int NT, int WAVES, class LK, int NP, bool INTERP>
 __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, ShpNormalArgs na) {
   using V = v2f;
   constexpr int NL = LK::n;
   constexpr int NTILES = NT * (NT + 1) / 2;
-  constexpr int XPL = shp_exchange_floats(NP) + SHX_PLANE;  // + one plane of (obs w, 1) pairs per pixel (per wave)
+  constexpr int XPL = shn_wave_floats(NP);
   extern __shared__ float smem[];
   float* s_d = smem;
   float* s_x = smem + ((a.D + 3) & ~3);
@@ -502,7 +505,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
   const float* __restrict__ gder = a.derived + (size_t)b * a.D;
   for (int i = tid; i < a.D; i += WG) s_d[i] = gder[i];
   float* xw = s_x + wave * XPL;
-  float* pl_ow = xw + shp_exchange_floats(NP);  // [pixel][2] = (obs w, 1): the observation column's two "factors"
+  float* pl_ow = xw + 2 * NP * SHN_PLANE;  // [pixel][2] = (obs w, 1): the observation column's two "factors"
   __syncthreads();
   const float* dL[NL > 0 ? NL : 1];
 #pragma unroll
@@ -510,7 +513,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
   const CompDesc shp = comps[NL];
   const float* dS = s_d + shp.d_off;
   float* wr_x = xw + 2 * lane;
-  float* wr_y = xw + NP * SHX_PLANE + 2 * lane;
+  float* wr_y = xw + NP * SHN_PLANE + 2 * lane;
   // the lane's channel of every tile row -- two factor addresses in the planes ([pixel][2] pairs, 8 floats per pixel group):
   // amplitude (n1, n2): X'[n1] and Y[n2]; the observation column: (obs w, 1); padding: order 2 NP - 1 of X and Y, which is
   // zero for every n_max this kernel serves (<= 2 NP - 2)
@@ -527,17 +530,19 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
       n2 = ch - n * (n + 1) / 2;
       n1 = n - n2;
     }
-    rd_a[t] = xw + (n1 >> 1) * SHX_PLANE + (n1 & 1) + 2 * k;
-    rd_b[t] = xw + NP * SHX_PLANE + (n2 >> 1) * SHX_PLANE + (n2 & 1) + 2 * k;
+    rd_a[t] = xw + (n1 >> 1) * SHN_PLANE + (n1 & 1) + 2 * k;
+    rd_b[t] = xw + NP * SHN_PLANE + (n2 >> 1) * SHN_PLANE + (n2 & 1) + 2 * k;
     if (ch == na.Dl) { rd_a[t] = pl_ow + 2 * k; rd_b[t] = pl_ow + 1 + 2 * k; }
   }
   v4f acc[NTILES];
 #pragma unroll
   for (int q = 0; q < NTILES; ++q) acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
-  V yy = V(0.f);  // sum of (obs w)^2 over the tiles that skip the MFMAs
+  float yy = 0.f;  // sum of (obs w)^2 over the runs that skip the MFMAs
   const int p0 = chunk * a.chunk;
   const int p1 = min(p0 + a.chunk, a.N);
   for (int base = p0; base < p1; base += WG * 2) {
+    // the lens on two pixels per lane (packed fp32 like the other kernels); the bases and the MFMA pass then take the wave's two
+    // 64-pixel runs one after the other, so that the planes of a wave are 64 pixels deep (27 KB / workgroup: three per CU)
     unsigned jj[2];
     bool valid[2];
 #pragma unroll
@@ -563,62 +568,60 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
       else if constexpr (kind == K_SHEAR) shear_fwd_v<V>(dL[i], x, y, bx, by);
       else sis_fwd_v<V>(dL[i], x, y, bx, by);
     }, std::make_integer_sequence<int, NL>{});
-    ShpPix<NP> ps0, ps1;
-    shp_pixel_coords<NP>(dS, bx.x, by.x, ps0);
-    shp_pixel_coords<NP>(dS, bx.y, by.y, ps1);
-    bool live = true;
-    if constexpr (INTERP) {
-      const bool inr = (shp_in_table(ps0.u) && shp_in_table(ps0.v)) || (shp_in_table(ps1.u) && shp_in_table(ps1.v));
-      live = __builtin_amdgcn_ballot_w64(inr) != 0;
-    }
-    if (!live) {  // every basis image vanishes on these pixels: only Y^T Y grows
-      yy += ow * ow;
-      continue;
-    }
-    auto bases = [&](ShpPix<NP>& ps, float w1, float* xb, float* yb) {
-      ShpRows<NP> r;
-      shp_pixel_gather<NP, INTERP>(a.shp_tab2, ps, r);
-      float fac = 1.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float w1 = h ? wgt.y : wgt.x, ow1 = h ? ow.y : ow.x;
+      ShpPix<NP> ps;
+      shp_pixel_coords<NP>(dS, h ? bx.y : bx.x, h ? by.y : by.x, ps);
       if constexpr (INTERP) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) r.xv[j] = __builtin_elementwise_fma(v2f(r.tu), r.xd[j], r.xv[j]);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) r.yv[j] = __builtin_elementwise_fma(v2f(r.tv), r.yd[j], r.yv[j]);
-      } else {
-        const int n_max = (int)dS[SHP_NMAX];
-        shp_hermite<NP>(ps.u, n_max, r.xv, r.xd);
-        shp_hermite<NP>(ps.v, n_max, r.yv, r.yd);
-        fac = exp_(-(ps.u * ps.u + ps.v * ps.v) * 0.5f);
+        const bool inr = shp_in_table(ps.u) && shp_in_table(ps.v);
+        if (__builtin_amdgcn_ballot_w64(inr) == 0) {  // every basis image vanishes on these 64 pixels: only Y^T Y grows
+          yy = __builtin_fmaf(ow1, ow1, yy);
+          continue;
+        }
       }
-      const float xs = w1 * fac;  // weight (and the Gaussian of direct mode) folded into the X factor
+      {
+        ShpRows<NP> r;
+        shp_pixel_gather<NP, INTERP>(a.shp_tab2, ps, r);
+        float fac = 1.f;
+        if constexpr (INTERP) {
 #pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        v2f xv = r.xv[j] * xs;
-        xv = V{xv.x == xv.x ? xv.x : 0.f, xv.y == xv.y ? xv.y : 0.f};  // NaN -> 0 like the stack (tf/simulator.py:140 on each basis image)
-        *reinterpret_cast<v2f*>(xb + j * SHX_PLANE) = xv;
-        *reinterpret_cast<v2f*>(yb + j * SHX_PLANE) = r.yv[j];
+          for (int j = 0; j < NP; ++j) r.xv[j] = __builtin_elementwise_fma(v2f(r.tu), r.xd[j], r.xv[j]);
+#pragma unroll
+          for (int j = 0; j < NP; ++j) r.yv[j] = __builtin_elementwise_fma(v2f(r.tv), r.yd[j], r.yv[j]);
+        } else {
+          const int n_max = (int)dS[SHP_NMAX];
+          shp_hermite<NP>(ps.u, n_max, r.xv, r.xd);
+          shp_hermite<NP>(ps.v, n_max, r.yv, r.yd);
+          fac = exp_(-(ps.u * ps.u + ps.v * ps.v) * 0.5f);
+        }
+        const float xs = w1 * fac;  // weight (and the Gaussian of direct mode) folded into the X factor
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          v2f xv = r.xv[j] * xs;
+          xv = V{xv.x == xv.x ? xv.x : 0.f, xv.y == xv.y ? xv.y : 0.f};  // NaN -> 0 like the stack (tf/simulator.py:140 on each basis image)
+          *reinterpret_cast<v2f*>(wr_x + j * SHN_PLANE) = xv;
+          *reinterpret_cast<v2f*>(wr_y + j * SHN_PLANE) = r.yv[j];
+        }
+        *reinterpret_cast<v2f*>(pl_ow + 2 * lane) = v2f{ow1, 1.f};
       }
-    };
-    bases(ps0, wgt.x, wr_x, wr_y);
-    bases(ps1, wgt.y, wr_x + 128, wr_y + 128);
-    *reinterpret_cast<v2f*>(pl_ow + 2 * lane) = v2f{ow.x, 1.f};
-    *reinterpret_cast<v2f*>(pl_ow + 128 + 2 * lane) = v2f{ow.y, 1.f};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 2
-    for (int kb = 0; kb < 32; ++kb) {
-      float v[NT];
+      for (int kb = 0; kb < 16; ++kb) {
+        float v[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) v[t] = rd_a[t][8 * kb] * rd_b[t][8 * kb];
-      int q = 0;
+        for (int t = 0; t < NT; ++t) v[t] = rd_a[t][8 * kb] * rd_b[t][8 * kb];
+        int q = 0;
 #pragma unroll
-      for (int ti = 0; ti < NT; ++ti)
+        for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-        for (int tj = 0; tj <= ti; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[ti], v[tj], acc[q], 0, 0, 0);
+          for (int tj = 0; tj <= ti; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[ti], v[tj], acc[q], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
   // ---- the four waves' tiles summed in fixed order through LDS (aliases the planes), then the lower tiles written ----
   __syncthreads();
@@ -637,7 +640,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
   }
   float* s_yy = s_red + NTILES * 256;
   {
-    const float t = wave_sum63(yy.x + yy.y);
+    const float t = wave_sum63(yy);
     if (lane == 63) s_yy[wave] = t;
   }
   __syncthreads();
