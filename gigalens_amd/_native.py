@@ -83,6 +83,7 @@ SYMBOLS = {
     "gl_model_num_linear": (c_int, [c_void_p]),
     "gl_model_linear_column": (c_int, [c_void_p, c_int]),
     "gl_lstsq_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "gl_lstsq_solve_flags": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t)]),
     "gl_lstsq_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_uint32, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p]),
     "gl_model_set_catalogue": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int32), POINTER(c_float)]),
@@ -464,6 +465,13 @@ class Model:
         _check(lib().gl_lstsq_fwd(self._h, _ptr(params), _ptr(obs), _ptr(err), B, int(parts), _ptr(coeffs),
                                   _ptr(stacked), _ptr(image), _ptr(ws), ws.numel(), _stream()))
         return ({"coeffs": coeffs, "stacked": stacked, "image": image}[want],)
+
+    def lstsq_solve_flags(self, B):
+        """Per-sample flags of the most recent linear solve on ``B`` samples: 0 = solved by the Cholesky attempt, 1 = by the
+        eigenvalue solve (a view into the workspace; measurement aid, ``gl_lstsq_solve_flags``)."""
+        off = c_size_t()
+        _check(lib().gl_lstsq_solve_flags(self._h, B, ctypes.byref(off)))
+        return self._lstsq_ws[off.value:off.value + 4 * B].view(torch.int32)
 
     def set_series(self, component, r0, coeffs):
         """Attach the coefficient field of a GL_SERIES lens (gl_model_set_series)."""

@@ -418,6 +418,7 @@ namespace {
 struct LstsqWs {
   float *stack_ss, *stack, *partial, *coeffs;
   float* mats;  // [B][2][D][D | 1]: A and V of the eigen solve for systems above LS_LDS_MAXN unknowns (else null)
+  int* todo;    // [B]: 1 = the Cholesky attempt left this system to the eigenvalue solve
   int chunk, n_chunks, Dp;
   size_t bytes;
 };
@@ -439,6 +440,7 @@ LstsqWs carve_lstsq(const gl_model* m, int B, void* base, size_t off) {
   w.partial = take((size_t)B * w.n_chunks * w.Dp * w.Dp);
   w.coeffs = take((size_t)B * D);
   w.mats = D > LS_LDS_MAXN ? take((size_t)B * 2 * D * (D | 1)) : nullptr;
+  w.todo = (int*)take((size_t)B);
   w.bytes = off;
   return w;
 }
@@ -642,6 +644,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   m->corr_max_pairs = env_int("GIGALENS_HIP_CORR_MAXPAIRS", 0);  // tests: force the slicing of the PSF launches (read once)
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
   m->lstsq_wgs = std::max(1, env_int("GIGALENS_HIP_LSTSQ_WGS", 2048));
+  m->lstsq_chol = env_int("GIGALENS_HIP_LSTSQ_CHOL", 1) != 0;    // tests: 0 = every system through the eigenvalue solve
   m->lstsq_fused = env_int("GIGALENS_HIP_LSTSQ_FUSED", 1) != 0;  // tests: 0 = the linear solve through the basis stack (read once)
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   if (shmem > 64 * 1024) { delete m; return fail(GL_EUNSUPPORTED, "model needs %zu B of LDS per workgroup (> 64 KiB)", shmem); }
@@ -991,6 +994,15 @@ size_t gl_lstsq_workspace_bytes(const gl_model* m, int B) {
   return carve_lstsq(m, B, nullptr, align_up(carve(m, B, nullptr).bytes, 256)).bytes;
 }
 
+int gl_lstsq_solve_flags(const gl_model* m, int B, size_t* offset_bytes) {
+  if (!m || B <= 0 || !offset_bytes) return fail(GL_EINVAL, "bad argument");
+  if ((int)m->lin_cols.size() > LS_LDS_MAXN || !m->lstsq_chol)
+    return fail(GL_EUNSUPPORTED, "no Cholesky attempt for this model: every system goes through the eigenvalue solve");
+  const LstsqWs lw = carve_lstsq(m, B, nullptr, align_up(carve(m, B, nullptr).bytes, 256));
+  *offset_bytes = (size_t)((const char*)lw.todo - (const char*)nullptr);
+  return GL_OK;
+}
+
 int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const float* err, int B, unsigned parts,
                  float* coeffs_or_null, float* stacked_or_null, float* image_or_null, void* workspace,
                  size_t workspace_bytes, void* hip_stream) {
@@ -1109,6 +1121,21 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
     GL_HIP(hipGetLastError());
     n_sum = 1;
   }
+  const int* todo = nullptr;
+  if (D <= LS_LDS_MAXN && m->lstsq_chol) {  // the inverse when the pseudo-inverse's cut is provably idle (gl_chol_solve_kernel)
+    const size_t sm = sizeof(float) * ((size_t)(2 * D + 1) * ((D + 1) | 1) + 8);
+    if (sm > 64 * 1024) {
+      static bool raised = false;
+      if (!raised) {
+        GL_HIP(hipFuncSetAttribute((const void*)&gl_chol_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+      }
+    }
+    hipLaunchKernelGGL(gl_chol_solve_kernel, dim3(B), dim3(256), sm, stream, lw.partial, lw.n_chunks, n_sum, D, lw.Dp, 1e-6f, coeffs,
+                       lw.todo);
+    GL_HIP(hipGetLastError());
+    todo = lw.todo;
+  }
   if (D <= LS_LDS_MAXN) {  // A and V in LDS: up to 129 KB of the CU's 160 (above 64 KB the kernel has to be told once)
     const size_t sm = sizeof(float) * ((size_t)2 * D * (D | 1) + 8 * D + 8);
     if (sm > 64 * 1024) {
@@ -1119,11 +1146,11 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
       }
     }
     hipLaunchKernelGGL((gl_eigh_solve_kernel<2, false>), dim3(B), dim3(64), sm, stream, lw.partial, lw.n_chunks, n_sum, D, lw.Dp,
-                       1e-6f, coeffs, (float*)nullptr);
+                       1e-6f, coeffs, (float*)nullptr, todo);
   } else {  // the two matrices in the workspace (L2), the vectors in LDS; four registers hold the tridiagonal
     const size_t sm = sizeof(float) * ((size_t)8 * D + 8);
     hipLaunchKernelGGL((gl_eigh_solve_kernel<4, true>), dim3(B), dim3(64), sm, stream, lw.partial, lw.n_chunks, n_sum, D, lw.Dp,
-                       1e-6f, coeffs, lw.mats);
+                       1e-6f, coeffs, lw.mats, todo);
   }
   GL_HIP(hipGetLastError());
   if (image_or_null && fused) {

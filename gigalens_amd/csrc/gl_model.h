@@ -96,6 +96,7 @@ struct gl_model {
   bool use_order = true;
   bool wave_prep = true;  // EPL models: one wavefront per sample in the front end (GIGALENS_HIP_WAVE_PREP=0: thread per component)
   int lstsq_wgs = 2048;     // workgroups the normal-matrix kernels of the linear solve aim for (pixel chunks per sample = this / B)
+  bool lstsq_chol = true;   // linear solve: Cholesky attempt first (gl_chol_solve_kernel), eigenvalue solve for what it leaves
   bool lstsq_fused = true;  // one-shapelet-source linear solves form the normal matrix from the bases (gl_shp_normal_kernel), no stack
   // measurement hooks (gl_model_set_timing): a ring of event pairs around the main-kernel launches, and the host
   // function of the most recent main launch (gl_model_last_main_kernel)

@@ -224,6 +224,10 @@ size_t gl_lstsq_workspace_bytes(const gl_model* m, int B);
 int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const float* err, int B, unsigned parts,
                  float* coeffs_or_null, float* stacked_or_null, float* image_or_null, void* workspace,
                  size_t workspace_bytes, void* hip_stream);
+/* Measurement aid: where, inside a workspace of gl_lstsq_workspace_bytes(m, B), the per-sample int32 flags of the most recent
+ * solve live: 0 = the Cholesky attempt proved tf.linalg.pinv's rcond cut idle and solved the system (csrc/gl_lstsq.hip.h
+ * gl_chol_solve_kernel), 1 = left to the eigenvalue solve.  GL_EUNSUPPORTED for systems the attempt does not serve (> 127). */
+int gl_lstsq_solve_flags(const gl_model* m, int B, size_t* offset_bytes);
 
 /* Galaxy catalogue of a GL_SCALED component (ScalingRelation.__init__, scaling_relation.py:27-55).  Must be attached
  * to every GL_SCALED component before gl_workspace_bytes / any compute call (the workspace holds one block of

@@ -324,3 +324,46 @@ def test_duplicate_components_take_the_pseudo_inverse_path(gl, n_max):
     # minimum-norm solution: the duplicates share their amplitude (cut directions carry nothing)
     a, b2 = c[..., 1:1 + L], c[..., 1 + L:]
     assert np.abs(a - b2).max() <= 2e-2 * np.abs(a).max()
+    # the Cholesky attempt (gl_chol_solve_kernel) must have refused every one of these systems
+    assert sim._model.lstsq_solve_flags(3).cpu().tolist() == [1, 1, 1]
+
+
+@pytest.mark.parametrize("kind,num_pix,batch", [("sersic", 32, 5), ("shapelets", 36, 4), ("shapelets7", 40, 3), ("shapelets10", 48, 2),
+                                                ("shapelets14", 44, 2)])
+def test_cholesky_attempt_agrees_with_the_eigenvalue_solve(gl, monkeypatch, kind, num_pix, batch):
+    """pinv(A, rcond) is inverse(A) when no eigenvalue lies under the cut (tf/simulator.py:238).  gl_chol_solve_kernel proves
+    that by factorising A - mu I and solves by LDL^T; what it cannot prove goes to the eigenvalue solve.  On well-conditioned
+    systems the two paths give the same coefficients (float32 rounding apart) and the oracle's."""
+    from oracle import ref_torch as ref
+    wl = _model(kind, num_pix, batch)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=batch)
+    monkeypatch.setenv("GIGALENS_HIP_LSTSQ_CHOL", "0")   # read once per model
+    sim_e = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=batch)
+    monkeypatch.delenv("GIGALENS_HIP_LSTSQ_CHOL")
+    x = wl.prior.sample(batch, seed=9)
+    obs, err = _observation(wl)
+    c = sim.lstsq_simulate(x, obs, err, return_coeffs=True).cpu().numpy()
+    flags = sim._model.lstsq_solve_flags(batch).cpu().numpy()
+    c_e = sim_e.lstsq_simulate(x, obs, err, return_coeffs=True).cpu().numpy()
+    from gigalens_amd import _native
+    with pytest.raises(_native.NativeLibraryError, match="eigenvalue solve"):
+        sim_e._model.lstsq_solve_flags(batch)
+    rs = ref.RefSimulator(wl.phys_model, wl.sim_config, batch, dtype=F64)
+    x64 = {g: [{k: v.double() for k, v in d.items()} for d in lst] for g, lst in x.items()}
+    st = ref.lstsq_simulate(rs, x64, obs, err, return_stacked=True).numpy()
+    X = (st / err[None, :, :, None]).reshape(batch, -1, st.shape[-1])
+    ev = np.linalg.eigvalsh(np.swapaxes(X, 1, 2) @ X)
+    cond = ev[:, -1] / np.maximum(ev[:, 0], 1e-300)
+    c_o = ref.lstsq_simulate(rs, x64, obs, err, return_coeffs=True).numpy()
+    easy = cond < 1e3
+    assert (flags[easy] == 0).all(), (flags, cond)        # far from the cut: the attempt must succeed
+    assert (flags[cond > 1e6] == 1).all(), (flags, cond)  # eigenvalues under the cut: it must not
+    for b in range(batch):
+        tol = 20 * 1.2e-7 * cond[b] + 1e-5  # float32 solves of a system with this condition number
+        scale = np.abs(c_o[b]).max()
+        if flags[b] == 0:
+            assert np.abs(c[b] - c_o[b]).max() <= tol * scale, (b, cond[b], np.abs(c[b] - c_o[b]).max() / scale)
+            assert np.abs(c[b] - c_e[b]).max() <= 2 * tol * scale
+    img = sim.lstsq_simulate(x, obs, err).cpu().numpy()
+    img_e = sim_e.lstsq_simulate(x, obs, err).cpu().numpy()
+    assert np.abs(img - img_e).max() <= 1e-4 * np.abs(img_e).max()
