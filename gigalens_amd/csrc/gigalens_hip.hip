@@ -420,6 +420,7 @@ struct LstsqWs {
   float* mats;  // [B][2][D][D | 1]: A and V of the eigen solve for systems above LS_LDS_MAXN unknowns (else null)
   int* todo;    // [B]: 1 = the Cholesky attempt left this system to the eigenvalue solve
   int chunk, n_chunks, Dp;
+  int n_chunks_f;  // workgroups per sample of the stack-free kernel (gl_shp_normal_kernel: 512-pixel tiles dealt round-robin)
   size_t bytes;
 };
 LstsqWs carve_lstsq(const gl_model* m, int B, void* base, size_t off) {
@@ -437,7 +438,10 @@ LstsqWs carve_lstsq(const gl_model* m, int B, void* base, size_t off) {
   w.n_chunks = (int)(((long long)HW + per - 1) / per);
   w.stack_ss = m->has_post ? take((size_t)B * D * HWs) : nullptr;
   w.stack = take((size_t)B * D * HW);
-  w.partial = take((size_t)B * w.n_chunks * w.Dp * w.Dp);
+  // three workgroups per CU there: 1.5 x the workgroup target = four full rounds of the chip at the default (measured: 2048 ->
+  // 0.708, 3072 -> 0.694, 4096 -> 0.697, 6144 -> 0.715 ms per C3L solve)
+  w.n_chunks_f = (int)std::min<long long>(((long long)HW + 511) / 512, std::max<long long>(1, (3LL * m->lstsq_wgs / 2 + B - 1) / B));
+  w.partial = take((size_t)B * std::max(w.n_chunks, w.n_chunks_f) * w.Dp * w.Dp);
   w.coeffs = take((size_t)B * D);
   w.mats = D > LS_LDS_MAXN ? take((size_t)B * 2 * D * (D | 1)) : nullptr;
   w.todo = (int*)take((size_t)B);
@@ -1043,11 +1047,11 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
                      (a.parts & (GL_PART_DEFLECT | GL_PART_SOURCE_LIGHT)) == (GL_PART_DEFLECT | GL_PART_SOURCE_LIGHT) &&
                      m->lstsq_fused;
   if (fused) {
+    lw.n_chunks = lw.n_chunks_f;
     const bool interp = (m->comps.back().flags & GL_FLAG_SHAPELETS_INTERPOLATE) != 0;
     constexpr int NPS = SH_SQ / 2;
     ShpNormalArgs sn{obs, err, lw.partial, D, lw.Dp};
     MainArgs fa = a;
-    fa.chunk = lw.chunk;
     const int nt = (D + 1 + 15) / 16;
     const size_t red = (size_t)(nt * (nt + 1) / 2 * 256 + 8) * sizeof(float);
     const size_t sh = (size_t)((m->D + 3) & ~3) * sizeof(float) +
@@ -1055,8 +1059,8 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
     const dim3 grid(lw.n_chunks, B), block(WG);
 #define GL_SHPN(NT_, I_)                                                                                        \
   do {                                                                                                          \
-    m->last_main_fn = (const void*)&gl_shp_normal_kernel<NT_, 3, L_EplShear, NPS, I_>;                          \
-    hipLaunchKernelGGL((gl_shp_normal_kernel<NT_, 3, L_EplShear, NPS, I_>), grid, block, sh, stream, fa, sn);  \
+    m->last_main_fn = (const void*)&gl_shp_normal_kernel<NT_, (I_ ? 4 : 3), L_EplShear, NPS, I_>;                          \
+    hipLaunchKernelGGL((gl_shp_normal_kernel<NT_, (I_ ? 4 : 3), L_EplShear, NPS, I_>), grid, block, sh, stream, fa, sn);  \
   } while (0)
     if (nt == 1) { if (interp) GL_SHPN(1, true); else GL_SHPN(1, false); }
     else if (nt == 2) { if (interp) GL_SHPN(2, true); else GL_SHPN(2, false); }
@@ -1123,16 +1127,19 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
   }
   const int* todo = nullptr;
   if (D <= LS_LDS_MAXN && m->lstsq_chol) {  // the inverse when the pseudo-inverse's cut is provably idle (gl_chol_solve_kernel)
-    const size_t sm = sizeof(float) * ((size_t)(2 * D + 1) * ((D + 1) | 1) + 8);
+    const int nb = D + 1 <= 64 ? 4 : D + 1 <= 80 ? 5 : 8;
+    const size_t sm = sizeof(float) * ((size_t)(D + 2) * (16 * nb + 1) + 4);
     if (sm > 64 * 1024) {
       static bool raised = false;
       if (!raised) {
-        GL_HIP(hipFuncSetAttribute((const void*)&gl_chol_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GL_HIP(hipFuncSetAttribute((const void*)&gl_chol_solve_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
       }
     }
-    hipLaunchKernelGGL(gl_chol_solve_kernel, dim3(B), dim3(256), sm, stream, lw.partial, lw.n_chunks, n_sum, D, lw.Dp, 1e-6f, coeffs,
-                       lw.todo);
+#define GL_CHOL(NB_) hipLaunchKernelGGL((gl_chol_solve_kernel<NB_>), dim3(B), dim3(256), sm, stream, lw.partial, lw.n_chunks, n_sum, D, \
+                                        lw.Dp, 1e-6f, coeffs, lw.todo)
+    if (nb == 4) GL_CHOL(4); else if (nb == 5) GL_CHOL(5); else GL_CHOL(8);
+#undef GL_CHOL
     GL_HIP(hipGetLastError());
     todo = lw.todo;
   }

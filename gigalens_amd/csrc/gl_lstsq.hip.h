@@ -461,88 +461,115 @@ __global__ void __launch_bounds__(64) gl_eigh_solve_kernel(const float* __restri
 // ---- per sample, first attempt: pinv(A) = inverse(A) when no eigenvalue lies under the cutoff ------------------------------
 // tf.linalg.pinv(A, rcond) drops the eigenvalues <= rcond * lambda_max of the symmetric normal matrix (tf/simulator.py:238).  By
 // Sylvester's law of inertia, A - mu I has a Cholesky factorisation (all pivots positive) exactly when every eigenvalue of A
-// exceeds mu; with mu = 4 rcond * min(trace A, max row sum) >= 4 rcond * lambda_max that proves the cut idle, and the
-// pseudo-inverse is the inverse.  The workgroup factorises A - mu I (the proof) and the augmented [A | b] (the solve, root-free
-// LDL^T: the row of b becomes L^-1 b on the way) side by side in LDS, one barrier per column, then one wave substitutes back.
-// The normal matrices of real fits are far on the safe side (C3L: condition numbers 2..24, tools/dev/lstsq_condition_probe.py);
-// systems that fail the proof -- duplicated components, empty bases, non-finite input -- set todo[b] and go to
-// gl_eigh_solve_kernel, which decides the cut on converged eigenvalues.
+// exceeds mu; with mu = 4 rcond ||A||_F >= 4 rcond * lambda_max that proves the cut idle, and the pseudo-inverse is the
+// inverse.  The workgroup factorises A - mu I (the proof) and the augmented [A | b] (the solve, root-free LDL^T: the row of b
+// becomes L^-1 b on the way) side by side.  256 threads own the lower triangles 16-cyclically in REGISTERS (thread (r, c): rows
+// r + 16 ii, columns c + 16 kk); per column j its owners publish the column through LDS -- for [A | b] into the column's own
+// slot, which leaves the whole factor in LDS for the back substitution (one wave) -- one barrier, and every thread updates its
+// elements.  (First version: both triangles in LDS, read-modify-write per element: 119 us for 1024 systems of 66 unknowns, all
+// of it LDS latency; this one 64 us.)  The normal matrices of real fits are far on the safe side (C3L: condition numbers
+// 2..24, tools/dev/lstsq_condition_probe.py); systems that fail the proof -- duplicated components, empty bases, non-finite
+// input -- set todo[b] and go to gl_eigh_solve_kernel, which decides the cut on converged eigenvalues.
+template <int NB>  // 16 NB >= n + 1
 __global__ void __launch_bounds__(256) gl_chol_solve_kernel(const float* __restrict__ partial, int n_chunks, int n_sum, int D,
                                                             int Dp, float rcond, float* __restrict__ coeffs,
                                                             int* __restrict__ todo) {
   extern __shared__ float sm[];
-  const int n = D, ld = (n + 1) | 1;
-  float* A1 = sm;                  // [n + 1][ld] lower triangle; row n = X^T Y
-  float* A2 = A1 + (n + 1) * ld;   // [n][ld] lower triangle of A - mu I
-  float* red = A2 + n * ld;        // [8]
+  constexpr int ld = 16 * NB + 1;
+  const int n = D;
+  float* Lc = sm;            // [n][ld]: slot j = column j of the factor, T[i][j] at Lc[j * ld + i] for j <= i <= n (row n: L^-1 b)
+  float* c2 = Lc + n * ld;   // [2][ld]: column j of the proof matrix, double-buffered on the parity of j
+  float* red = c2 + 2 * ld;  // [4]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tr = tid >> 4, tc = tid & 15;
   const float* src = partial + (size_t)b * n_chunks * Dp * Dp;
-  float tr = 0.f;
-  for (int i = wave; i <= n; i += 4)
-    for (int j = lane; j <= i && j < n; j += 64) {
-      float s = 0.f;
-      for (int ch = 0; ch < n_sum; ++ch) s += src[(size_t)ch * Dp * Dp + i * Dp + j];
-      A1[i * ld + j] = s;
-      if (i == j) tr += s;
-    }
-  tr = wave_sum63(tr);
-  if (lane == 63) red[wave] = tr;
-  __syncthreads();
-  // max absolute row sum of the symmetric matrix from its lower triangle
-  float rs = 0.f;
-  for (int i = tid; i < n; i += 256) {
-    float s = 0.f;
-    for (int j = 0; j < n; ++j) s += fabsf(j <= i ? A1[i * ld + j] : A1[j * ld + i]);
-    rs = fmaxf(rs, s);
-  }
+  float T1[NB][NB], T2[NB][NB];
+  float fro = 0.f;
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) rs = fmaxf(rs, __shfl_xor(rs, o, 64));
-  if (lane == 0) red[4 + wave] = rs;
+  for (int ii = 0; ii < NB; ++ii)
+#pragma unroll
+    for (int kk = 0; kk <= ii; ++kk) {
+      const int i = 16 * ii + tr, k = 16 * kk + tc;
+      float v = 0.f;
+      if (k <= i && k < n && i <= n)
+        for (int ch = 0; ch < n_sum; ++ch) v += src[(size_t)ch * Dp * Dp + i * Dp + k];
+      T1[ii][kk] = v;
+      if (i < n) fro = __builtin_fmaf(i == k ? v : 2.f * v, v, fro);
+    }
+  fro = wave_sum63(fro);
+  if (lane == 63) red[wave] = fro;
   __syncthreads();
-  const float trace = (red[0] + red[1]) + (red[2] + red[3]);
-  const float rowsum = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-  const float mu = 4.0f * rcond * fminf(trace, rowsum);
+  const float mu = 4.0f * rcond * sqrtf((red[0] + red[1]) + (red[2] + red[3]));
   bool ok = mu > 0.f && mu < 3.0e38f;  // an empty or non-finite system is the eigenvalue path's business
-  for (int i = wave; i < n; i += 4)
-    for (int j = lane; j <= i; j += 64) A2[i * ld + j] = A1[i * ld + j] - (i == j ? mu : 0.f);
-  const int tr_ = tid >> 4, tc = tid & 15;
-  for (int j = 0; j < n && ok; ++j) {
-    __syncthreads();
-    const float p1 = A1[j * ld + j], p2 = A2[j * ld + j];
-    ok = p1 > 0.f && p2 > 0.f;  // uniform: every thread reads the same two pivots
-    if (!ok) break;
-    const float ip1 = 1.0f / p1, ip2 = 1.0f / p2;
-    // trailing update with the UNSCALED column j (root-free): T[i][k] -= T[i][j] T[k][j] / T[j][j],  j < k <= i
-    for (int i = j + 1 + tr_; i <= n; i += 16) {
-      const float a1 = A1[i * ld + j] * ip1;
-      const float a2 = i < n ? A2[i * ld + j] * ip2 : 0.f;
-      for (int k = j + 1 + tc; k <= i && k < n; k += 16) {
-        A1[i * ld + k] = __builtin_fmaf(-a1, A1[k * ld + j], A1[i * ld + k]);
-        if (i < n) A2[i * ld + k] = __builtin_fmaf(-a2, A2[k * ld + j], A2[i * ld + k]);
+#pragma unroll
+  for (int ii = 0; ii < NB; ++ii)
+#pragma unroll
+    for (int kk = 0; kk <= ii; ++kk) T2[ii][kk] = T1[ii][kk] - ((ii == kk && tr == tc) ? mu : 0.f);
+#pragma unroll
+  for (int jb = 0; jb < NB; ++jb) {
+    for (int jj = 0; jj < 16 && ok; ++jj) {
+      const int j = 16 * jb + jj;
+      if (j >= n) break;
+      float* cj1 = Lc + j * ld;
+      float* cj2 = c2 + (j & 1) * ld;
+      if (tc == jj) {
+#pragma unroll
+        for (int ii = jb; ii < NB; ++ii) {
+          const int i = 16 * ii + tr;
+          if (i >= j && i <= n) { cj1[i] = T1[ii][jb]; cj2[i] = T2[ii][jb]; }
+        }
       }
+      __syncthreads();
+      const float p1 = cj1[j], p2 = cj2[j];
+      ok = p1 > 0.f && p2 > 0.f;  // uniform: every thread reads the same two pivots
+      if (!ok) break;
+      const float ip1 = 1.0f / p1, ip2 = 1.0f / p2;
+      // root-free trailing update with the unscaled column: T[i][k] -= T[i][j] T[k][j] / T[j][j],  j < k <= i.  No guards: a
+      // register outside that range (columns already published, the upper halves of the diagonal blocks, rows and columns past
+      // the matrix) takes a meaningless update from stale LDS, and is never published or read afterwards.
+      float ck1[NB], ck2[NB], ri1[NB], ri2[NB];
+#pragma unroll
+      for (int q = jb; q < NB; ++q) {
+        ck1[q] = cj1[16 * q + tc];
+        ck2[q] = cj2[16 * q + tc];
+        ri1[q] = cj1[16 * q + tr] * ip1;
+        ri2[q] = cj2[16 * q + tr] * ip2;
+      }
+#pragma unroll
+      for (int ii = jb; ii < NB; ++ii)
+#pragma unroll
+        for (int kk = jb; kk <= ii; ++kk) {
+          T1[ii][kk] = __builtin_fmaf(-ri1[ii], ck1[kk], T1[ii][kk]);
+          T2[ii][kk] = __builtin_fmaf(-ri2[ii], ck2[kk], T2[ii][kk]);
+        }
     }
   }
   __syncthreads();
   if (tid == 0) todo[b] = ok ? 0 : 1;
   if (!ok || wave != 0) return;
-  // A = L D L^T with D = the pivots and L[k][i] = A1[k][i] / D_i; row n holds L^-1 b.  x_i = (row_n[i] - sum_{k>i} A1[k][i] x_k) / D_i
-  constexpr int R = (LS_LDS_MAXN + 63) / 64;
-  float acc[R];
+  // A = L D L^T with D = the pivots and L[m][i] = T[m][i] / D_i; row n holds w = L^-1 b.  x_i = (w_i - sum_{m>i} T[m][i] x_m) / D_i
+  constexpr int R = (16 * NB - 1 + 63) / 64;
+  float acc[R], w[R], idv[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const int i = lane + 64 * r < n ? lane + 64 * r : 0;
+    acc[r] = 0.f;
+    w[r] = Lc[i * ld + n];
+    idv[r] = 1.0f / Lc[i * ld + i];
+  }
   for (int k = n - 1; k >= 0; --k) {
     float xk = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if ((k >> 6) == r) {
-        const float mine = (A1[n * ld + (lane + 64 * r < n ? lane + 64 * r : 0)] - acc[r]) / A1[k * ld + k];
+        const float mine = (w[r] - acc[r]) * idv[r];
         xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), k & 63));
       }
     if (lane == 0) coeffs[(size_t)b * D + k] = xk;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = lane + 64 * r;
-      if (i < k) acc[r] = __builtin_fmaf(A1[k * ld + i], xk, acc[r]);
+      if (i < k) acc[r] = __builtin_fmaf(Lc[i * ld + k], xk, acc[r]);
     }
   }
 }

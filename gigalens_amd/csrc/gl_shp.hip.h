@@ -538,16 +538,21 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
 #pragma unroll
   for (int q = 0; q < NTILES; ++q) acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
   float yy = 0.f;  // sum of (obs w)^2 over the runs that skip the MFMAs
-  const int p0 = chunk * a.chunk;
-  const int p1 = min(p0 + a.chunk, a.N);
-  for (int base = p0; base < p1; base += WG * 2) {
+  // 512-pixel tiles dealt round-robin to the sample's workgroups: the shapelet support is a compact region of the image, and
+  // contiguous chunks would leave some workgroups all MFMA passes and others none
+  // Inside a tile the four waves swap 64-pixel runs from trip to trip: with a fixed assignment waves 0, 2 would see left halves
+  // of 128-pixel rows only and waves 1, 3 right halves, and a lensed source is rarely symmetric -- the workgroup then waits for
+  // its busiest wave at the end.
+  const int p1 = a.N;
+  int rot = wave;
+  for (int base = chunk * (WG * 2); base < p1; base += (int)gridDim.x * (WG * 2), ++rot) {
     // the lens on two pixels per lane (packed fp32 like the other kernels); the bases and the MFMA pass then take the wave's two
     // 64-pixel runs one after the other, so that the planes of a wave are 64 pixels deep (27 KB / workgroup: three per CU)
     unsigned jj[2];
     bool valid[2];
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
-      const int j = base + w * WG + tid;
+      const int j = base + w * WG + ((rot & 3) << 6) + lane;
       valid[w] = j < p1;
       jj[w] = (unsigned)(valid[w] ? j : p1 - 1);
     }
@@ -608,8 +613,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 2
-      for (int kb = 0; kb < 16; ++kb) {
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) {  // fully unrolled: every LDS offset is an immediate, no address arithmetic beside the MFMAs
         float v[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = rd_a[t][8 * kb] * rd_b[t][8 * kb];
@@ -626,15 +631,15 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
   // ---- the four waves' tiles summed in fixed order through LDS (aliases the planes), then the lower tiles written ----
   __syncthreads();
   float* s_red = s_x;
+  // (all reads of a wave's turn first, then the adds and the stores: written as one read-modify-write per element the compiler
+  // keeps them in order, 60 dependent LDS round trips per turn -- 40k cycles per workgroup, 15% of its life, measured)
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
+      float prev[NTILES * 4];
 #pragma unroll
-      for (int q = 0; q < NTILES; ++q)
+      for (int e = 0; e < NTILES * 4; ++e) prev[e] = wv == 0 ? 0.f : s_red[e * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int idx = (q * 4 + r) * 64 + lane;
-          s_red[idx] = (wv == 0 ? 0.f : s_red[idx]) + acc[q][r];
-        }
+      for (int e = 0; e < NTILES * 4; ++e) s_red[e * 64 + lane] = prev[e] + acc[e >> 2][e & 3];
     }
     __syncthreads();
   }
@@ -646,13 +651,23 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
   __syncthreads();
   const float yy_skipped = (s_yy[0] + s_yy[1]) + (s_yy[2] + s_yy[3]);
   float* out = na.partial + ((size_t)b * gridDim.x + chunk) * na.Dp * na.Dp;
-  for (int e = tid; e < NTILES * 256; e += WG) {
-    const int q = e >> 8, r = (e >> 6) & 3, ll = e & 63;
+  // one 16-byte store per lane: lane (R, c4) of a wave takes columns 4 c4 .. 4 c4 + 3 of row R of a tile (four consecutive floats
+  // of the reduction buffer); Dp is a multiple of 4, so a quad is inside the matrix or outside as a whole
+  for (int q = wave; q < NTILES; q += 4) {
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
     const int tj = q - ti * (ti + 1) / 2;
-    const int i = 16 * ti + 4 * (ll >> 4) + r, j = 16 * tj + (ll & 15);
-    if (i < na.Dp && j < na.Dp) out[i * na.Dp + j] = s_red[e] + ((i == na.Dl && j == na.Dl) ? yy_skipped : 0.f);
+    const int R = lane >> 2, c4 = lane & 3;
+    const int i = 16 * ti + R, j = 16 * tj + 4 * c4;
+    float4 v = *reinterpret_cast<const float4*>(s_red + (q * 4 + (R & 3)) * 64 + 16 * (R >> 2) + 4 * c4);
+    if (i == na.Dl && (na.Dl >> 2) == (j >> 2)) {
+      const int o = na.Dl & 3;
+      v.x += o == 0 ? yy_skipped : 0.f;
+      v.y += o == 1 ? yy_skipped : 0.f;
+      v.z += o == 2 ? yy_skipped : 0.f;
+      v.w += o == 3 ? yy_skipped : 0.f;
+    }
+    if (i < na.Dp && j < na.Dp) *reinterpret_cast<float4*>(out + i * na.Dp + j) = v;
   }
 }
 
