@@ -147,7 +147,6 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.out_scale = m->conversion_factor;
   a.partial = w.partial;
   a.shp_tab = m->d_shp_tab;
-  a.shp_tab2 = m->d_shp_tab2;
   a.nfw_tab = m->d_nfw_tab;
   a.dbg = m->dbg_flags;
   a.shp_stride = m->shp_stride;
@@ -682,11 +681,6 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
                     // orders above 10, whose shapelet components all run the runtime-order path -- the n_max = 20 one (stride 24)
     glh::build_shapelet_table(m->shp_big ? SH_CAPB : SH_CAP, tab, &m->shp_stride);
     ok = ok && up((void**)&m->d_shp_tab, tab.data(), tab.size() * sizeof(float));
-    std::vector<float> tab2;  // gl_shp.hip.h: values | differences per node, order pairs in loaded register pairs
-    if (!m->shp_big) {
-      glh::build_shapelet_pair_table(tab, m->shp_stride, SH_CAP, SH_SQ, tab2);
-      ok = ok && up((void**)&m->d_shp_tab2, tab2.data(), tab2.size() * sizeof(float));
-    }
   }
   m->has_post = grid->psf != nullptr || grid->supersample != 1;
   if (m->has_post) {
@@ -866,7 +860,6 @@ void gl_model_destroy(gl_model* m) {
   if (m->d_gy) (void)hipFree(m->d_gy);
   if (m->d_pix) (void)hipFree(m->d_pix);
   if (m->d_shp_tab) (void)hipFree(m->d_shp_tab);
-  if (m->d_shp_tab2) (void)hipFree(m->d_shp_tab2);
   if (m->d_nfw_tab) (void)hipFree(m->d_nfw_tab);
   if (m->d_corr_k) (void)hipFree(m->d_corr_k);
   if (m->d_psf) (void)hipFree(m->d_psf);

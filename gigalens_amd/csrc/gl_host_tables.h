@@ -24,20 +24,6 @@ inline void build_shapelet_table(int n_max, std::vector<float>& tab, int* stride
   *stride = st;
 }
 
-// The table of gl_shp.hip.h: per node the values of `n_ord` orders followed by the differences to the next node, both as the
-// float32 numbers the stride-`st` table above holds (the difference is the float32 subtraction the older kernels perform on the
-// device); node kShapeletNodes is a zero row (coordinates outside [-5, 5]); orders above n_max are zero.
-inline void build_shapelet_pair_table(const std::vector<float>& tab, int st, int n_max, int n_ord, std::vector<float>& out) {
-  out.assign((size_t)(kShapeletNodes + 1) * 2 * n_ord, 0.f);
-  for (int i = 0; i < kShapeletNodes; ++i)
-    for (int n = 0; n <= n_max && n < n_ord; ++n) {
-      const float lo = tab[(size_t)i * st + n];
-      out[(size_t)i * 2 * n_ord + n] = lo;
-      if (i + 1 < kShapeletNodes) out[(size_t)i * 2 * n_ord + n_ord + n] = tab[(size_t)(i + 1) * st + n] - lo;
-    }
-}
-
-
 // NFW:  h(X) = g(X) / X^2  -- the radial deflection of a spherical NFW halo is  alpha(R) = 4 rho0 Rs^2 g(X) / X * (d / R)
 // = K0 h(X) d  with X = R / Rs (tf/profiles/mass/nfw.py:26-52).  h has no parameters, so the cluster kernel reads it from
 // ONE table shared by every halo of every sample.  Nodes follow the float format itself: octave e in [kNfwLog2Lo,

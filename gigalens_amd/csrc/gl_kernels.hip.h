@@ -90,7 +90,6 @@ struct MainArgs {
   float* partial;  // [B][n_chunks][A]
   const float* shp_tab;
   int shp_stride;
-  const float* shp_tab2;  // gl_shp.hip.h: per node the values of orders 0..11 then the differences to the next node; node 6000 = zeros
   const int* order;  // cost-ordered dispatch: blockIdx.y -> sample index (heaviest first), or null
   unsigned parts;    // forward-only partial renders (tf/simulator.py:242-328): bit0 deflect, bit1 lens light, bit2 sources
   // galaxy catalogues (K_SCALED): per-galaxy static blocks [G][DP_NS], per-(sample, galaxy) blocks [B][G][GM_ND]

@@ -52,14 +52,18 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     const size_t epi = (size_t)(16 * m->Apad + 4 * 16 * 17) * sizeof(float);
     const size_t sh = (size_t)((m->D + 3) & ~3) * sizeof(float) + std::max(shp_exchange_bytes(NPS), epi);
     const bool interp = (m->comps.back().flags & GL_FLAG_SHAPELETS_INTERPOLATE) != 0;
-#define GL_SHP(LLK_, I_)                                                                                  \
-  do {                                                                                                    \
-    m->last_main_fn = (const void*)&gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_>;                     \
-    hipLaunchKernelGGL((gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_>), grid, block, sh, stream, a);   \
+    // whole 512-pixel tiles, no mask, no pixel list: the instantiation without the ragged-end tile code
+    const bool ragged = a.mask || a.pix || (a.N % (2 * WG)) != 0 || (a.chunk % (2 * WG)) != 0;
+#define GL_SHP2(LLK_, I_, R_)                                                                                 \
+  do {                                                                                                        \
+    m->last_main_fn = (const void*)&gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_, R_>;                     \
+    hipLaunchKernelGGL((gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_, R_>), grid, block, sh, stream, a);   \
   } while (0)
+#define GL_SHP(LLK_, I_) do { if (ragged) GL_SHP2(LLK_, I_, true); else GL_SHP2(LLK_, I_, false); } while (0)
     if (m->static_id == ST_EPLSHEAR_SHAPELETS) { if (interp) GL_SHP(C_None, true); else GL_SHP(C_None, false); }
     else { if (interp) GL_SHP(C_SersicE, true); else GL_SHP(C_SersicE, false); }
 #undef GL_SHP
+#undef GL_SHP2
     return true;
   }
 #define GL_LAUNCH(TT, WW, LK, CK, SK)                                                        \

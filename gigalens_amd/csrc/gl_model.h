@@ -60,7 +60,6 @@ struct gl_model {
   float* d_gy = nullptr;
   int* d_pix = nullptr;
   float* d_shp_tab = nullptr;
-  float* d_shp_tab2 = nullptr;  // gl_shp.hip.h layout (values | differences per node)
   float* d_nfw_tab = nullptr;  // models with NFW lenses: h(X) = g(X) / X^2 on the float format's own grid (gl_host_tables.h)
   int chunk_px_override = 0;  // -DGL_EXPERIMENTS builds only
   int dbg_flags = 0;          // -DGL_EXPERIMENTS builds only

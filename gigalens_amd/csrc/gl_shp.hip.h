@@ -4,21 +4,21 @@
 // Round-3 redesign of the shapelet render / VJP (the scalar one-pixel-per-thread kernel it replaces spent 574 VALU
 // instructions per pixel, 69 accumulator registers per lane and ran at 2 waves per SIMD):
 //   * lens side in pixel-PAIR form (gl_vec.hip.h): the ray-shoot, the chi^2 terms and the lens VJP issue as packed fp32.
-//   * shapelet side one pixel at a time, packed over ORDER pairs: the interpolation table stores, per node, the values of
-//     orders (0 .. 2 NP - 1) followed by the differences to the next node, so a coordinate costs six 16-byte loads and NP
-//     packed FMAs -- the loaded register pairs ARE the packed operands (orders 2j, 2j+1), no shuffles.
+//   * shapelet side one pixel at a time, packed over the pixel's TWO COORDINATES: (X_n(u), Y_n(v)) advance through the
+//     three-term recurrence in one packed instruction stream.  Table mode generates the values at the two bracketing nodes of
+//     the reference's 6000-node grid the same way (ShpNodeGen below) instead of loading them.
 //   * ONE contraction serves the value and both derivatives: with s_n2 = sum_n1 a(n1,n2) X_n1 and s'_n2 the same sum over
-//     the derivative basis X'_n1,   S = sum Y s,  dS/du = sum Y s',  dS/dv = sum Y' s.   The amplitude matrix is read row by row
-//     through scalar loads (SGPR pairs a(n1, 2j..2j+1): shapelets_prep writes the zero-padded square matrix behind the
-//     triangle), X_n1 is a broadcast half of a register pair: 2 x 36 + 18 packed FMAs per pixel where the separable form of
-//     round 2 spent 242 scalar ones.
+//     the derivative basis X'_n1,   S = sum Y s,  dS/du = sum Y s',  dS/dv = sum Y' s.   Row n1 of the contraction runs as soon
+//     as order n1 exists (X_n1 is a broadcast half of a register pair, the row two n2 per register from the workgroup's LDS copy
+//     of the zero-padded square matrix shapelets_prep writes behind the triangle): 2 x 36 packed FMAs + 33 scalar ones per
+//     pixel where the separable form of round 2 spent 242 scalar ones.
 //   * the amplitude gradient  G(n1,n2) = sum_pixels gS X_n1 Y_n2  is a rank-1 update per pixel -- a GEMM with the pixels as
 //     the contraction index.  It runs on the matrix pipe in exact fp32 (v_mfma_f32_16x16x4_f32: same arithmetic as an FMA
-//     chain): each wave parks (gS X) and Y of its pixels in LDS as order-pair planes [j][pixel][2] (conflict-free 8-byte
-//     stores) and reads them back transposed -- lane (m, k) = order m of pixel 4 kb + k, conflict-free 4-byte reads: plane
-//     stride = 4 mod 32 banks -- as the A and B operands of one MFMA per four pixels.  G lives in FOUR accumulator registers
-//     per lane instead of 66 VGPRs, co-issues with the vector work of the other waves, and the 66-value epilogue reduction
-//     of the scalar kernel disappears (one 16 x 16 tile per wave, summed over the four waves in fixed order).
+//     chain): each wave parks (X_n, Y_n) of its pixels in LDS, one plane [pixel][2] per order (conflict-free 8-byte stores),
+//     and reads them back transposed -- lane (m, k) = order m of pixel 4 kb + k, 4-byte reads, plane stride = 4 mod 32 banks --
+//     as the A and B operands of one MFMA per four pixels.  G lives in FOUR accumulator registers per lane instead of 66
+//     VGPRs, and the 66-value epilogue reduction of the scalar kernel disappears (one 16 x 16 tile per wave, summed over the
+//     four waves in fixed order).
 // Bitwise reproducible like every other kernel of the path: no atomics, fixed summation order.
 #pragma once
 #include "gl_pair.hip.h"
@@ -34,55 +34,80 @@ __host__ __device__ constexpr size_t shp_exchange_bytes(int np) { return (size_t
 
 template <int NP> struct ShpPix { float S, Su, Sv, u, v, dx, dy, fac; };  // what a pixel's VJP needs of its forward pass
 
-// table row of one coordinate: NP pairs of values at the node below and NP pairs of differences to the next node
-// `live`: the pixel's OTHER coordinate is inside the table too.  Every output of a pixel is a product with a basis along v or
-// its slope (S = sum Y s, dS/du = sum Y s', dS/dv = sum Y' s, G = gS X Y^T), so a pixel with one coordinate outside renders
-// exactly zero whatever the other basis is: both of its rows are sent to the zero row, which all such lanes share (one L1
-// access per instruction instead of one per lane: the gather is what binds this kernel).  0.289 -> 0.272 ms at C3.
-// (Skipping per pixel SLOT instead of per tile -- the lane's two pixels tested separately -- was slower, 0.300 ms: behind its own
-// branch the second pixel's gather no longer overlaps the first pixel's contraction.)
-template <int NP>
-__device__ __forceinline__ void shp_row(const float* __restrict__ tab, float u, bool live, v2f (&val)[NP], v2f (&dif)[NP], float& tt) {
-  const float scale = (float)(SH_NODES - 1) / 10.f;
-  const float fi = (u + 5.f) * scale;  // tfp.math.interp_regular_1d_grid on [-5, 5], fill 0 outside (shapelets.py:58-60)
-  const bool inside = live && (fi >= 0.f) && (fi <= (float)(SH_NODES - 1));
-  const float fic = clamp_(fi, 0.f, (float)(SH_NODES - 1));
-  const float fb = fmin_(floor_(fic), (float)(SH_NODES - 2));  // the last node belongs to the last interval (t = 1)
-  tt = fic - fb;
-  const unsigned row = inside ? (unsigned)(int)fb : (unsigned)SH_NODES;  // outside (or NaN): the zero row appended to the table
-  // 32-bit byte offset from the (scalar) table base: one VALU for the address, 4 NP floats per node
-  const float4* __restrict__ r = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + row * (unsigned)(16 * NP));
-#pragma unroll
-  for (int q = 0; q < NP / 2; ++q) {
-    const float4 a = r[q], b = r[NP / 2 + q];
-    val[2 * q] = v2f{a.x, a.y}; val[2 * q + 1] = v2f{a.z, a.w};
-    dif[2 * q] = v2f{b.x, b.y}; dif[2 * q + 1] = v2f{b.z, b.w};
-  }
-}
+// ---- the bases of one pixel, (u, v)-packed: val[n] = (X_n(u), Y_n(v)), two coordinates per packed instruction -------------------
+// The orders are produced one at a time -- value() = (X_n(u), Y_n(v)), slope() = (X'_n, Y'_n), then advance(n) -- so that the
+// caller consumes each (parks it, runs its row of the contraction) instead of holding 2 x 2 x 12 basis registers.
 
-// direct mode (shapelets.py:67-85): normalised Hermite recurrence, X'_n = sqrt(2n) X_{n-1}; orders above n_max stay zero
-template <int NP>
-__device__ __forceinline__ void shp_hermite(float u, int n_max, v2f (&val)[NP], v2f (&dif)[NP]) {
-  float X[2 * NP], dX[2 * NP];
-  X[0] = 0.75112554446494248286f;
-  dX[0] = 0.f;
-#pragma unroll
-  for (int n = 1; n < 2 * NP; ++n) {
-    const float a = (float)__builtin_sqrt(2.0 / n), bc = (float)__builtin_sqrt((n - 1.0) / n), dc = (float)__builtin_sqrt(2.0 * n);
-    const float xn = a * u * X[n - 1] - (n >= 2 ? bc * X[n - 2] : 0.f);
-    X[n] = n <= n_max ? xn : 0.f;
-    dX[n] = n <= n_max ? dc * X[n - 1] : 0.f;
+// Table mode (shapelets.py:39-40, 55-62: tfp.math.interp_regular_1d_grid over phi_n(linspace(-5, 5, 6000)), fill 0 outside).
+// The node values are not LOADED, they are generated: phi_0 at the node below by one exponential, the higher orders by the
+// normalised three-term recurrence -- and the DIFFERENCE to the next node by its own recurrence
+//     D_{n+1} = a_n (u0 + h) D_n - b_n D_{n-1} + a_n h V_n,      D_0 = V_0 expm1(-h (u0 + h / 2)),
+// so that the slope of the interpolant (what the position gradients see) carries no cancellation: both are good to ~1e-6 of
+// the basis amplitude, the distance between the reference's own float32 nodes and exact ones (checked against the float64
+// table over all 6000 nodes in tests/).  Round 3 first gathered [values | differences] rows of a 576 KB table, 96 bytes per
+// coordinate and lane: 120 M vector-L1 accesses per C3 launch = 72 % of the L1's 64 bytes per cycle, with the VALU a third busy.
+// value() = the interpolant, slope() = its difference per node spacing; a pixel with either coordinate outside the table has
+// every basis value zero (V_0 = 0 propagates), which is what fill 0 x anything gives.  Orders above the model's n_max are
+// generated too: their amplitudes are zeros of the padded matrix, their gradient entries and normal-matrix channels never stored.
+struct ShpNodeGen {
+  static constexpr float top = (float)(SH_NODES - 1), h = 10.f / top;
+  v2f u0, t, Vp, Dp, Vc, Dc;
+  __device__ __forceinline__ void init(float u, float v) {
+    const v2f fi = (v2f{u, v} + 5.f) * (top / 10.f);
+    const bool live = (fi.x >= 0.f) && (fi.x <= top) && (fi.y >= 0.f) && (fi.y <= top);  // NaN: not live
+    const v2f fic = v2f{clamp_(fi.x, 0.f, top), clamp_(fi.y, 0.f, top)};
+    const v2f fb = v2f{fmin_(floor_(fic.x), top - 1.f), fmin_(floor_(fic.y), top - 1.f)};  // the last node belongs to the last interval (t = 1)
+    t = fic - fb;
+    u0 = (fb - 0.5f * top) * h;  // node below: (i - 2999.5) h, symmetric about 0
+    const v2f e0 = exp2_(u0 * u0 * (float)(-0.5 * kLog2e));
+    const v2f z = __builtin_elementwise_fma(u0, v2f(-h), v2f(-0.5f * h * h));  // -(u1^2 - u0^2) / 2 with u1 = u0 + h; |z| < 8.4e-3
+    v2f em1 = __builtin_elementwise_fma(z, v2f(1.f / 6.f), v2f(0.5f));
+    em1 = __builtin_elementwise_fma(z, em1, v2f(1.f)) * z;  // expm1(z) to 2e-10
+    Vp = v2f(0.f);
+    Dp = v2f(0.f);
+    Vc = live ? e0 * 0.75112554446494248286f : v2f(0.f);
+    Dc = Vc * em1;
   }
-#pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    val[j] = v2f{X[2 * j], X[2 * j + 1]};
-    dif[j] = v2f{dX[2 * j], dX[2 * j + 1]};
+  __device__ __forceinline__ v2f value() const { return __builtin_elementwise_fma(t, Dc, Vc); }
+  __device__ __forceinline__ v2f slope() const { return Dc; }
+  __device__ __forceinline__ void advance(int n) {  // order n -> n + 1 (n a compile-time constant after unrolling)
+    const float an = (float)__builtin_sqrt(2.0 / (n + 1)), bn = (float)__builtin_sqrt((double)n / (n + 1)), ah = an * h;
+    const v2f au0 = u0 * an, au1 = au0 + ah;
+    v2f vn, dn;
+    if (n == 0) {
+      vn = au0 * Vc;
+      dn = __builtin_elementwise_fma(au1, Dc, Vc * ah);
+    } else {
+      vn = __builtin_elementwise_fma(au0, Vc, -(Vp * bn));
+      dn = __builtin_elementwise_fma(au1, Dc, -(Dp * bn));
+      dn = __builtin_elementwise_fma(v2f(ah), Vc, dn);
+    }
+    Vp = Vc; Dp = Dc;
+    Vc = vn; Dc = dn;
   }
-}
+};
 
-// ---- forward of one pixel, in two steps so that the kernel can put the table gathers of BOTH pixels of a lane in flight before
-// either chain starts (a gather is a full trip to the L2; issued one row at a time the chains are latency-bound) ------------------
-template <int NP> struct ShpRows { v2f xv[NP], xd[NP], yv[NP], yd[NP]; float tu, tv; };
+// direct mode (shapelets.py:67-85): normalised Hermite recurrence, X'_n = sqrt(2n) X_{n-1}
+struct ShpDirectGen {
+  v2f uv, Vp, Vc, Dc;
+  __device__ __forceinline__ void init(float u, float v) {
+    uv = v2f{u, v};
+    Vp = v2f(0.f);
+    Vc = v2f(0.75112554446494248286f);
+    Dc = v2f(0.f);
+  }
+  __device__ __forceinline__ v2f value() const { return Vc; }
+  __device__ __forceinline__ v2f slope() const { return Dc; }
+  __device__ __forceinline__ void advance(int n) {
+    const float an = (float)__builtin_sqrt(2.0 / (n + 1)), bn = (float)__builtin_sqrt((double)n / (n + 1));
+    const v2f au = uv * an;
+    const v2f vn = n == 0 ? au * Vc : __builtin_elementwise_fma(au, Vc, -(Vp * bn));
+    Dc = Vc * (float)__builtin_sqrt(2.0 * (n + 1));
+    Vp = Vc;
+    Vc = vn;
+  }
+};
+template <bool INTERP> using ShpGen = std::conditional_t<INTERP, ShpNodeGen, ShpDirectGen>;
 
 template <int NP> __device__ __forceinline__ void shp_pixel_coords(const float* d, float px, float py, ShpPix<NP>& st) {
   const float ib = d[SHP_IB];
@@ -91,79 +116,77 @@ template <int NP> __device__ __forceinline__ void shp_pixel_coords(const float* 
   st.u = st.dx * ib;
   st.v = st.dy * ib;
 }
-// the table's support, with the expression shp_row itself uses: outside it a basis and its slope are exactly zero
+// the table's support, with the expression shp_basis_nodes itself uses: outside it a basis and its slope are exactly zero
 __device__ __forceinline__ bool shp_in_table(float u) {
   const float fi = (u + 5.f) * ((float)(SH_NODES - 1) / 10.f);
   return (fi >= 0.f) && (fi <= (float)(SH_NODES - 1));
 }
-template <int NP, bool INTERP>
-__device__ __forceinline__ void shp_pixel_gather(const float* __restrict__ tab, const ShpPix<NP>& st, ShpRows<NP>& r) {
-  if constexpr (INTERP) {
-    const bool live = shp_in_table(st.u) && shp_in_table(st.v);
-    shp_row<NP>(tab, st.u, live, r.xv, r.xd, r.tu);
-    shp_row<NP>(tab, st.v, live, r.yv, r.yd, r.tv);
-  }
-}
 
+// ---- forward of one pixel ----------------------------------------------------------------------------------------------------
 //   gA : the sample's zero-padded square amplitude matrix [2NP][2NP] in GLOBAL memory (wave-uniform address: scalar loads)
-//   ybuf: this lane's slot of the wave's Y planes (dword address of plane 0): Y is parked there for the MFMA pass
+//   buf: this lane's slot of the wave's exchange planes (plane n = (X_n, Y_n) of every pixel): parked there for the MFMA pass
 template <int NP, bool INTERP, bool GRAD>
-__device__ __forceinline__ float shp_pixel_fwd(const float* d, const v2f* __restrict__ gA, ShpRows<NP>& r, float* __restrict__ xbuf,
-                                               float* __restrict__ ybuf, ShpPix<NP>& st) {
-  if constexpr (INTERP) {
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.xv[j] = __builtin_elementwise_fma(v2f(r.tu), r.xd[j], r.xv[j]);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) r.yv[j] = __builtin_elementwise_fma(v2f(r.tv), r.yd[j], r.yv[j]);
-    st.fac = 1.f;
-  } else {
-    const int n_max = (int)d[SHP_NMAX];
-    shp_hermite<NP>(st.u, n_max, r.xv, r.xd);
-    shp_hermite<NP>(st.v, n_max, r.yv, r.yd);
-    st.fac = exp_(-(st.u * st.u + st.v * st.v) * 0.5f);  // shapelets.py:70
-  }
-  if constexpr (GRAD) {  // both bases are parked for the MFMA pass right away: no basis register outlives this function
-#pragma unroll
-    for (int j = 0; j < NP; ++j) *reinterpret_cast<v2f*>(xbuf + j * SHX_PLANE) = r.xv[j];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) *reinterpret_cast<v2f*>(ybuf + j * SHX_PLANE) = r.yv[j];
-  }
-  // s_n2 = sum_n1 a(n1, n2) X_n1 (and s'_n2 with X'_n1), two n2 per register; rows beyond the triangle are zero and skipped
-  v2f s[NP], sd[NP];
-#pragma unroll
-  for (int j = 0; j < NP; ++j) { s[j] = v2f(0.f); sd[j] = v2f(0.f); }
+__device__ __forceinline__ float shp_pixel_fwd(const float* d, const v2f* __restrict__ gA, float* __restrict__ buf, ShpPix<NP>& st) {
+  constexpr int NO = 2 * NP;
+  // s_n2 = sum_n1 a(n1, n2) X_n1 (and s'_n2 with X'_n1), two n2 per register; rows beyond the triangle are zero and skipped.  Row
+  // n1 of the contraction runs as soon as order n1 exists; of the basis only (Y_n, Y'_n) is kept for the sums over n2.
   // (The 72 matrix entries are scalar loads the compiler issues together; with the kernel's pointers that is more SGPRs than a
   // wave has, so some pointers are parked in VGPR lanes: ~60 v_readlane per tile.  Splitting the rows into dependent groups, a
   // scheduling barrier, or a laundered pointer all made the allocation worse: measured, see DESIGN.md.)
+  v2f s[NP], sd[NP], yk[NO - 1];
 #pragma unroll
-  for (int n1 = 0; n1 < 2 * NP - 1; ++n1) {
-    const float xn = (n1 & 1) ? r.xv[n1 >> 1].y : r.xv[n1 >> 1].x;
-    const float dn = (n1 & 1) ? r.xd[n1 >> 1].y : r.xd[n1 >> 1].x;
+  for (int j = 0; j < NP; ++j) { s[j] = v2f(0.f); sd[j] = v2f(0.f); }
+  // Row n1 + 1 of the matrix is read (LDS broadcast) while row n1 is in use, and no earlier: its address carries an opaque zero
+  // derived from order n1 (left alone, the compiler issues all 72 reads first and the kernel no longer fits its registers).
+  auto load_row = [&](int n1, float dep, v2f (&row)[NP]) {
+    int z = 0;
+    if constexpr (INTERP) asm volatile("v_and_b32 %0, 0, %1" : "=v"(z) : "v"(dep));  // (direct mode: the compiler's own order fits)
+    const v2f* __restrict__ p = reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(gA) + z) + n1 * NP;
 #pragma unroll
-    for (int j = 0; 2 * j + n1 < 2 * NP - 1; ++j) {  // n2 = 2j, 2j+1 with n1 + n2 <= 2 NP - 2 (the largest n_max this NP serves)
-      const v2f arow = gA[n1 * NP + j];
-      s[j] = __builtin_elementwise_fma(v2f(xn), arow, s[j]);
-      if (GRAD) sd[j] = __builtin_elementwise_fma(v2f(dn), arow, sd[j]);
+    for (int j = 0; 2 * j + n1 < NO - 1; ++j) row[j] = p[j];
+  };
+  ShpGen<INTERP> gen;
+  gen.init(st.u, st.v);
+  v2f row[2][NP];  // (two rows ahead: no faster)
+  load_row(0, st.u, row[0]);
+#pragma unroll
+  for (int n1 = 0; n1 < NO - 1; ++n1) {
+    const v2f W = gen.value(), D = gen.slope();
+    if (n1 + 1 < NO - 1) load_row(n1 + 1, W.x, row[(n1 + 1) & 1]);
+    if constexpr (GRAD) *reinterpret_cast<v2f*>(buf + n1 * SHX_PLANE) = W;  // parked for the MFMA pass right away
+    yk[n1] = v2f{W.y, D.y};
+#pragma unroll
+    for (int j = 0; 2 * j + n1 < NO - 1; ++j) {  // n2 = 2j, 2j+1 with n1 + n2 <= 2 NP - 2 (the largest n_max this NP serves)
+      const v2f arow = row[n1 & 1][j];
+      s[j] = __builtin_elementwise_fma(v2f(W.x), arow, s[j]);
+      if (GRAD) sd[j] = __builtin_elementwise_fma(v2f(D.x), arow, sd[j]);
     }
+    if (n1 + 1 < NO - 1) gen.advance(n1);
   }
-  v2f S2 = v2f(0.f), Su2 = v2f(0.f), Sv2 = v2f(0.f);
+  if constexpr (GRAD) *reinterpret_cast<v2f*>(buf + (NO - 1) * SHX_PLANE) = v2f(0.f);  // the pad order (NO = 2 NP serves n_max <= NO - 2)
+  st.fac = INTERP ? 1.f : exp_(-(st.u * st.u + st.v * st.v) * 0.5f);  // shapelets.py:70
+  float S = 0.f, Su = 0.f, Sv = 0.f;
 #pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    S2 = __builtin_elementwise_fma(r.yv[j], s[j], S2);
+  for (int n2 = 0; n2 < NO - 1; ++n2) {
+    const float sn = (n2 & 1) ? s[n2 >> 1].y : s[n2 >> 1].x;
+    S = __builtin_fmaf(yk[n2].x, sn, S);
     if (GRAD) {
-      Su2 = __builtin_elementwise_fma(r.yv[j], sd[j], Su2);
-      Sv2 = __builtin_elementwise_fma(r.yd[j], s[j], Sv2);
+      const float sdn = (n2 & 1) ? sd[n2 >> 1].y : sd[n2 >> 1].x;
+      Su = __builtin_fmaf(yk[n2].x, sdn, Su);
+      Sv = __builtin_fmaf(yk[n2].y, sn, Sv);
     }
   }
-  st.S = S2.x + S2.y;
-  if (GRAD) { st.Su = Su2.x + Su2.y; st.Sv = Sv2.x + Sv2.y; }
+  st.S = S;
+  if (GRAD) { st.Su = Su; st.Sv = Sv; }
   return st.fac * st.S;
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------------------------
 // Component list: LK lenses, LLK lens lights (Sersic kinds), then exactly one K_SHAPELETS source.  Every thread owns pixels
 // (j, j + 256) of a 512-pixel tile; the two shapelet chains of a lane run one after the other.
-template <int MODE, int WAVES, class LK, class LLK, int NP, bool INTERP>
+// RAGGED = false: the launch site guarantees whole 512-pixel tiles, no mask and no pixel list (every BASELINE config) -- the kernel
+// then carries no ragged-end tile code at all (beside the steady-state body that instantiation does not fit 256 registers).
+template <int MODE, int WAVES, class LK, class LLK, int NP, bool INTERP, bool RAGGED>
 __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
   using V = v2f;
   constexpr int NL = LK::n, NLL = LLK::n;
@@ -196,17 +219,18 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
   for (int i = 0; i < NLL; ++i) dC[i] = s_d + comps[NL + i].d_off;
   const CompDesc shp = comps[NL + NLL];
   const float* dS = s_d + shp.d_off;
-  const v2f* __restrict__ gA = reinterpret_cast<const v2f*>(gder + shp.d_off + SHP_SQ);
+  // the zero-padded square amplitude matrix, from the workgroup's LDS copy of the sample's constants: uniform addresses, so every
+  // read is a broadcast (as 72 vector registers filled by global loads it was a third of the kernel's L1 traffic)
+  const v2f* __restrict__ gA = INTERP ? reinterpret_cast<const v2f*>(dS + SHP_SQ) : reinterpret_cast<const v2f*>(gder + shp.d_off + SHP_SQ);
   const bool has_err = a.err != nullptr, has_mask = a.mask != nullptr, has_pix = a.pix != nullptr;
-  // exchange planes of this wave: gX at [0, NP), Y at [NP, 2 NP); a lane parks pixel slot w at pixel index 64 w + lane
+  // exchange planes of this wave: plane n = (X_n, Y_n) of each pixel; a lane parks pixel slot w at pixel index 64 w + lane
   float* xw = s_x + wave * shp_exchange_floats(NP);
-  float* wr_gx = xw + 2 * lane;
-  float* wr_y = xw + NP * SHX_PLANE + 2 * lane;
+  float* wr_xy = xw + 2 * lane;
   // transposed read: lane (m, k) = (lane & 15, lane >> 4) takes order m of pixel 4 kb + k; orders beyond 2 NP - 1 re-read the last
   // (their rows / columns of the tile are never stored)
   const int mm = min(lane & 15, 2 * NP - 1);
-  const float* rd_gx = xw + (mm >> 1) * SHX_PLANE + (mm & 1) + 2 * (lane >> 4);
-  const float* rd_y = rd_gx + NP * SHX_PLANE;
+  const float* rd_gx = xw + mm * SHX_PLANE + 2 * (lane >> 4);
+  const float* rd_y = rd_gx + 1;
   float* wr_gs = xw + 2 * NP * SHX_PLANE + lane;            // gS of pixel slot w at 64 w + lane
   const float* rd_gs = xw + 2 * NP * SHX_PLANE + (lane >> 4);  // pixel 4 kb + k of the operand lane (m, k)
 
@@ -259,12 +283,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     }
     if (shp_live) {
       ++n_live;
-      ShpRows<NP> r0;
-      shp_pixel_gather<NP, INTERP>(a.shp_tab2, ps0, r0);
-      const float l0 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, r0, wr_gx, wr_y, ps0);
-      ShpRows<NP> r1;
-      shp_pixel_gather<NP, INTERP>(a.shp_tab2, ps1, r1);
-      const float l1 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, r1, wr_gx + 128, wr_y + 128, ps1);
+      const float l0 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, wr_xy, ps0);
+      const float l1 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, wr_xy + 128, ps1);
       m += V{l0, l1};
     }
     auto nanp = m != m;
@@ -298,7 +318,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
         st1 += nm;
       }
       if (MODE == LL_GRAD) {
-        V g = has_err ? -(dmo * is2) : (dmo * dmo * is2 - 1.f) * (is2 * (0.5f * a.inv_t)) - dmo * is2;
+        // (0.5 / t as a scalar operand and an inline constant: folded into one packed register it was the kernel's only spill)
+        V g = has_err ? -(dmo * is2) : (dmo * dmo * is2 - 1.f) * ((is2 * a.inv_t) * 0.5f) - dmo * is2;
         gm = nanp ? V(0.f) : (CHECK ? g * w : g) * a.out_scale;
       }
     }
@@ -382,11 +403,15 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     }
   };
   {
-    const bool plain = !has_mask && !has_pix;
     int base = p0;
-    if (plain)
+    if constexpr (!RAGGED) {
       for (; base + WG * 2 <= p1; base += WG * 2) tile(base, std::false_type{});
-    for (; base < p1; base += WG * 2) tile(base, std::true_type{});
+    } else {
+      const bool plain = !has_mask && !has_pix;
+      if (plain)
+        for (; base + WG * 2 <= p1; base += WG * 2) tile(base, std::false_type{});
+      for (; base < p1; base += WG * 2) tile(base, std::true_type{});
+    }
   }
   if (MODE == IMG_FWD) return;
   float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
@@ -512,8 +537,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
   for (int i = 0; i < NL; ++i) dL[i] = s_d + comps[i].d_off;
   const CompDesc shp = comps[NL];
   const float* dS = s_d + shp.d_off;
-  float* wr_x = xw + 2 * lane;
-  float* wr_y = xw + NP * SHN_PLANE + 2 * lane;
+  float* wr_xy = xw + 2 * lane;  // plane n = (X_n w, Y_n) of each pixel
   // the lane's channel of every tile row -- two factor addresses in the planes ([pixel][2] pairs, 8 floats per pixel group):
   // amplitude (n1, n2): X'[n1] and Y[n2]; the observation column: (obs w, 1); padding: order 2 NP - 1 of X and Y, which is
   // zero for every n_max this kernel serves (<= 2 NP - 2)
@@ -530,8 +554,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
       n2 = ch - n * (n + 1) / 2;
       n1 = n - n2;
     }
-    rd_a[t] = xw + (n1 >> 1) * SHN_PLANE + (n1 & 1) + 2 * k;
-    rd_b[t] = xw + NP * SHN_PLANE + (n2 >> 1) * SHN_PLANE + (n2 & 1) + 2 * k;
+    rd_a[t] = xw + n1 * SHN_PLANE + 2 * k;
+    rd_b[t] = xw + n2 * SHN_PLANE + 1 + 2 * k;
     if (ch == na.Dl) { rd_a[t] = pl_ow + 2 * k; rd_b[t] = pl_ow + 1 + 2 * k; }
   }
   v4f acc[NTILES];
@@ -586,28 +610,19 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
         }
       }
       {
-        ShpRows<NP> r;
-        shp_pixel_gather<NP, INTERP>(a.shp_tab2, ps, r);
-        float fac = 1.f;
-        if constexpr (INTERP) {
+        constexpr int NO = 2 * NP;
+        const float fac = INTERP ? 1.f : exp_(-(ps.u * ps.u + ps.v * ps.v) * 0.5f);
+        const v2f xs = v2f{w1 * fac, 1.f};  // weight (and the Gaussian of direct mode) folded into the X factor
+        ShpGen<INTERP> gen;
+        gen.init(ps.u, ps.v);
 #pragma unroll
-          for (int j = 0; j < NP; ++j) r.xv[j] = __builtin_elementwise_fma(v2f(r.tu), r.xd[j], r.xv[j]);
-#pragma unroll
-          for (int j = 0; j < NP; ++j) r.yv[j] = __builtin_elementwise_fma(v2f(r.tv), r.yd[j], r.yv[j]);
-        } else {
-          const int n_max = (int)dS[SHP_NMAX];
-          shp_hermite<NP>(ps.u, n_max, r.xv, r.xd);
-          shp_hermite<NP>(ps.v, n_max, r.yv, r.yd);
-          fac = exp_(-(ps.u * ps.u + ps.v * ps.v) * 0.5f);
+        for (int n = 0; n < NO - 1; ++n) {
+          v2f xy = gen.value() * xs;
+          xy.x = xy.x == xy.x ? xy.x : 0.f;  // NaN -> 0 like the stack (tf/simulator.py:140 on each basis image)
+          *reinterpret_cast<v2f*>(wr_xy + n * SHN_PLANE) = xy;
+          if (n + 1 < NO - 1) gen.advance(n);
         }
-        const float xs = w1 * fac;  // weight (and the Gaussian of direct mode) folded into the X factor
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-          v2f xv = r.xv[j] * xs;
-          xv = V{xv.x == xv.x ? xv.x : 0.f, xv.y == xv.y ? xv.y : 0.f};  // NaN -> 0 like the stack (tf/simulator.py:140 on each basis image)
-          *reinterpret_cast<v2f*>(wr_x + j * SHN_PLANE) = xv;
-          *reinterpret_cast<v2f*>(wr_y + j * SHN_PLANE) = r.yv[j];
-        }
+        *reinterpret_cast<v2f*>(wr_xy + (NO - 1) * SHN_PLANE) = v2f(0.f);  // the pad order: what the padding channels read
         *reinterpret_cast<v2f*>(pl_ow + 2 * lane) = v2f{ow1, 1.f};
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

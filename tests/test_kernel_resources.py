@@ -19,7 +19,7 @@ EPLSHEAR, SIE, NONE, SERSIC, SHAPELETS = "glk::KindList<1, 4>", "glk::KindList<2
 DISPATCHED = {
     "C1 SIE | Sersic": [f"gl_pair_kernel<{m}, {V2}, {w}, {SIE}, {NONE}, {SERSIC} >" for m, w in ((0, 4), (1, 3), (2, 4), (3, 3))],
     "C2 EPL+Shear | Sersic": [f"gl_pair_kernel<{m}, {V2}, {w}, {EPLSHEAR}, {NONE}, {SERSIC} >" for m, w in ((0, 4), (1, 3), (2, 4), (3, 3))],
-    "C3 EPL+Shear | Shapelets": [f"gl_shp_kernel<{m}, 2, {EPLSHEAR}, {NONE}, 6, true>" for m in (0, 1, 2, 3)],  # table mode (the default)
+    "C3 EPL+Shear | Shapelets": [f"gl_shp_kernel<{m}, 2, {EPLSHEAR}, {NONE}, 6, true, false>" for m in (0, 1, 2, 3)],  # table mode (the default), whole tiles
     "C4 / C5 8 NFW | 20 Sersic": ["gl_main_kernel<0, 4, false, 0, false>", "gl_cluster_kernel<1, 8, 20, false, 2>",
                                   "gl_main_kernel<2, 4, false, 0, false>", "gl_cluster_kernel<3, 8, 20, false, 2>"],
 }
@@ -54,9 +54,12 @@ ALLOWED_SPILLS = [
     (r"gl_main_kernel<[13], 2, true, [01], false>", "shapelets through the interpreter, gradient modes (models outside the specialised compositions)"),
     (r"gl_static_kernel<[13], [24], ", "pre-pair tile variants of the specialised kernels in gradient modes: reached only with GIGALENS_HIP_PAIR=0 / GIGALENS_HIP_TILE*"),
     (r"gl_series_hessian_precompute_kernel<", "one-off float64 jet precompute of the Hessian series (not on the per-step path)"),
-    (r"gl_shp_kernel<[13], 2, glk::KindList<1, 4>, glk::KindList<17>, \d, true>",
+    (r"gl_shp_kernel<[13], 2, glk::KindList<1, 4>, glk::KindList<(17)?>, \d, true, true>",
+     "shapelet kernel, table mode, gradient modes, RAGGED instantiation (masks, pixel lists, pixel counts that are not whole "
+     "512-pixel tiles -- no BASELINE config): the ragged-end tile code beside the steady-state body does not fit 256 registers"),
+    (r"gl_shp_kernel<[13], 2, glk::KindList<1, 4>, glk::KindList<17>, \d, true, false>",
      "shapelet kernel WITH a lens-light component, table mode, gradient modes (the shapelets-demo model, not a BASELINE config): "
-     "14-19 VGPRs past the 256 of two waves per SIMD; measured 0.334 ms per 1024 (round-2 kernel: 0.383)"),
+     "16 VGPRs past the 256 of two waves per SIMD; measured 0.286 ms per 1024 at C3D (round-2 kernel: 0.383)"),
     (r"gl_shp_normal_kernel<5, 4, glk::KindList<1, 4>, 6, true>",
      "stack-free normal matrix, five tile rows, table mode: held to 128 VGPRs for four workgroups per CU at the price of two "
      "spilled registers outside the MFMA loop; measured 0.644 ms per 1024 C3L solves against 0.662 at 129 VGPRs / three per CU"),
