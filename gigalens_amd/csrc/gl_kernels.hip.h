@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) gl_prep_wave_kernel(const CompDesc* __res
     if (n_max <= SH_CAP)
       for (int e = lane; e < SH_SQ * SH_SQ; e += 64) {
         const int n1 = e / SH_SQ, n2 = e - n1 * SH_SQ, n = n1 + n2;
-        d[SHP_SQ + e] = n <= n_max ? p[3 + n * (n + 1) / 2 + n2] : 0.f;
+        d[SHP_SQ + e] = n <= n_max ? p[3 + n * (n + 1) / 2 + n2] * (SH_K[n1] * SH_K[n2]) : 0.f;  // scaled for the monic basis of gl_shp.hip.h
       }
   }
   for (int c = 0; c < n_comp; ++c) {  // wave-uniform: every lane joins the table of every EPL lens

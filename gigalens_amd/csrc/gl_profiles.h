@@ -64,6 +64,11 @@ enum { SHP_CX = 0, SHP_CY, SHP_IB, SHP_NMAX, SHP_AMP = 4 };
 // SH_SQ columns -- gl_shp.hip.h reads its rows as SGPR pairs (n2 = 2j, 2j + 1)
 constexpr int SH_SQ = 12;
 constexpr int SHP_SQ = SHP_AMP + ((SH_MAXL + 3) & ~3);
+// phi_n = SH_K[n] P_n with the monic recurrence P_{n+1} = u P_n - (n / 2) P_{n-1} (SH_K[n] = sqrt(2^n / n!)): gl_shp.hip.h advances
+// P -- two instructions per order instead of three -- and the square matrix behind SHP_SQ holds a(n1, n2) SH_K[n1] SH_K[n2]
+constexpr float SH_K[12] = {1.f, 1.4142135623730951f, 1.4142135623730951f, 1.1547005383792515f, 0.81649658092772603f,
+                            0.5163977794943222f, 0.29814239699997197f, 0.15936381457791915f, 0.079681907288959575f,
+                            0.037562411321267405f, 0.016798421022632321f, 0.007162870791336714f};
 enum { SHPA_CX = 0, SHPA_CY, SHPA_IB, SHPA_AMP = 3 };
 
 GL_HD int sh_layers(int n_max) { return (n_max + 1) * (n_max + 2) / 2; }
@@ -770,7 +775,7 @@ template <class R> GL_HD void shapelets_prep(const R* p, int n_max, R* d) {
   for (int n1 = 0; n1 < SH_SQ; ++n1)
     for (int n2 = 0; n2 < SH_SQ; ++n2) {
       const int n = n1 + n2;
-      d[SHP_SQ + n1 * SH_SQ + n2] = n <= n_max ? p[3 + n * (n + 1) / 2 + n2] : (R)0;
+      d[SHP_SQ + n1 * SH_SQ + n2] = n <= n_max ? p[3 + n * (n + 1) / 2 + n2] * (R)(SH_K[n1] * SH_K[n2]) : (R)0;
     }
 }
 

@@ -51,7 +51,7 @@ template <int NP> struct ShpPix { float S, Su, Sv, u, v, dx, dy, fac; };  // wha
 // generated too: their amplitudes are zeros of the padded matrix, their gradient entries and normal-matrix channels never stored.
 struct ShpNodeGen {
   static constexpr float top = (float)(SH_NODES - 1), h = 10.f / top;
-  v2f u0, t, Vp, Dp, Vc, Dc;
+  v2f u0, u1, t, Vp, Dp, Vc, Dc;
   __device__ __forceinline__ void init(float u, float v) {
     const v2f fi = (v2f{u, v} + 5.f) * (top / 10.f);
     const bool live = (fi.x >= 0.f) && (fi.x <= top) && (fi.y >= 0.f) && (fi.y <= top);  // NaN: not live
@@ -59,6 +59,7 @@ struct ShpNodeGen {
     const v2f fb = v2f{fmin_(floor_(fic.x), top - 1.f), fmin_(floor_(fic.y), top - 1.f)};  // the last node belongs to the last interval (t = 1)
     t = fic - fb;
     u0 = (fb - 0.5f * top) * h;  // node below: (i - 2999.5) h, symmetric about 0
+    u1 = u0 + h;
     const v2f e0 = exp2_(u0 * u0 * (float)(-0.5 * kLog2e));
     const v2f z = __builtin_elementwise_fma(u0, v2f(-h), v2f(-0.5f * h * h));  // -(u1^2 - u0^2) / 2 with u1 = u0 + h; |z| < 8.4e-3
     v2f em1 = __builtin_elementwise_fma(z, v2f(1.f / 6.f), v2f(0.5f));
@@ -70,24 +71,20 @@ struct ShpNodeGen {
   }
   __device__ __forceinline__ v2f value() const { return __builtin_elementwise_fma(t, Dc, Vc); }
   __device__ __forceinline__ v2f slope() const { return Dc; }
-  __device__ __forceinline__ void advance(int n) {  // order n -> n + 1 (n a compile-time constant after unrolling)
-    const float an = (float)__builtin_sqrt(2.0 / (n + 1)), bn = (float)__builtin_sqrt((double)n / (n + 1)), ah = an * h;
-    const v2f au0 = u0 * an, au1 = au0 + ah;
-    v2f vn, dn;
-    if (n == 0) {
-      vn = au0 * Vc;
-      dn = __builtin_elementwise_fma(au1, Dc, Vc * ah);
-    } else {
-      vn = __builtin_elementwise_fma(au0, Vc, -(Vp * bn));
-      dn = __builtin_elementwise_fma(au1, Dc, -(Dp * bn));
-      dn = __builtin_elementwise_fma(v2f(ah), Vc, dn);
-    }
+  // order n -> n + 1 (n a compile-time constant after unrolling), in the monic scaling phi_n = SH_K[n] P_n:
+  //   P_{n+1} = u0 P_n - (n / 2) P_{n-1},      Q_{n+1} = (u0 + h) Q_n - (n / 2) Q_{n-1} + h P_n      (Q: difference to the next node)
+  __device__ __forceinline__ void advance(int n) {
+    const float bn = 0.5f * (float)n;
+    const v2f vn = n == 0 ? u0 * Vc : __builtin_elementwise_fma(u0, Vc, -(Vp * bn));
+    v2f dn = n == 0 ? u1 * Dc : __builtin_elementwise_fma(u1, Dc, -(Dp * bn));
+    dn = __builtin_elementwise_fma(v2f(h), Vc, dn);
     Vp = Vc; Dp = Dc;
     Vc = vn; Dc = dn;
   }
 };
 
-// direct mode (shapelets.py:67-85): normalised Hermite recurrence, X'_n = sqrt(2n) X_{n-1}
+// direct mode (shapelets.py:67-85): the Hermite polynomial part without the Gaussian, same monic scaling; X'_n = sqrt(2n) X_{n-1}
+// becomes P'_n = n P_{n-1}
 struct ShpDirectGen {
   v2f uv, Vp, Vc, Dc;
   __device__ __forceinline__ void init(float u, float v) {
@@ -98,11 +95,9 @@ struct ShpDirectGen {
   }
   __device__ __forceinline__ v2f value() const { return Vc; }
   __device__ __forceinline__ v2f slope() const { return Dc; }
-  __device__ __forceinline__ void advance(int n) {
-    const float an = (float)__builtin_sqrt(2.0 / (n + 1)), bn = (float)__builtin_sqrt((double)n / (n + 1));
-    const v2f au = uv * an;
-    const v2f vn = n == 0 ? au * Vc : __builtin_elementwise_fma(au, Vc, -(Vp * bn));
-    Dc = Vc * (float)__builtin_sqrt(2.0 * (n + 1));
+  __device__ __forceinline__ void advance(int n) {  // P_{n+1} = u P_n - (n / 2) P_{n-1},  P'_{n+1} = (n + 1) P_n
+    const v2f vn = n == 0 ? uv * Vc : __builtin_elementwise_fma(uv, Vc, -(Vp * (0.5f * (float)n)));
+    Dc = Vc * (float)(n + 1);
     Vp = Vc;
     Vc = vn;
   }
@@ -165,17 +160,18 @@ __device__ __forceinline__ float shp_pixel_fwd(const float* d, const v2f* __rest
   }
   if constexpr (GRAD) *reinterpret_cast<v2f*>(buf + (NO - 1) * SHX_PLANE) = v2f(0.f);  // the pad order (NO = 2 NP serves n_max <= NO - 2)
   st.fac = INTERP ? 1.f : exp_(-(st.u * st.u + st.v * st.v) * 0.5f);  // shapelets.py:70
-  float S = 0.f, Su = 0.f, Sv = 0.f;
+  v2f SSv = v2f(0.f);  // (S, dS/dv): (Y_n2, Y'_n2) against s_n2
+  float Su = 0.f;
 #pragma unroll
   for (int n2 = 0; n2 < NO - 1; ++n2) {
     const float sn = (n2 & 1) ? s[n2 >> 1].y : s[n2 >> 1].x;
-    S = __builtin_fmaf(yk[n2].x, sn, S);
+    SSv = __builtin_elementwise_fma(yk[n2], v2f(sn), SSv);
     if (GRAD) {
       const float sdn = (n2 & 1) ? sd[n2 >> 1].y : sd[n2 >> 1].x;
       Su = __builtin_fmaf(yk[n2].x, sdn, Su);
-      Sv = __builtin_fmaf(yk[n2].y, sn, Sv);
     }
   }
+  const float S = SSv.x, Sv = SSv.y;
   st.S = S;
   if (GRAD) { st.Su = Su; st.Sv = Sv; }
   return st.fac * st.S;
@@ -491,7 +487,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       while ((n + 1) * (n + 2) / 2 <= i) ++n;
       const int n2 = i - n * (n + 1) / 2, n1 = n - n2;
       const float* t = s_g + n1 * 17 + n2;
-      out[shp.a_off + SHPA_AMP + i] = (t[0] + t[16 * 17]) + (t[2 * 16 * 17] + t[3 * 16 * 17]);
+      // the planes hold the monic basis: G(n1, n2) = SH_K[n1] SH_K[n2] sum gS P_n1 P_n2
+      out[shp.a_off + SHPA_AMP + i] = ((t[0] + t[16 * 17]) + (t[2 * 16 * 17] + t[3 * 16 * 17])) * (SH_K[n1] * SH_K[n2]);
     }
   }
 }
@@ -617,7 +614,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
         gen.init(ps.u, ps.v);
 #pragma unroll
         for (int n = 0; n < NO - 1; ++n) {
-          v2f xy = gen.value() * xs;
+          v2f xy = gen.value() * (xs * SH_K[n]);  // phi_n = SH_K[n] P_n: the channels of the normal matrix are the normalised bases
           xy.x = xy.x == xy.x ? xy.x : 0.f;  // NaN -> 0 like the stack (tf/simulator.py:140 on each basis image)
           *reinterpret_cast<v2f*>(wr_xy + n * SHN_PLANE) = xy;
           if (n + 1 < NO - 1) gen.advance(n);
