@@ -79,7 +79,7 @@ if rows_sp:
         sp["pair"] = {"algorithmic_bytes_B1": b1, "achieved_GBps": b1 / t / 1e9, "frac_of_8TBps": b1 / t / 8e12,
                       "hbm_bytes_measured": sp["fwd"]["hbm_bytes_per_launch"] + sp["bwd"]["hbm_bytes_per_launch"]}
 summary["simulate_pair_C2"] = sp
-c3l = summary["pmc_C3L"] = pmc("pmc_C3L", kernel_filter=("gl_normal_mfma_kernel",))
+c3l = summary["pmc_C3L"] = pmc("pmc_C3L", kernel_filter=("gl_shp_normal_kernel", "gl_normal_mfma_kernel"))  # stack-free kernel (round 3) / SYRK
 if c3l.get("SQ_VALU_MFMA_BUSY_CYCLES") and c3l.get("GRBM_GUI_ACTIVE"):
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles over all SIMDs (MI355X_MICROARCH.md, PMC units); 1024 SIMDs
     c3l["mfma_busy_frac"] = c3l["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c3l["GRBM_GUI_ACTIVE"] / 8.0)
