@@ -64,8 +64,12 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   const int p1 = min(p0 + a.chunk, a.N);
   // One tile = W*256 pixels.  CHECK=false is the steady state (whole tile inside the chunk, no pixel mask):
   // no validity selects, no weights.  CHECK=true handles the ragged last tile and img_region weights.
-  auto tile = [&](int base, auto check_tag) {
+  // err_tag: 0 no error map, 1 error map (both compile the variance and the cotangent of their own case: as a run-time choice the
+  // two were computed side by side and selected, 10 instructions per pixel pair), 2 decided at run time (the ragged-end tile)
+  auto tile = [&](int base, auto check_tag, auto err_tag) {
     constexpr bool CHECK = decltype(check_tag)::value;
+    constexpr int ERR = decltype(err_tag)::value;
+    const bool herr = ERR == 2 ? has_err : ERR == 1;
     unsigned jj[W], pidx[W];
     bool valid[W];
     V x, y, vmask = V(1.f);
@@ -131,15 +135,15 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
       if constexpr (W == 2) {
         o = V{ldf(a.obs, po[0]), ldf(a.obs, po[1])};
         if (CHECK && has_mask) w = w * V{ldf(a.mask, po[0]), ldf(a.mask, po[1])};
-        if (has_err) e = V{ldf(a.err, po[0]), ldf(a.err, po[1])};
+        if (herr) e = V{ldf(a.err, po[0]), ldf(a.err, po[1])};
       } else {
         o = ldf(a.obs, po[0]);
         if (CHECK && has_mask) w = w * ldf(a.mask, po[0]);
-        if (has_err) e = ldf(a.err, po[0]);
+        if (herr) e = ldf(a.err, po[0]);
       }
       // tf/model.py:92-99; sigma^2 = bg^2 + m/t (no clip: negative -> NaN like sqrt of a negative)
       V dmo = m - o;
-      V s2 = has_err ? e * e : m * a.inv_t + a.bg2;
+      V s2 = herr ? e * e : m * a.inv_t + a.bg2;
       V is2 = rcp(s2);
       V nm = vlog<V>(s2 * (float)(2 * kPi));  // NaN for sigma^2 < 0, like log(2 pi sqrt(.)^2) in the reference
       V c2 = __builtin_elementwise_fma(nm, V(0.f), dmo * dmo * is2);  // + 0 * nm: carries that NaN into chi^2
@@ -152,7 +156,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
         st1 += nm;
       }
       if (MODE == LL_GRAD) {
-        V g = has_err ? -(dmo * is2) : (dmo * dmo * is2 - 1.f) * (is2 * (0.5f * a.inv_t)) - dmo * is2;
+        V g = herr ? -(dmo * is2) : (dmo * dmo * is2 - 1.f) * (is2 * (0.5f * a.inv_t)) - dmo * is2;
         gm = nanp ? V(0.f) : (CHECK ? g * w : g) * a.out_scale;
       }
     }
@@ -186,9 +190,13 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
     const bool plain = !has_mask && !has_pix;
     int base = p0;
     if (GL_DBG(a.dbg, 1)) base = p1;
-    if (plain)
-      for (; base + WG * W <= p1; base += WG * W) tile(base, std::false_type{});
-    for (; base < p1; base += WG * W) tile(base, std::true_type{});
+    if (plain) {
+      if (has_err)
+        for (; base + WG * W <= p1; base += WG * W) tile(base, std::false_type{}, std::integral_constant<int, 1>{});
+      else
+        for (; base + WG * W <= p1; base += WG * W) tile(base, std::false_type{}, std::integral_constant<int, 0>{});
+    }
+    for (; base < p1; base += WG * W) tile(base, std::true_type{}, std::integral_constant<int, 2>{});
   }
   if (MODE == IMG_FWD) return;
   float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;

@@ -246,12 +246,11 @@ class CFG:
         return d
 
 
-def pair_model(cfg, mean_series_pairs, frac_odd, W=2, frac_short=0.0):
+def pair_model(cfg, mean_series_pairs, frac_odd, W=2, frac_short=0.0, error_map=False):
     """Execution model of gl_pair_kernel / gl_static_kernel in a likelihood / gradient mode, steady state.
 
-    The pixel loop of the CHECK=false instantiation is the FIRST outermost loop that contains an inner loop (the EPL
-    series loop) -- for models without EPL, the outermost loop with the most flops; every trip processes W pixels per
-    lane.  Its blocks are weighted as follows:
+    The pixel loop of the CHECK=false instantiation is the first (with `error_map`) or second outermost loop with a substantial
+    body; every trip processes W pixels per lane.  Its blocks are weighted as follows:
       * blocks that dominate the loop's latch run once per trip,
       * the inner loop (two series terms per trip) runs `mean_series_pairs` times on average,
       * a conditional block behind the inner loop holding >= 4 packed FMAs is the term the two-term loop leaves over:
@@ -261,9 +260,10 @@ def pair_model(cfg, mean_series_pairs, frac_odd, W=2, frac_short=0.0):
         the blocks of that bypass with probability `frac_short`,
       * other conditional blocks (optional loads of the mask / error planes: <= 3 VALU, no flops) are counted as executed.
     Returns per-lane flops and VALU wave-instructions per PIXEL, and the decomposition."""
-    tops = [l for l in cfg.loops if l.parent is None]
-    cands = [l for l in tops if l.children]
-    tile = cands[0] if cands else max(tops, key=lambda l: cfg.tally(l.blocks)["flops"])
+    # likelihood modes compile the steady-state tile twice, in address order: with an error map, without one (gl_pair.hip.h err_tag),
+    # then the ragged-end tile; image modes have the one steady-state loop and the ragged one
+    hot = _hot_loops(cfg)
+    tile = hot[0 if error_map or len(hot) < 3 else 1]
     inner = sorted(tile.children, key=lambda l: l.header)
     inner_blocks = set().union(*[c.blocks for c in inner]) if inner else set()
     own = tile.blocks - inner_blocks
@@ -411,7 +411,7 @@ def execution_model(co, name, md, series, p_live=None):
     cfg = CFG(ins)
     s = series or {}
     per_pixel, detail = pair_model(cfg, float(s.get("mean_pair_trips", 0.0)), float(s.get("frac_odd", 0.0)), W,
-                                   float(s.get("frac_short", 0.0)))
+                                   float(s.get("frac_short", 0.0)), bool(s.get("error_map", False)))
     return dict(flops_per_pixel=round(per_pixel["flops"], 2), valu_insts_per_pixel=round(per_pixel["valu"], 2),
                 trans_per_pixel=round(per_pixel["trans"], 2), packed_insts_per_pixel=round(per_pixel["packed"], 2),
                 flop_weights="v_pk_fma 4, v_pk_mul/add 2, v_fma 2, v_mul/add/sub 1, transcendental 1, other 0 (per lane)",
