@@ -93,6 +93,11 @@ SYMBOLS = {
                                   c_void_p, c_int, c_void_p, c_void_p]),
     "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
+    "gl_user_profile_check": (c_int, [ctypes.c_char_p, c_int, c_int]),
+    "gl_user_profile_create": (c_int, [ctypes.c_char_p, c_int, c_int, POINTER(c_void_p)]),
+    "gl_user_profile_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
+    "gl_user_profile_destroy": (None, [c_void_p]),
     "gl_profile_hessian": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p]),
     "gl_kind_num_params": (c_int, [POINTER(gl_component)]),
@@ -153,10 +158,99 @@ def component_of(profile):
     kind, iparam, flags = profile._component()
     if not kind:
         raise NativeLibraryError(
-            f"profile {getattr(profile, 'name', type(profile).__name__)!r} has no gl_kind: user-defined deriv / light bodies are "
-            "not supported -- the profile maths lives in the HIP library (adding a profile means adding a kind: "
-            "gigalens_amd/csrc/gl_profiles.h and the dispatch switches of gl_kernels.hip.h; see INTEGRATION.md)")
+            f"profile {getattr(profile, 'name', type(profile).__name__)!r} has no gl_kind: user-defined deriv / light bodies "
+            "written in Python cannot run here, and the pixel kernels of LensSimulator take built-in kinds only (adding one means "
+            "adding a kind: gigalens_amd/csrc/gl_profiles.h and the dispatch switches of gl_kernels.hip.h).  For the plugin-level "
+            "calls (deriv / light on points, differentiable) give the class a `hip_body`: one HIP C++ function template that "
+            "the library compiles at run time (include/gigalens_hip.h gl_user_profile_create; see INTEGRATION.md)")
     return gl_component(kind, iparam, flags, 0)
+
+
+# --------------------------------------------------------------------------------------------------
+# user-written profile bodies (profile.py: `hip_body`), compiled once per (body, kind, parameter count) by hiprtc
+# --------------------------------------------------------------------------------------------------
+class _UserProfile:
+    def __init__(self, body, is_light, n_params):
+        h = c_void_p()
+        _check(lib().gl_user_profile_create(body.encode(), int(is_light), int(n_params), ctypes.byref(h)))
+        self._h, self.is_light, self.n_params = h, bool(is_light), int(n_params)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().gl_user_profile_destroy(self._h)
+        except Exception:
+            pass
+
+
+_USER_PROFILES = {}
+
+
+def user_profile_of(profile):
+    from gigalens_amd.profile import LightProfile
+    body = getattr(profile, "hip_body", None)
+    if not body:
+        return None
+    device()
+    is_light = isinstance(profile, LightProfile)
+    key = (body, is_light, len(profile.params))
+    if key not in _USER_PROFILES:
+        _USER_PROFILES[key] = _UserProfile(body, is_light, len(profile.params))
+    return _USER_PROFILES[key]
+
+
+def user_profile_check(body, is_light, n_params):
+    """Compile a body without a GPU (gl_user_profile_check); raises NativeLibraryError with the compiler's message."""
+    _check(lib().gl_user_profile_check(body.encode(), int(bool(is_light)), int(n_params)))
+
+
+class _UserEval(torch.autograd.Function):
+    """Values of a compiled user body on points [n_pts, B] with parameters [B, n]; when a gradient is wanted the same launch
+    returns the Jacobian with respect to (x, y, parameters) from forward-mode duals, and backward contracts it."""
+
+    @staticmethod
+    def forward(ctx, up, xb, yb, P):
+        n_pts, B = xb.shape
+        n_out = 1 if up.is_light else 2
+        out0 = torch.empty_like(xb)
+        out1 = None if up.is_light else torch.empty_like(xb)
+        need = any(ctx.needs_input_grad[1:])
+        jac = torch.empty((n_out, up.n_params + 2, n_pts, B), dtype=torch.float32, device=xb.device) if need else None
+        _check(lib().gl_user_profile_eval(up._h, _ptr(xb), _ptr(yb), n_pts, B, 1, _ptr(P), _ptr(out0), _ptr(out1), _ptr(jac),
+                                          _stream()))
+        ctx.jac = jac
+        return (out0,) if up.is_light else (out0, out1)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        J = ctx.jac
+        g = torch.stack([torch.zeros_like(J[0, 0]) if gi is None else gi for gi in gs], dim=0)  # [n_out, n_pts, B]
+        full = (g[:, None] * J).sum(dim=0)                                                           # [n + 2, n_pts, B]
+        gP = full[2:].sum(dim=1).transpose(0, 1).contiguous() if J.shape[1] > 2 else None            # [B, n]
+        return None, full[0], full[1], gP
+
+
+def _user_eval(up, profile, x, y, kwargs):
+    dev = device()
+    names = list(profile.params)
+    missing = [n for n in names if n not in kwargs]
+    if missing:
+        raise TypeError(f"{profile.name}: missing parameters {missing}")
+    x = torch.as_tensor(x, dtype=torch.float32, device=dev)
+    y = torch.as_tensor(y, dtype=torch.float32, device=dev)
+    vals = [torch.as_tensor(kwargs[n], dtype=torch.float32, device=dev) for n in names]
+    out_shape = torch.broadcast_shapes(x.shape, y.shape, *[v.shape for v in vals])
+    B = out_shape[-1] if len(out_shape) else 1
+    for n, v in zip(names, vals):
+        if v.dim() > 1 and any(s != 1 for s in v.shape[:-1]):
+            raise NativeLibraryError(f"{profile.name}.{n}: parameters may only vary along the last (batch) axis")
+    if vals:
+        P = torch.stack([v.reshape(-1)[-B:].expand(B) if v.numel() > 1 else v.reshape(()).expand(B) for v in vals], dim=1).contiguous()
+    else:
+        P = torch.zeros((B, 0), dtype=torch.float32, device=dev)
+    xb = x.expand(out_shape).reshape(-1, B).contiguous()
+    yb = y.expand(out_shape).reshape(-1, B).contiguous()
+    return tuple(o.reshape(out_shape) for o in _UserEval.apply(up, xb, yb, P))
 
 
 def device():
@@ -280,6 +374,9 @@ def profile_hessian(profile, x, y, kwargs):
 
 
 def profile_eval(profile, x, y, kwargs):
+    up = user_profile_of(profile) if not profile._component()[0] else None
+    if up is not None:
+        return _user_eval(up, profile, x, y, kwargs)
     dev = device()
     comp = component_of(profile)
     names = list(profile.params)

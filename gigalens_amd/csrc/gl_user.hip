@@ -1,0 +1,241 @@
+// gl_user.hip -- the open plugin boundary: profile bodies written by the USER, compiled at run time into a point kernel.
+//
+// The reference's extension point is a Python subclass: MassProfile.deriv / LightProfile.light are abstract (profile.py:58-82) and
+// a user writes them in TensorFlow.  Here a profile is normally a gl_kind the library implements; this file opens the same door
+// for the plugin-level calls (deriv / light on arbitrary points, with derivatives): the user supplies ONE function template in
+// HIP C++ over a number type R,
+//     template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy);     // mass profile: deflection
+//     template <class R> __device__ R    light(R x, R y, const R* p);                   // light profile: surface brightness
+// hiprtc compiles it once for gfx950 together with a forward-mode dual number type (namespace gl: arithmetic, comparisons, sqrt
+// exp log pow sin cos tan atan atan2 sinh cosh tanh atanh abs, found by argument-dependent lookup, so the body just writes
+// sqrt(x)) and a kernel that instantiates it on float (values) and on gl::Dual<n_params + 2> (values and the Jacobian with
+// respect to x, y and every parameter in one pass).  Nothing is refused but compile errors, which come back verbatim.
+// The pixel kernels of the likelihood path still take built-in kinds only (gl_model_create): see INTEGRATION.md.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gigalens_hip.h"
+#include "gl_model.h"
+
+namespace {
+
+const char* kPrelude = R"GLSRC(
+namespace gl {
+template <int N> struct Dual {
+  float v;
+  float d[N];
+  __device__ Dual() : v(0.f) { for (int i = 0; i < N; ++i) d[i] = 0.f; }
+  __device__ Dual(float x) : v(x) { for (int i = 0; i < N; ++i) d[i] = 0.f; }
+  __device__ Dual(double x) : v((float)x) { for (int i = 0; i < N; ++i) d[i] = 0.f; }
+  __device__ Dual(int x) : v((float)x) { for (int i = 0; i < N; ++i) d[i] = 0.f; }
+  __device__ static Dual var(float x, int k) { Dual r(x); r.d[k] = 1.f; return r; }
+};
+// f(a) with derivative fp:  chain rule
+template <int N> __device__ inline Dual<N> chain(const Dual<N>& a, float f, float fp) {
+  Dual<N> r; r.v = f; for (int i = 0; i < N; ++i) r.d[i] = fp * a.d[i]; return r;
+}
+template <int N> __device__ inline Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> __device__ inline Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> __device__ inline Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> __device__ inline Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+  const float ib = 1.f / b.v, q = a.v * ib;
+  Dual<N> r; r.v = q; for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - q * b.d[i]) * ib; return r;
+}
+template <int N> __device__ inline Dual<N> operator-(const Dual<N>& a) { Dual<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+template <int N> __device__ inline Dual<N> operator+(const Dual<N>& a) { return a; }
+#define GL_MIXED(OP)                                                                                                   \
+  template <int N, class S> __device__ inline auto operator OP(const Dual<N>& a, S b) -> decltype(a OP Dual<N>((float)b)) { return a OP Dual<N>((float)b); } \
+  template <int N, class S> __device__ inline auto operator OP(S a, const Dual<N>& b) -> decltype(Dual<N>((float)a) OP b) { return Dual<N>((float)a) OP b; }
+GL_MIXED(+) GL_MIXED(-) GL_MIXED(*) GL_MIXED(/)
+#undef GL_MIXED
+template <int N> __device__ inline Dual<N>& operator+=(Dual<N>& a, const Dual<N>& b) { a = a + b; return a; }
+template <int N> __device__ inline Dual<N>& operator-=(Dual<N>& a, const Dual<N>& b) { a = a - b; return a; }
+template <int N> __device__ inline Dual<N>& operator*=(Dual<N>& a, const Dual<N>& b) { a = a * b; return a; }
+template <int N> __device__ inline Dual<N>& operator/=(Dual<N>& a, const Dual<N>& b) { a = a / b; return a; }
+template <int N, class S> __device__ inline Dual<N>& operator+=(Dual<N>& a, S b) { a.v += (float)b; return a; }
+template <int N, class S> __device__ inline Dual<N>& operator-=(Dual<N>& a, S b) { a.v -= (float)b; return a; }
+template <int N, class S> __device__ inline Dual<N>& operator*=(Dual<N>& a, S b) { a = a * Dual<N>((float)b); return a; }
+template <int N, class S> __device__ inline Dual<N>& operator/=(Dual<N>& a, S b) { a = a / Dual<N>((float)b); return a; }
+#define GL_CMP(OP)                                                                                           \
+  template <int N> __device__ inline bool operator OP(const Dual<N>& a, const Dual<N>& b) { return a.v OP b.v; } \
+  template <int N, class S> __device__ inline bool operator OP(const Dual<N>& a, S b) { return a.v OP (float)b; } \
+  template <int N, class S> __device__ inline bool operator OP(S a, const Dual<N>& b) { return (float)a OP b.v; }
+GL_CMP(<) GL_CMP(>) GL_CMP(<=) GL_CMP(>=) GL_CMP(==) GL_CMP(!=)
+#undef GL_CMP
+template <int N> __device__ inline Dual<N> sqrt(const Dual<N>& a) { const float s = ::sqrtf(a.v); return chain(a, s, 0.5f / s); }
+template <int N> __device__ inline Dual<N> exp(const Dual<N>& a) { const float e = ::expf(a.v); return chain(a, e, e); }
+template <int N> __device__ inline Dual<N> log(const Dual<N>& a) { return chain(a, ::logf(a.v), 1.f / a.v); }
+template <int N> __device__ inline Dual<N> sin(const Dual<N>& a) { return chain(a, ::sinf(a.v), ::cosf(a.v)); }
+template <int N> __device__ inline Dual<N> cos(const Dual<N>& a) { return chain(a, ::cosf(a.v), -::sinf(a.v)); }
+template <int N> __device__ inline Dual<N> tan(const Dual<N>& a) { const float t = ::tanf(a.v); return chain(a, t, 1.f + t * t); }
+template <int N> __device__ inline Dual<N> atan(const Dual<N>& a) { return chain(a, ::atanf(a.v), 1.f / (1.f + a.v * a.v)); }
+template <int N> __device__ inline Dual<N> sinh(const Dual<N>& a) { return chain(a, ::sinhf(a.v), ::coshf(a.v)); }
+template <int N> __device__ inline Dual<N> cosh(const Dual<N>& a) { return chain(a, ::coshf(a.v), ::sinhf(a.v)); }
+template <int N> __device__ inline Dual<N> tanh(const Dual<N>& a) { const float t = ::tanhf(a.v); return chain(a, t, 1.f - t * t); }
+template <int N> __device__ inline Dual<N> atanh(const Dual<N>& a) { return chain(a, ::atanhf(a.v), 1.f / (1.f - a.v * a.v)); }
+template <int N> __device__ inline Dual<N> abs(const Dual<N>& a) { return a.v < 0.f ? -a : a; }
+template <int N> __device__ inline Dual<N> fabs(const Dual<N>& a) { return a.v < 0.f ? -a : a; }
+template <int N> __device__ inline Dual<N> atan2(const Dual<N>& y, const Dual<N>& x) {
+  const float r2 = x.v * x.v + y.v * y.v, ir2 = 1.f / r2;
+  Dual<N> r; r.v = ::atan2f(y.v, x.v); for (int i = 0; i < N; ++i) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) * ir2; return r;
+}
+template <int N> __device__ inline Dual<N> pow(const Dual<N>& a, const Dual<N>& b) {  // a > 0
+  const float p = ::powf(a.v, b.v), la = ::logf(a.v);
+  Dual<N> r; r.v = p; for (int i = 0; i < N; ++i) r.d[i] = p * (b.d[i] * la + b.v * a.d[i] / a.v); return r;
+}
+template <int N, class S> __device__ inline Dual<N> pow(const Dual<N>& a, S b) { const float e = (float)b; return chain(a, ::powf(a.v, e), e * ::powf(a.v, e - 1.f)); }
+template <int N, class S> __device__ inline Dual<N> pow(S a, const Dual<N>& b) { const float p = ::powf((float)a, b.v); return chain(b, p, p * ::logf((float)a)); }
+template <int N> __device__ inline Dual<N> fmin(const Dual<N>& a, const Dual<N>& b) { return a.v < b.v ? a : b; }
+template <int N> __device__ inline Dual<N> fmax(const Dual<N>& a, const Dual<N>& b) { return a.v > b.v ? a : b; }
+// the value of a number, for branches the body wants to take on plain floats
+__device__ inline float value(float a) { return a; }
+template <int N> __device__ inline float value(const Dual<N>& a) { return a.v; }
+}  // namespace gl
+)GLSRC";
+
+const char* kKernel = R"GLSRC(
+extern "C" __global__ void __launch_bounds__(256) gl_user_point_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n,
+                                                                       int B, int xy_batched, const float* __restrict__ params,
+                                                                       float* __restrict__ out0, float* __restrict__ out1,
+                                                                       float* __restrict__ jac) {
+  constexpr int NPAR = GL_USER_NP, N = GL_USER_NP + 2;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x, total = n * (long long)B;
+  if (i >= total) return;
+  const int b = (int)(i % B);
+  const long long ip = xy_batched ? i : i / B;
+  const float* p = params + (size_t)b * NPAR;
+  if (!jac) {
+    float pp[NPAR > 0 ? NPAR : 1];
+    for (int k = 0; k < NPAR; ++k) pp[k] = p[k];
+#if GL_USER_LIGHT
+    out0[i] = light<float>(x[ip], y[ip], pp);
+#else
+    float fx = 0.f, fy = 0.f;
+    deriv<float>(x[ip], y[ip], pp, fx, fy);
+    out0[i] = fx;
+    out1[i] = fy;
+#endif
+    return;
+  }
+  typedef gl::Dual<N> D;
+  D pp[NPAR > 0 ? NPAR : 1];
+  for (int k = 0; k < NPAR; ++k) pp[k] = D::var(p[k], 2 + k);
+  const D X = D::var(x[ip], 0), Y = D::var(y[ip], 1);
+#if GL_USER_LIGHT
+  const D f = light<D>(X, Y, pp);
+  out0[i] = f.v;
+  for (int j = 0; j < N; ++j) jac[(size_t)j * total + i] = f.d[j];
+#else
+  D fx, fy;
+  deriv<D>(X, Y, pp, fx, fy);
+  out0[i] = fx.v;
+  out1[i] = fy.v;
+  for (int j = 0; j < N; ++j) {
+    jac[(size_t)j * total + i] = fx.d[j];
+    jac[(size_t)(N + j) * total + i] = fy.d[j];
+  }
+#endif
+}
+)GLSRC";
+
+}  // namespace
+
+struct gl_user_profile {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+  int is_light = 0, n_params = 0;
+};
+
+namespace {
+// body -> gfx950 code object (no device needed); GL_OK or the compiler's own words
+int compile_user_profile(const char* body, int is_light, int n_params, std::vector<char>& code) {
+  using glk::fail;
+  if (!body) return fail(GL_EINVAL, "body is null");
+  if (n_params < 0 || n_params > 62) return fail(GL_EINVAL, "n_params %d outside [0, 62]", n_params);
+  std::string src = std::string(kPrelude) + "\n#line 1 \"user_profile\"\n" + body + "\n" + kKernel;
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "gl_user_profile.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    return fail(GL_ELAUNCH, "hiprtcCreateProgram failed");
+  const std::string d_np = "-DGL_USER_NP=" + std::to_string(n_params), d_l = std::string("-DGL_USER_LIGHT=") + (is_light ? "1" : "0");
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", d_np.c_str(), d_l.c_str()};
+  const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    (void)hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n ? n : 1, '\0');
+    if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+    (void)hiprtcDestroyProgram(&prog);
+    // the first error line onward, as much as the message buffer holds
+    const size_t at = log.find("error");
+    const size_t from = at == std::string::npos ? 0 : log.rfind('\n', at) == std::string::npos ? 0 : log.rfind('\n', at) + 1;
+    return fail(GL_EINVAL, "user profile does not compile (%s):\n%.380s", hiprtcGetErrorString(rc), log.c_str() + from);
+  }
+  size_t code_size = 0;
+  if (hiprtcGetCodeSize(prog, &code_size) != HIPRTC_SUCCESS || !code_size) {
+    (void)hiprtcDestroyProgram(&prog);
+    return fail(GL_ELAUNCH, "hiprtcGetCodeSize failed");
+  }
+  code.resize(code_size);
+  const hiprtcResult rc2 = hiprtcGetCode(prog, code.data());
+  (void)hiprtcDestroyProgram(&prog);
+  if (rc2 != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcGetCode failed");
+  return GL_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int gl_user_profile_check(const char* body, int is_light, int n_params) {
+  std::vector<char> code;
+  return compile_user_profile(body, is_light, n_params, code);
+}
+
+int gl_user_profile_create(const char* body, int is_light, int n_params, gl_user_profile** out) {
+  using glk::fail;
+  if (!out) return fail(GL_EINVAL, "out is null");
+  *out = nullptr;
+  std::vector<char> code;
+  if (int rc = compile_user_profile(body, is_light, n_params, code)) return rc;
+  gl_user_profile* u = new gl_user_profile;
+  u->is_light = is_light ? 1 : 0;
+  u->n_params = n_params;
+  hipError_t e = hipModuleLoadData(&u->module, code.data());
+  if (e == hipSuccess) e = hipModuleGetFunction(&u->fn, u->module, "gl_user_point_kernel");
+  if (e != hipSuccess) {
+    if (u->module) (void)hipModuleUnload(u->module);
+    delete u;
+    return fail(GL_ELAUNCH, "loading the compiled user profile failed: %s", hipGetErrorString(e));
+  }
+  *out = u;
+  return GL_OK;
+}
+
+int gl_user_profile_eval(const gl_user_profile* u, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
+                         const float* params, float* out0, float* out1, float* jac_or_null, void* hip_stream) {
+  using glk::fail;
+  if (!u) return fail(GL_EINVAL, "user profile is null");
+  if (!x || !y || !out0 || (!u->is_light && !out1)) return fail(GL_EINVAL, "x / y / out is null");
+  if (u->n_params > 0 && !params) return fail(GL_EINVAL, "params is null");
+  if (n_pts < 0 || B < 1) return fail(GL_EINVAL, "bad n_pts / B");
+  if (n_pts == 0) return GL_OK;
+  long long n = n_pts;
+  const long long total = n * (long long)B;
+  if ((total + 255) / 256 > 0x7fffffffLL) return fail(GL_EINVAL, "too many points for one launch");
+  void* args[] = {(void*)&x, (void*)&y, (void*)&n, (void*)&B, (void*)&xy_batched, (void*)&params, (void*)&out0, (void*)&out1, (void*)&jac_or_null};
+  const hipError_t e = hipModuleLaunchKernel(u->fn, (unsigned)((total + 255) / 256), 1, 1, 256, 1, 1, 0, (hipStream_t)hip_stream, args, nullptr);
+  if (e != hipSuccess) return fail(GL_ELAUNCH, "launch of the user profile kernel failed: %s", hipGetErrorString(e));
+  return GL_OK;
+}
+
+void gl_user_profile_destroy(gl_user_profile* u) {
+  if (!u) return;
+  if (u->module) (void)hipModuleUnload(u->module);
+  delete u;
+}
+
+}  // extern "C"

@@ -16,6 +16,13 @@ class Parameterized(ABC):
     _name: str
     _params: List[str]
     _kind: int = 0  # gl_kind
+    # A profile the library has no kind for may carry its body instead (the reference's extension point, profile.py:58-82, is a
+    # subclass with a TensorFlow body): ONE HIP C++ function template over a number type R, compiled at run time,
+    #     template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy);   (MassProfile;  p = params in order)
+    #     template <class R> __device__ R    light(R x, R y, const R* p);                 (LightProfile; amplitude last)
+    # It serves the plugin-level calls -- deriv / light on points, differentiable through torch.autograd (forward-mode duals
+    # inside) -- see include/gigalens_hip.h gl_user_profile_create; LensSimulator's pixel kernels take built-in kinds only.
+    hip_body: str = ""
 
     def __init__(self, *args, **kwargs):
         self.name = self._name

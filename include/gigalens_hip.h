@@ -336,6 +336,25 @@ int gl_model_last_main_kernel(const gl_model* m, char* buf, size_t cap);
  * conditional blocks with. */
 int gl_model_launch_shape(const gl_model* m, int B, int* chunk_px, int* n_chunks, int* row_floats, size_t* partial_offset_bytes);
 
+/* ---- Open plugin boundary: user-written profile bodies (csrc/gl_user.hip) -------------------------------------------------------
+ * The reference's extension point is a Python subclass with a TensorFlow body: MassProfile.deriv / LightProfile.light are
+ * abstract (src/gigalens/profile.py:58-82).  Here the body is ONE function template in HIP C++ over a number type R,
+ *     template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy);     (mass profile: the deflection)
+ *     template <class R> __device__ R    light(R x, R y, const R* p);                   (light profile: surface brightness)
+ * with p = the profile's n_params parameters in their declared order.  hiprtc compiles it once for gfx950 with a forward-mode
+ * dual number (arithmetic, comparisons, sqrt exp log pow sin cos tan atan atan2 sinh cosh tanh atanh abs fmin fmax resolve by
+ * argument-dependent lookup; gl::value(r) gives the plain float of a number for branches).  Compile errors come back verbatim
+ * through gl_last_error (GL_EINVAL).  gl_user_profile_check compiles only (no device needed).
+ *   eval: x, y [n_pts] or [n_pts,B] (xy_batched), params [B,n_params], out0 (, out1 for mass profiles) [n_pts,B];
+ *   jac_or_null [n_out][n_params + 2][n_pts,B]: d out / d (x, y, p_0 .. p_{n-1}) of the same pass (n_out = 2 mass, 1 light).
+ * Plugin-level calls only: the pixel kernels of the likelihood path take built-in kinds (gl_model_create). */
+typedef struct gl_user_profile gl_user_profile;
+int gl_user_profile_check(const char* body, int is_light, int n_params);
+int gl_user_profile_create(const char* body, int is_light, int n_params, gl_user_profile** out);
+int gl_user_profile_eval(const gl_user_profile* u, const float* x, const float* y, int64_t n_pts, int B, int xy_batched,
+                         const float* params, float* out0, float* out1, float* jac_or_null, void* hip_stream);
+void gl_user_profile_destroy(gl_user_profile* u);
+
 const char* gl_last_error(void);
 const char* gl_version(void);
 

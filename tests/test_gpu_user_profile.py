@@ -1,0 +1,98 @@
+"""The open plugin boundary on the GPU (csrc/gl_user.hip): the reference lets a user subclass MassProfile / LightProfile and write
+deriv / light (src/gigalens/profile.py:58-82); here such a class carries a `hip_body`, compiled at run time, and serves the same
+plugin-level calls.  Parity: a user-written SIS equals the built-in kind; derivatives (forward-mode duals in the kernel,
+contracted by torch.autograd) equal a float64 torch restatement."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_parity import gl  # noqa: F401
+from tests.test_user_profile_compile import SIS_BODY
+
+pytestmark = pytest.mark.gpu
+
+
+def _profiles():
+    from gigalens_amd.profile import LightProfile, MassProfile
+
+    class UserSIS(MassProfile):
+        _name, _params = "USER_SIS", ["theta_E", "center_x", "center_y"]
+        hip_body = SIS_BODY
+
+    class UserGauss(LightProfile):
+        """An elliptical Gaussian with a branch and a transcendental of its own: I = amp exp(-q2 / 2) / (1 + |x - cx|)."""
+        _name, _params, _amp = "USER_GAUSS", ["sigma", "q", "center_x", "center_y"], "amp"
+        hip_body = """
+        template <class R> __device__ R light(R x, R y, const R* p) {
+          R dx = x - p[2], dy = y - p[3];
+          R q2 = (dx * dx * p[1] + dy * dy / p[1]) / (p[0] * p[0]);
+          R damp = dx < 0.f ? 1.f - dx : 1.f + dx;    // |dx| with a branch on the value
+          return p[4] * exp(-0.5f * q2) / damp;
+        }
+        """
+    return UserSIS, UserGauss
+
+
+def test_user_written_sis_equals_the_built_in(gl):
+    from gigalens_amd.profiles.mass.sis import SIS
+    UserSIS, _ = _profiles()
+    r = np.random.default_rng(0)
+    B = 5
+    x = torch.tensor(r.uniform(-2, 2, (7, 9, 1)), dtype=torch.float32, device="cuda")
+    y = torch.tensor(r.uniform(-2, 2, (7, 9, 1)), dtype=torch.float32, device="cuda")
+    kw = dict(theta_E=torch.tensor(r.uniform(0.5, 1.5, B), dtype=torch.float32, device="cuda"),
+              center_x=torch.tensor(r.normal(0, 0.1, B), dtype=torch.float32, device="cuda"),
+              center_y=torch.tensor(r.normal(0, 0.1, B), dtype=torch.float32, device="cuda"))
+    ax, ay = UserSIS().deriv(x, y, **kw)
+    bx, by = SIS().deriv(x, y, **kw)
+    assert ax.shape == bx.shape == (7, 9, B)
+    assert torch.allclose(ax, bx, rtol=2e-6, atol=1e-7) and torch.allclose(ay, by, rtol=2e-6, atol=1e-7)
+
+
+def test_gradients_of_user_bodies_match_float64_autograd(gl):
+    UserSIS, UserGauss = _profiles()
+    r = np.random.default_rng(1)
+    B = 4
+    mk = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True)
+    x, y = mk(r.uniform(-2, 2, (11, 1))), mk(r.uniform(-2, 2, (11, 1)))
+    th, cx, cy = mk(r.uniform(0.5, 1.5, B)), mk(r.normal(0, 0.1, B)), mk(r.normal(0, 0.1, B))
+    ax, ay = UserSIS().deriv(x, y, theta_E=th, center_x=cx, center_y=cy)
+    w0, w1 = torch.tensor(r.normal(size=(11, B)), device="cuda", dtype=torch.float32), torch.tensor(r.normal(size=(11, B)), device="cuda", dtype=torch.float32)
+    (ax * w0 + ay * w1).sum().backward()
+    d = lambda t: t.detach().double().cpu().requires_grad_(True)
+    x6, y6, th6, cx6, cy6 = d(x), d(y), d(th), d(cx), d(cy)
+    dx, dy = x6 - cx6, y6 - cy6
+    rr = torch.sqrt(dx * dx + dy * dy)
+    (th6 * dx / rr * w0.double().cpu() + th6 * dy / rr * w1.double().cpu()).sum().backward()
+    for a, b in ((x, x6), (y, y6), (th, th6), (cx, cx6), (cy, cy6)):
+        assert a.grad is not None and a.grad.shape == a.shape
+        assert np.allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-4, atol=2e-5 * float(b.grad.abs().max())), (a.grad, b.grad)
+    # light profile: amplitude is the last parameter (profile.py:24-60)
+    sg, q, amp = mk(r.uniform(0.5, 1.0, B)), mk(r.uniform(0.6, 1.0, B)), mk(r.uniform(1.0, 3.0, B))
+    cx2, cy2 = mk(r.normal(0, 0.1, B)), mk(r.normal(0, 0.1, B))
+    x2, y2 = mk(r.uniform(-2, 2, (13, 1))), mk(r.uniform(-2, 2, (13, 1)))
+    I = UserGauss().light(x2, y2, sigma=sg, q=q, center_x=cx2, center_y=cy2, amp=amp)
+    assert I.shape == (13, B)
+    w = torch.tensor(r.normal(size=(13, B)), device="cuda", dtype=torch.float32)
+    (I * w).sum().backward()
+    X, Y, S, Q, A, CX, CY = d(x2), d(y2), d(sg), d(q), d(amp), d(cx2), d(cy2)
+    ddx, ddy = X - CX, Y - CY
+    I6 = A * torch.exp(-0.5 * (ddx * ddx * Q + ddy * ddy / Q) / (S * S)) / (1 + ddx.abs())
+    assert np.allclose(I.detach().cpu().numpy(), I6.detach().numpy(), rtol=2e-5, atol=1e-6)
+    (I6 * w.double().cpu()).sum().backward()
+    for a, b in ((x2, X), (y2, Y), (sg, S), (q, Q), (amp, A), (cx2, CX), (cy2, CY)):
+        assert np.allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=3e-4, atol=3e-5 * float(b.grad.abs().max())), (a.grad, b.grad)
+
+
+def test_user_profiles_stay_out_of_the_pixel_kernels_with_a_clear_message(gl):
+    from gigalens_amd import _native
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.simulator import LensSimulator, SimulatorConfig
+    UserSIS, _ = _profiles()
+    with pytest.raises(_native.NativeLibraryError, match="built-in kinds only"):
+        LensSimulator(PhysicalModel([UserSIS()], [], [Sersic()]), SimulatorConfig(delta_pix=0.1, num_pix=8), bs=1)
+    with pytest.raises(_native.NativeLibraryError, match="does not compile"):
+        class Broken(UserSIS):
+            hip_body = "template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) { fx = nope; }"
+        Broken().deriv(torch.zeros(3, device="cuda"), torch.zeros(3, device="cuda"), theta_E=1.0, center_x=0.0, center_y=0.0)
