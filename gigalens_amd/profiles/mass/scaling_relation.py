@@ -19,8 +19,11 @@ class ScalingRelation(MassProfile):
     ray-shooting pass (gl_dpie.h), so no ``(x, y, b, g)`` tensor is ever formed and ``chunk_size`` (the reference's
     memory bound, :33-36,46) is accepted and unused.
 
-    Built for the dPIE family (``DPIS``, ``DPIE``, ``DPIEP``) with scaling parameters among the amplitude and the
-    two radii -- what ``DPIESubhalo`` (dpie_subhalo.py) uses.
+    The fused kernels are built for the dPIE family (``DPIS``, ``DPIE``, ``DPIEP``) with scaling parameters among the
+    amplitude and the two radii -- what ``DPIESubhalo`` (dpie_subhalo.py) uses; only those can be part of a
+    ``PhysicalModel``.  Any other base profile -- another built-in kind, other scaling parameters, a user-written
+    ``hip_body`` -- is served at the plugin level the way the reference does it (:61-83): ``deriv`` / ``hessian`` evaluate the
+    base profile on ``chunk_size`` galaxies at a time and sum.
     """
 
     _kind = 9
@@ -32,12 +35,14 @@ class ScalingRelation(MassProfile):
         self._params = list(scaling_params)
         self.scaling_params = list(scaling_params)
         super().__init__(**kwargs)
-        if getattr(profile, "_kind", 0) not in _BASE_KINDS:
-            raise NotImplementedError(f"ScalingRelation over {profile.name} is not built (dPIS, dPIE, dPIEP are)")
-        slots = list(profile.params[:3])  # amplitude, inner radius, outer radius
-        bad = [p for p in self.scaling_params if p not in slots]
-        if bad or not self.scaling_params:
-            raise NotImplementedError(f"scaling parameters must be among {slots}, got {self.scaling_params}")
+        if not self.scaling_params:
+            raise ValueError("ScalingRelation needs at least one scaling parameter")
+        unknown = [p for p in self.scaling_params if p not in profile.params]
+        if unknown:
+            raise ValueError(f"{profile.name} has no parameters {unknown}")
+        slots = list(profile.params[:3])  # dPIE family: amplitude, inner radius, outer radius
+        # fused kernels: dPIE family with scales among its first three parameters; everything else: the generic plugin-level sum
+        self._generic = getattr(profile, "_kind", 0) not in _BASE_KINDS or any(p not in slots for p in self.scaling_params)
         self.lum_star = float(lum_star)
         self.power = {k: float(v) for k, v in scaling_params_power.items()}
         self.galaxy_cat = galaxy_catalogue
@@ -54,6 +59,11 @@ class ScalingRelation(MassProfile):
 
     # -- what the native library consumes (include/gigalens_hip.h: gl_model_set_catalogue) --------------------------
     def _component(self):
+        if self._generic:
+            raise _native.NativeLibraryError(
+                f"ScalingRelation over {self.profile.name} with scales {self.scaling_params}: the pixel kernels sum populations of "
+                "dPIS, dPIE, dPIEP members scaled in amplitude and radii only; other populations are served at the plugin level "
+                "(deriv / hessian on points), not inside a PhysicalModel")
         return (self._kind, len(self.scaling_params), 0)
 
     def _unscaled(self):
@@ -83,8 +93,43 @@ class ScalingRelation(MassProfile):
 
     def deriv(self, x, y, **scales):
         """scaling_relation.py:61-70."""
+        if self._generic:
+            return self._sum_over_galaxies(self.profile.deriv, 2, x, y, scales)
         return _native.scaled_eval(self, x, y, scales)
 
     def hessian(self, x, y, **scales):
         """scaling_relation.py:72-83: the sum of the members' Hessians as the base profile resolves ``hessian``."""
+        if self._generic:
+            return self._sum_over_galaxies(self.profile.hessian, 4, x, y, scales)
         return _native.scaled_hessian(self, x, y, scales)
+
+    # -- any base profile, at the plugin level: (x, y, b) -> (x, y, b, g) chunk by chunk like the reference (:61-70), with the
+    # (b, g) pair folded into the base profile's batch axis (its parameters vary along the last axis only)
+    def _sum_over_galaxies(self, fn, n_out, x, y, scales):
+        dev = _native.device()
+        missing = [k for k in self.scaling_params if k not in scales]
+        if missing:
+            raise TypeError(f"{self.name}: missing parameters {missing}")
+        x = torch.as_tensor(x, dtype=torch.float32, device=dev)
+        y = torch.as_tensor(y, dtype=torch.float32, device=dev)
+        sc = {k: torch.as_tensor(scales[k], dtype=torch.float32, device=dev) for k in self.scaling_params}
+        shape = torch.broadcast_shapes(x.shape, y.shape, *[v.shape for v in sc.values()])
+        B = shape[-1] if len(shape) else 1
+        xb, yb = x.expand(shape).reshape(-1, B), y.expand(shape).reshape(-1, B)
+        unscaled = {k: torch.from_numpy(v).to(dev) for k, v in self._unscaled().items()}
+        out = [torch.zeros_like(xb) for _ in range(n_out)]
+        for pos in range(0, self.n_galaxy, max(1, int(self.chunk_size))):
+            g = slice(pos, min(pos + max(1, int(self.chunk_size)), self.n_galaxy))
+            ng = g.stop - g.start
+            kw = {}
+            for k in list(self.profile.params) + [c for c in getattr(self.profile, "constants", []) if c not in self.profile.params]:
+                if k in self.scaling_params:  # scale_b * (L_g / L*)^power  ->  index b * ng + g
+                    s_b = sc[k].reshape(-1)[-B:].expand(B) if sc[k].numel() > 1 else sc[k].reshape(()).expand(B)
+                    kw[k] = (s_b[:, None] * unscaled[k][g][None, :]).reshape(B * ng)
+                else:
+                    col = torch.as_tensor(np.asarray(self.galaxy_cat[k], dtype=np.float32)[g], device=dev)
+                    kw[k] = col[None, :].expand(B, ng).reshape(B * ng)
+            res = fn(xb[:, :, None].expand(-1, B, ng).reshape(-1, B * ng), yb[:, :, None].expand(-1, B, ng).reshape(-1, B * ng), **kw)
+            for o, r in zip(out, res):
+                o += r.reshape(-1, B, ng).sum(dim=-1)
+        return tuple(o.reshape(shape) for o in out)

@@ -181,8 +181,10 @@ def test_catalogue_errors(gl):
     from gigalens_amd import _native
     from gigalens_amd.profiles.mass.epl import EPL
     from gigalens_amd.profiles.mass.scaling_relation import ScalingRelation
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(KeyError, match="lacks the columns"):  # any base profile is accepted (plugin level); its constants must be there
         ScalingRelation(EPL(), ["theta_E"], 1.0, {"theta_E": 0.5}, dict(lum=[1.0]))
+    with pytest.raises(ValueError, match="no parameters"):
+        ScalingRelation(EPL(), ["r_cut"], 1.0, {"r_cut": 0.5}, dict(lum=[1.0]))
     wl = gl.workloads.make("C6", num_pix=16, batch=2, n_galaxies=5, n_sources=1)
     sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=2)
     with pytest.raises(_native.NativeLibraryError):  # component 0 is the dPIE halo, not a GL_SCALED lens

@@ -75,9 +75,14 @@ def test_scaling_relation_outside_the_dpie_family_is_refused():
     from gigalens_amd import _native
     from gigalens_amd.profiles.mass.nfw import NFW
     from gigalens_amd.profiles.mass.scaling_relation import ScalingRelation
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.simulator import LensSimulator, SimulatorConfig
     cat = dict(lum=np.ones(3, np.float32), center_x=np.zeros(3, np.float32), center_y=np.zeros(3, np.float32))
-    with pytest.raises(NotImplementedError, match="dPIS, dPIE, dPIEP"):
-        ScalingRelation(NFW(), ["Rs"], 1.0, {"Rs": 0.5}, dict(cat, alpha_Rs=np.ones(3, np.float32)))
+    # a population of NFW halos is served at the plugin level (tests/test_gpu_user_profile.py) but not inside a model
+    pop = ScalingRelation(NFW(), ["Rs"], 1.0, {"Rs": 0.5}, dict(cat, alpha_Rs=np.ones(3, np.float32)))
+    with pytest.raises(_native.NativeLibraryError, match="dPIS, dPIE, dPIEP"):
+        LensSimulator(PhysicalModel([pop], [], [Sersic()]), SimulatorConfig(delta_pix=0.1, num_pix=8), bs=1)
     L = _native.lib()
     one = torch.zeros(4, device="cuda")
     cols = (ctypes.c_int32 * 3)(0, -1, -1)

@@ -40,10 +40,16 @@ def test_catalogue_table_matches_the_oracle_constants():
     un = ref.scaled_unscaled_factors(sub)  # (L/L*)^power in float32, scaling_relation.py:52-55
     assert np.allclose(t[:, 0], un["theta_E"].numpy(), rtol=2e-7) and np.allclose(t[:, 2], un["r_cut"].numpy(), rtol=2e-7)
     assert np.allclose(t[:, 1], 0.03) and np.allclose(t[:, 3], CAT["center_x"]) and np.all(t[:, 5:] == 0)  # dPIS: no e1, e2
-    with pytest.raises(NotImplementedError):
-        ScalingRelation(EPL(), ["theta_E"], 1.0, {"theta_E": 0.5}, dict(lum=[1.0]))
-    with pytest.raises(NotImplementedError):
-        ScalingRelation(DPIE(), ["center_x"], 1.0, {"center_x": 0.5}, CAT)
+    # any base profile / any of its parameters may scale (scaling_relation.py:8-19): such populations are served at the plugin level
+    # (the generic sum over galaxies) and refused only inside a PhysicalModel, where the fused kernels take the dPIE family
+    with pytest.raises(KeyError):
+        ScalingRelation(EPL(), ["theta_E"], 1.0, {"theta_E": 0.5}, dict(lum=[1.0]))  # the EPL's other parameters are not in the catalogue
+    odd = ScalingRelation(DPIE(), ["center_x"], 1.0, {"center_x": 0.5},
+                          dict(CAT, theta_E=[1.0] * 3, r_core=[0.03] * 3, r_cut=[1.0] * 3, e1=[0.0] * 3, e2=[0.0] * 3))
+    assert odd._generic
+    from gigalens_amd import _native
+    with pytest.raises(_native.NativeLibraryError, match="dPIS, dPIE, dPIEP"):
+        odd._component()
     with pytest.raises(KeyError):
         ScalingRelation(DPIE(), ["theta_E"], 1.0, {"theta_E": 0.5}, CAT)  # r_core / r_cut columns missing
 
