@@ -42,6 +42,8 @@ class gl_grid(ctypes.Structure):
 # every symbol include/gigalens_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "gl_model_create": (c_int, [POINTER(gl_component), c_int, c_int, c_int, POINTER(gl_grid), POINTER(c_void_p)]),
+    "gl_model_create_user": (c_int, [POINTER(gl_component), c_int, c_int, c_int, POINTER(gl_grid), POINTER(ctypes.c_char_p), c_int,
+                                     POINTER(c_void_p)]),
     "gl_model_destroy": (None, [c_void_p]),
     "gl_model_num_params": (c_int, [c_void_p]),
     "gl_model_param_offset": (c_int, [c_void_p, c_int]),
@@ -154,15 +156,24 @@ def _ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
-def component_of(profile):
+def component_of(profile, bodies=None):
+    """gl_component of a profile.  ``bodies``: the list a model under construction collects user-written bodies in (`hip_body`
+    profiles become GL_USER_MASS / GL_USER_LIGHT components pointing into it); None outside a model."""
     kind, iparam, flags = profile._component()
+    if not kind and bodies is not None and getattr(profile, "hip_body", ""):
+        from gigalens_amd.profile import LightProfile
+        n = len(profile._native_params())
+        if n > 16:
+            raise NativeLibraryError(f"profile {profile.name!r}: a user-written profile inside a model takes at most 16 parameters, got {n}")
+        if profile.hip_body not in bodies:
+            bodies.append(profile.hip_body)
+        return gl_component(20 if isinstance(profile, LightProfile) else 13, n, bodies.index(profile.hip_body), 0)
     if not kind:
         raise NativeLibraryError(
             f"profile {getattr(profile, 'name', type(profile).__name__)!r} has no gl_kind: user-defined deriv / light bodies "
-            "written in Python cannot run here, and the pixel kernels of LensSimulator take built-in kinds only (adding one means "
-            "adding a kind: gigalens_amd/csrc/gl_profiles.h and the dispatch switches of gl_kernels.hip.h).  For the plugin-level "
-            "calls (deriv / light on points, differentiable) give the class a `hip_body`: one HIP C++ function template that "
-            "the library compiles at run time (include/gigalens_hip.h gl_user_profile_create; see INTEGRATION.md)")
+            "written in Python cannot run here.  Give the class a `hip_body` -- one HIP C++ function template over a number type "
+            "that the library compiles at run time (include/gigalens_hip.h gl_user_profile_create / gl_model_create_user; see "
+            "INTEGRATION.md) -- and it serves deriv / light on points as well as LensSimulator's pixel kernels")
     return gl_component(kind, iparam, flags, 0)
 
 
@@ -484,7 +495,7 @@ class Model:
     """Owns one ``gl_model`` (immutable descriptor + grid on the current device)."""
 
     def __init__(self, components, n_lens, n_lens_light, n_src, height, width, supersample, grid_x, grid_y,
-                 pix_index, conversion_factor, psf=None):
+                 pix_index, conversion_factor, psf=None, bodies=None):
         self.device = device()
         L = lib()
         n = len(components)
@@ -505,7 +516,11 @@ class Model:
             g.psf_h, g.psf_w = pk.shape
         h = c_void_p()
         with torch.cuda.device(self.device):
-            _check(L.gl_model_create(arr, n_lens, n_lens_light, n_src, ctypes.byref(g), ctypes.byref(h)))
+            if bodies:  # user-written profiles: the interpreter kernel is compiled with them now (seconds, once)
+                barr = (ctypes.c_char_p * len(bodies))(*[b.encode() for b in bodies])
+                _check(L.gl_model_create_user(arr, n_lens, n_lens_light, n_src, ctypes.byref(g), barr, len(bodies), ctypes.byref(h)))
+            else:
+                _check(L.gl_model_create(arr, n_lens, n_lens_light, n_src, ctypes.byref(g), ctypes.byref(h)))
         self._h = h
         self.P = L.gl_model_num_params(h)
         self.N = L.gl_model_num_pixels(h)

@@ -259,6 +259,7 @@ int run_order(const gl_model* m, int B, const Workspace& w, MainArgs* a, hipStre
 // image-position likelihood on the packed parameter rows `params` [B,P] (already on the device)
 int run_positions(const gl_model* m, const float* params, int B, const Workspace& w, bool want_grad, hipStream_t stream) {
   if (m->n_series) return fail(GL_EUNSUPPORTED, "a series-expansion lens lives on the pixel grid only (series_profile.py:76-81): no image-position likelihood");
+  if (m->has_user) return fail(GL_EUNSUPPORTED, "the image-position likelihood is not built for models with user-written profiles");
   PosArgs a{};
   a.comps = m->d_comps;
   a.n_lens = m->n_lens;
@@ -463,7 +464,13 @@ int gl_kind_num_params(const gl_component* comp) {
 
 int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int n_src, const gl_grid* grid,
                     gl_model** out) {
+  return gl_model_create_user(comps, n_lens, n_lens_light, n_src, grid, nullptr, 0, out);
+}
+
+int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light, int n_src, const gl_grid* grid,
+                         const char* const* bodies, int n_bodies, gl_model** out) {
   if (!out) return fail(GL_EINVAL, "out is null");
+  if (n_bodies < 0 || (n_bodies > 0 && !bodies)) return fail(GL_EINVAL, "bad user bodies");
   *out = nullptr;
   if (!grid) return fail(GL_EINVAL, "grid is null");
   if (n_lens < 0 || n_lens_light < 0 || n_src < 0) return fail(GL_EINVAL, "negative component count");
@@ -491,13 +498,21 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
   for (int i = 0; i < n_comp; ++i) {
     const gl_component& c = comps[i];
     const bool mass = i < n_lens;
-    const bool is_mass_kind = c.kind >= GL_EPL && c.kind <= GL_TNFW;
-    const bool is_light_kind = c.kind >= GL_SERSIC && c.kind <= GL_CORE_SERSIC;
+    const bool is_mass_kind = (c.kind >= GL_EPL && c.kind <= GL_TNFW) || c.kind == GL_USER_MASS;
+    const bool is_light_kind = (c.kind >= GL_SERSIC && c.kind <= GL_CORE_SERSIC) || c.kind == GL_USER_LIGHT;
     if ((mass && !is_mass_kind) || (!mass && !is_light_kind)) {
       delete m;
       return fail(GL_EINVAL, "component %d: kind %d is not a %s profile", i, c.kind, mass ? "mass" : "light");
     }
     int iparam = c.iparam;
+    if (c.kind == GL_USER_MASS || c.kind == GL_USER_LIGHT) {
+      if (iparam < 0 || iparam > USER_MAXP || (int)c.flags >= n_bodies || !bodies[c.flags]) {
+        delete m;
+        return fail(GL_EINVAL, "component %d: a user-written profile takes 0..%d parameters and the index of its body (got %d parameters, "
+                               "body %u of %d)", i, USER_MAXP, iparam, c.flags, n_bodies);
+      }
+      m->has_user = true;
+    }
     if (c.kind == GL_EPL) {
       if (iparam <= 0) iparam = 50;  // epl.py:15
       if (iparam > 1000) { delete m; return fail(GL_EINVAL, "EPL niter %d too large", iparam); }
@@ -564,6 +579,10 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     m->tile_grad = (tg == 4 || tg == 1 || tg == 2) ? tg : 0;
   }
   m->static_id = env_int("GIGALENS_HIP_STATIC", 1) ? match_static(m) : 0;
+  if (m->has_user) {  // the run-time compiled interpreter serves the whole model
+    m->static_id = 0;
+    if (m->shp_big) { delete m; return fail(GL_EUNSUPPORTED, "user-written profiles beside shapelets with n_max > %d", SH_CAP); }
+  }
   if (m->shp_big) {  // orders above SH_CAP: the runtime-order interpreter variant only (compiled for the basic profile families)
     m->static_id = 0;
     if (m->fam) {
@@ -604,7 +623,7 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     if (m->tile == 1) m->tile = 2;
     if (m->tile_grad == 1) m->tile_grad = 2;
   }
-  if (env_int("GIGALENS_HIP_CLUSTER", 1) && !m->static_id && n_lens_light == 0 && n_lens >= 1 && n_lens <= 8 && n_src >= 1 &&
+  if (env_int("GIGALENS_HIP_CLUSTER", 1) && !m->static_id && !m->has_user && n_lens_light == 0 && n_lens >= 1 && n_lens <= 8 && n_src >= 1 &&
       n_src <= 20 && (size_t)64 * m->Apad * sizeof(float) <= 64 * 1024) {
     bool ok_c = true, ell = false;
     for (int i = 0; i < n_lens; ++i) ok_c = ok_c && m->comps[i].kind == K_NFW;
@@ -773,6 +792,14 @@ int gl_model_create(const gl_component* comps, int n_lens, int n_lens_light, int
     gl_model_destroy(m);
     return fail(GL_ENOMEM, "device allocation / upload failed in gl_model_create");
   }
+  if (m->has_user) {  // the interpreter kernel with the user's bodies inside, compiled now (a few seconds, once per model)
+    m->tile = 2;
+    m->tile_grad = 2;
+    if (int rc = compile_user_model(m, bodies, n_bodies)) {
+      gl_model_destroy(m);
+      return rc;
+    }
+  }
   *out = m;
   return GL_OK;
 }
@@ -854,6 +881,7 @@ int gl_model_launch_shape(const gl_model* m, int B, int* chunk_px, int* n_chunks
 
 void gl_model_destroy(gl_model* m) {
   if (!m) return;
+  if (m->user_module) (void)hipModuleUnload(m->user_module);
   for (hipEvent_t e : m->evs) (void)hipEventDestroy(e);
   if (m->d_comps) (void)hipFree(m->d_comps);
   if (m->d_gx) (void)hipFree(m->d_gx);
@@ -1004,6 +1032,7 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
                  float* coeffs_or_null, float* stacked_or_null, float* image_or_null, void* workspace,
                  size_t workspace_bytes, void* hip_stream) {
   if (!m) return fail(GL_EINVAL, "model is null");
+  if (m->has_user) return fail(GL_EUNSUPPORTED, "the linear-amplitude solve is not built for models with user-written profiles");
   const int D = (int)m->lin_cols.size();
   if (D == 0) return fail(GL_EINVAL, "the model has no linear (light amplitude) coefficients");
   if (!params || !workspace) return fail(GL_EINVAL, "params / workspace is null");
@@ -1446,6 +1475,7 @@ int gl_profile_hessian(const gl_component* comp, const float* x, const float* y,
 int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, const float* y, int64_t n_pts,
                  int xy_batched, float* out, void* hip_stream) {
   if (!m || !params || !out) return fail(GL_EINVAL, "null argument");
+  if (m->has_user) return fail(GL_EUNSUPPORTED, "lens maps are not built for models with user-written profiles");
   if ((x == nullptr) != (y == nullptr)) return fail(GL_EINVAL, "x and y must both be given or both be null");
   if (B <= 0 || n_pts <= 0) return fail(GL_EINVAL, "B and n_pts must be positive");
   if ((int)m->cats.size() != m->n_scaled) return fail(GL_EINVAL, "GL_SCALED component without a catalogue");

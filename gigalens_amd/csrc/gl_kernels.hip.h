@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(128) gl_prep_kernel(const CompDesc* __restrict
     case K_SERSIC: sersic_prep<float>(p, false, d); break;
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, d); break;
+    case K_USER_MASS: case K_USER_LIGHT: for (int k = 0; k < cd.iparam; ++k) d[k] = p[k]; break;  // the body reads its parameters
   }
   if (cost && c == cost_comp) cost[b] = reinterpret_cast<const int*>(d)[EPL_KI];
 }
@@ -326,6 +327,7 @@ __global__ void __launch_bounds__(128) gl_zprep_kernel(const CompDesc* __restric
     case K_SERSIC: sersic_prep<float>(p, false, dd); break;
     case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, dd); break;
     case K_SHAPELETS: shapelets_prep<float>(p, cd.iparam, dd); break;
+    case K_USER_MASS: case K_USER_LIGHT: for (int k = 0; k < cd.iparam; ++k) dd[k] = p[k]; break;
   }
   if (cost && c == cost_comp) cost[b] = reinterpret_cast<const int*>(dd)[EPL_KI];
 }
@@ -411,6 +413,7 @@ __global__ void __launch_bounds__(256) gl_prep_wave_kernel(const CompDesc* __res
       case K_CORE_SERSIC: core_sersic_prep<float>(p, d); break;
       case K_SERSIC: sersic_prep<float>(p, false, d); break;
       case K_SERSIC_ELLIPSE: sersic_prep<float>(p, true, d); break;
+      case K_USER_MASS: case K_USER_LIGHT: for (int k = 0; k < cd.iparam; ++k) d[k] = p[k]; break;
       case K_SHAPELETS:  // the four constants here; the amplitude blocks below, by the whole wavefront
         d[SHP_CX] = p[1]; d[SHP_CY] = p[2]; d[SHP_IB] = 1.f / p[0]; d[SHP_NMAX] = (float)cd.iparam;
         break;
@@ -727,6 +730,12 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
 #pragma unroll
           for (int t = 0; t < T; ++t) { float ax, ay; sis_fwd(d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
           break;
+#ifdef GL_HAVE_USER  // run-time compiled variant of this kernel (gl_user.hip): the bodies of the model's user-written profiles
+        case K_USER_MASS:
+#pragma unroll
+          for (int t = 0; t < T; ++t) { float ax, ay; glu::mass_fwd(comps[l].flags, d, x[t], y[t], ax, ay); bx[t] -= ax; by[t] -= ay; }
+          break;
+#endif
         case K_DPIE:
           if constexpr (DP) {
 #pragma unroll
@@ -841,6 +850,11 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
 #pragma unroll
           for (int t = 0; t < T; ++t) m[t] += core_sersic_fwd<float>(d, src ? bx[t] : x[t], src ? by[t] : y[t]);
         }
+#ifdef GL_HAVE_USER
+      } else if (cd.kind == K_USER_LIGHT) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) m[t] += glu::light_fwd(cd.flags, d, src ? bx[t] : x[t], src ? by[t] : y[t]);
+#endif
       } else if constexpr (T % 2 == 0) {
 #pragma unroll
         for (int t = 0; t < T; t += 2) {
@@ -931,6 +945,19 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
             }
             wave_acc<SHPA_AMP + SH_MAXL>(acc, ac, cd.a_off, cd.n_acc);
           }
+#ifdef GL_HAVE_USER
+        } else if (cd.kind == K_USER_LIGHT) {  // d I / d (x, y, p) from forward-mode duals of the user's body
+          float acc[USER_MAXP];
+#pragma unroll
+          for (int k = 0; k < USER_MAXP; ++k) acc[k] = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            float dgx = 0.f, dgy = 0.f;
+            glu::light_vjp(cd.flags, d, src ? bx[t] : x[t], src ? by[t] : y[t], gm[t], acc, dgx, dgy);
+            if (src) { gbx[t] += dgx; gby[t] += dgy; }
+          }
+          wave_acc<USER_MAXP>(acc, ac, cd.a_off, cd.n_acc);
+#endif
         } else if (cd.kind == K_CORE_SERSIC) {
           if constexpr (XF) {
             float acc[CSR_NACC];
@@ -1030,6 +1057,16 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
             for (int t = 0; t < T; ++t) sis_vjp(d, x[t], y[t], gbx[t], gby[t], acc);
             wave_acc<SIS_NACC>(acc, ac, cd.a_off);
           } break;
+#ifdef GL_HAVE_USER
+          case K_USER_MASS: {
+            float acc[USER_MAXP];
+#pragma unroll
+            for (int k = 0; k < USER_MAXP; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) glu::mass_vjp(cd.flags, d, x[t], y[t], gbx[t], gby[t], acc);
+            wave_acc<USER_MAXP>(acc, ac, cd.a_off, cd.n_acc);
+          } break;
+#endif
           case K_DPIS:
           case K_DPIE:
           case K_DPIEP: if constexpr (DP) {
@@ -1196,6 +1233,7 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
         case K_SERSIC: sersic_finalize<float>(p, false, acc, g); break;
         case K_SERSIC_ELLIPSE: sersic_finalize<float>(p, true, acc, g); break;
         case K_SHAPELETS: if constexpr (!BASIC) shapelets_finalize<float>(p, cd.iparam, acc, g); break;
+        case K_USER_MASS: case K_USER_LIGHT: if constexpr (!BASIC) { for (int k = 0; k < cd.iparam; ++k) g[k] = acc[k]; } break;  // d/dp_k as summed
       }
     }
     __syncthreads();

@@ -115,7 +115,15 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
 #define GL_MAIN_FAM(TT, S_) \
   do { if (m->fam == 2) GL_MAIN(TT, S_, 2); else if (m->fam == 1) GL_MAIN(TT, S_, 1); else GL_MAIN(TT, S_, 0); } while (0)
   bool done = false;
-  if (m->shp_big) {  // shapelets above n_max = 10: the runtime-order interpreter variant (basic profile families, T = 2)
+  if (m->has_user) {  // a model with user-written profiles: the interpreter compiled at run time with their bodies (gl_user.hip)
+    if (!m->user_fn[MODE]) return fail(GL_EUNSUPPORTED, "this call is not served for models with user-written profiles");
+    MainArgs args = a;
+    void* kargs[] = {(void*)&args};
+    m->last_main_fn = nullptr;
+    GL_HIP(hipModuleLaunchKernel(m->user_fn[MODE], grid.x, grid.y, 1, block.x, 1, 1, (unsigned)shmem, stream, kargs, nullptr));
+    done = true;
+  }
+  if (!done && m->shp_big) {  // shapelets above n_max = 10: the runtime-order interpreter variant (basic profile families, T = 2)
     m->last_main_fn = (const void*)&gl_main_kernel<MODE, 2, true, 0, true>;
     hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true, 0, true>), grid, block, shmem, stream, a);
     done = true;

@@ -8,8 +8,16 @@
 // R = double on the host so that tests/hostmath can check the hand-written
 // VJPs against autograd to 1e-10 (test harness only; never a product path).
 #pragma once
+#if !defined(__HIPCC_RTC__)  // (the run-time compiler of user profiles brings its own device headers and has no host library)
 #include <cmath>
 #include <cstdint>
+#else
+typedef signed long long int64_t;
+typedef unsigned long long uint64_t;
+typedef signed int int32_t;
+typedef unsigned int uint32_t;
+typedef unsigned long size_t_rtc_unused;
+#endif
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>

@@ -52,6 +52,10 @@ struct gl_model {
   int P = 0, D = 0, A = 0, Apad = 0, ncols = 64;
   bool has_shapelets = false, has_table = false;
   bool shp_big = false;  // some shapelet component has n_max > SH_CAP: wide table, runtime-order interpreter variant for all of them
+  // user-written profiles inside the model (K_USER_MASS / K_USER_LIGHT): the interpreter kernel compiled at run time with their bodies
+  bool has_user = false;
+  hipModule_t user_module = nullptr;
+  hipFunction_t user_fn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // per Mode (IMG_BASIS: none)
   int height = 0, width = 0, supersample = 1, N = 0;
   float conversion_factor = 1.f;
   // device-resident, immutable
@@ -131,6 +135,8 @@ namespace glk {
 // launches the dominant kernel of a call for one mode (gl_launch.hip.h); explicit instantiations live in gl_launch_mode*.hip
 template <int MODE>
 int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream);
+// gl_user.hip: compile gl_main_kernel with the model's user bodies (n_bodies HIP C++ sources), fill user_module / user_fn
+__attribute__((visibility("hidden"))) int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies);
 int match_static(const gl_model* m);
 extern template int launch_main<IMG_FWD>(const gl_model*, const MainArgs&, int, int, hipStream_t);
 extern template int launch_main<IMG_BWD>(const gl_model*, const MainArgs&, int, int, hipStream_t);

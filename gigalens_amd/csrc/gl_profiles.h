@@ -27,9 +27,12 @@ enum Kind : int {
   K_SCALED = 9,                         // ScalingRelation over a galaxy catalogue (gl_dpie.h); iparam = catalogue slot
   K_SERIES = 10,                        // series expansion of a (scaled) dPIE in r_cut (gl_series.h); iparam = order, flags = field slot
   K_NFW_ELLIPSE = 11, K_TNFW = 12,      // gl_extra.h
+  K_USER_MASS = 13,                     // a body the user wrote (gl_user.hip): iparam = its parameter count, flags = body slot of the model
   K_SERSIC = 16, K_SERSIC_ELLIPSE = 17, K_SHAPELETS = 18,
-  K_CORE_SERSIC = 19                    // gl_extra.h
+  K_CORE_SERSIC = 19,                   // gl_extra.h
+  K_USER_LIGHT = 20                     // same for a light profile (amplitude: whatever the body makes of its parameters)
 };
+constexpr int USER_MAXP = 16;  // parameters of a user-written profile inside a model (its gradient sums are register arrays)
 
 constexpr int SH_CAP = 10;                              // largest n_max the register-resident / matrix-pipe shapelet kernels serve
 constexpr int SH_MAXL = (SH_CAP + 1) * (SH_CAP + 2) / 2;  // 66
@@ -91,6 +94,8 @@ GL_HD int kind_num_params(int kind, int iparam) {
     case K_SERSIC: return 5;
     case K_SERSIC_ELLIPSE: return 7;
     case K_SHAPELETS: return 3 + sh_layers(iparam);
+    case K_USER_MASS:
+    case K_USER_LIGHT: return (iparam >= 0 && iparam <= USER_MAXP) ? iparam : -1;
   }
   return -1;
 }
@@ -113,6 +118,8 @@ GL_HD int kind_num_derived(int kind, int iparam) {
     case K_SERSIC_ELLIPSE: return SER_ND + 2;
     case K_SHAPELETS:  // n_max <= 10: amplitude triangle zero-padded to n_max = 10, then the square matrix; above: the triangle only
       return iparam <= SH_CAP ? SHP_SQ + SH_SQ * SH_SQ : SHP_AMP + ((SH_MAXLB + 3) & ~3);
+    case K_USER_MASS:
+    case K_USER_LIGHT: return iparam > 0 ? ((iparam + 3) & ~3) : 4;  // the parameters themselves
   }
   return -1;
 }
@@ -154,6 +161,8 @@ GL_HD int kind_num_acc(int kind, int iparam) {
     case K_SERSIC:
     case K_SERSIC_ELLIPSE: return SER_NACC;
     case K_SHAPELETS: return SHPA_AMP + sh_layers(iparam);
+    case K_USER_MASS:
+    case K_USER_LIGHT: return iparam;  // one sum per parameter
   }
   return -1;
 }

@@ -188,6 +188,125 @@ int compile_user_profile(const char* body, int is_light, int n_params, std::vect
 }
 }  // namespace
 
+// ---- user bodies inside a model: the interpreter kernel compiled with them ----------------------------------------------------
+#include <dlfcn.h>
+
+#include "gl_kernels.hip.h"  // MainArgs, Mode, kinds (host view; the device code of this translation unit is unused)
+
+namespace glk {
+
+// the directory of the kernel headers: next to the library (gigalens_amd/lib/ -> gigalens_amd/csrc/), or GIGALENS_HIP_CSRC
+static std::string csrc_dir() {
+  if (const char* e = getenv("GIGALENS_HIP_CSRC")) return e;
+  Dl_info info{};
+  if (dladdr((const void*)&gl_version, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    const size_t a = p.rfind('/');
+    if (a != std::string::npos) {
+      p.resize(a);  // .../lib
+      const size_t b = p.rfind('/');
+      if (b != std::string::npos) return p.substr(0, b) + "/csrc";
+    }
+  }
+  return "gigalens_amd/csrc";
+}
+
+int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
+  // which body serves which kind, with how many parameters (a body used by several components must agree with itself)
+  std::vector<int> npar(n_bodies, -1), light(n_bodies, -1);
+  for (const CompDesc& cd : m->comps) {
+    if (cd.kind != K_USER_MASS && cd.kind != K_USER_LIGHT) continue;
+    const int w = (int)cd.flags, l = cd.kind == K_USER_LIGHT;
+    if ((npar[w] >= 0 && npar[w] != cd.iparam) || (light[w] >= 0 && light[w] != l))
+      return fail(GL_EINVAL, "user body %d is used with different parameter counts / as mass and light profile", w);
+    npar[w] = cd.iparam;
+    light[w] = l;
+  }
+  std::string src = "#define GL_HAVE_USER 1\n";
+  src += kPrelude;
+  for (int w = 0; w < n_bodies; ++w) {
+    if (npar[w] < 0) continue;
+    src += "namespace glu_body" + std::to_string(w) + " {\n#line 1 \"user_profile_" + std::to_string(w) + "\"\n" + bodies[w] + "\n}\n";
+  }
+  auto cases = [&](int want_light, const char* fmt_body) {
+    std::string out;
+    for (int w = 0; w < n_bodies; ++w) {
+      if (npar[w] < 0 || light[w] != want_light) continue;
+      std::string b = fmt_body;
+      auto rep = [&](const std::string& k, const std::string& v) { for (size_t at; (at = b.find(k)) != std::string::npos;) b.replace(at, k.size(), v); };
+      rep("@W", std::to_string(w));
+      rep("@N1", std::to_string(npar[w] > 0 ? npar[w] : 1));
+      rep("@N2", std::to_string(npar[w] + 2));
+      rep("@N", std::to_string(npar[w]));
+      out += b;
+    }
+    return out;
+  };
+  src += "#line 1 \"gl_user_glue\"\nnamespace glu {\n"
+         "__device__ inline void mass_fwd(unsigned which, const float* d, float x, float y, float& ax, float& ay) {\n  ax = ay = 0.f;\n  switch (which) {\n";
+  src += cases(0, "    case @W: { float p[@N1]; for (int k = 0; k < @N; ++k) p[k] = d[k]; glu_body@W::deriv<float>(x, y, p, ax, ay); } break;\n");
+  src += "  }\n}\n"
+         "__device__ inline void mass_vjp(unsigned which, const float* d, float x, float y, float gx, float gy, float* acc) {\n  switch (which) {\n";
+  src += cases(0, "    case @W: { typedef gl::Dual<@N1> D; D p[@N1]; for (int k = 0; k < @N; ++k) p[k] = D::var(d[k], k); D fx, fy;\n"
+                  "      glu_body@W::deriv<D>(D(x), D(y), p, fx, fy); for (int k = 0; k < @N; ++k) acc[k] += gx * fx.d[k] + gy * fy.d[k]; } break;\n");
+  src += "  }\n}\n"
+         "__device__ inline float light_fwd(unsigned which, const float* d, float x, float y) {\n  switch (which) {\n";
+  src += cases(1, "    case @W: { float p[@N1]; for (int k = 0; k < @N; ++k) p[k] = d[k]; return glu_body@W::light<float>(x, y, p); }\n");
+  src += "  }\n  return 0.f;\n}\n"
+         "__device__ inline void light_vjp(unsigned which, const float* d, float x, float y, float g, float* acc, float& dgx, float& dgy) {\n  switch (which) {\n";
+  src += cases(1, "    case @W: { typedef gl::Dual<@N2> D; D p[@N1]; for (int k = 0; k < @N; ++k) p[k] = D::var(d[k], 2 + k);\n"
+                  "      const D f = glu_body@W::light<D>(D::var(x, 0), D::var(y, 1), p); dgx += g * f.d[0]; dgy += g * f.d[1];\n"
+                  "      for (int k = 0; k < @N; ++k) acc[k] += g * f.d[2 + k]; } break;\n");
+  src += "  }\n}\n}  // namespace glu\n#include \"gl_kernels.hip.h\"\n";
+  // the instantiations launch_main would pick for an interpreter model: T = 2, the model's shapelet / family switches
+  std::string names[4];
+  for (int mode = 0; mode < 4; ++mode) {
+    names[mode] = "glk::gl_main_kernel<" + std::to_string(mode) + ", 2, " + (m->has_shapelets ? "true" : "false") + ", " + std::to_string(m->fam) + ", false>";
+    src += "template __global__ void " + names[mode] + "(glk::MainArgs);\n";
+  }
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    return fail(GL_ELAUNCH, "hiprtcCreateProgram failed");
+  for (int mode = 0; mode < 4; ++mode) (void)hiprtcAddNameExpression(prog, names[mode].c_str());
+  const std::string inc = "-I" + csrc_dir();
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+  const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    (void)hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n ? n : 1, '\0');
+    if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+    (void)hiprtcDestroyProgram(&prog);
+    const size_t at = log.find("error");
+    const size_t from = at == std::string::npos ? 0 : log.rfind('\n', at) == std::string::npos ? 0 : log.rfind('\n', at) + 1;
+    return fail(GL_EINVAL, "user profile does not compile (%s; kernel headers from %s):\n%.330s", hiprtcGetErrorString(rc), csrc_dir().c_str(), log.c_str() + from);
+  }
+  std::string lowered[4];
+  for (int mode = 0; mode < 4; ++mode) {
+    const char* ln = nullptr;
+    if (hiprtcGetLoweredName(prog, names[mode].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+      (void)hiprtcDestroyProgram(&prog);
+      return fail(GL_ELAUNCH, "hiprtcGetLoweredName failed for %s", names[mode].c_str());
+    }
+    lowered[mode] = ln;
+  }
+  size_t code_size = 0;
+  if (hiprtcGetCodeSize(prog, &code_size) != HIPRTC_SUCCESS || !code_size) {
+    (void)hiprtcDestroyProgram(&prog);
+    return fail(GL_ELAUNCH, "hiprtcGetCodeSize failed");
+  }
+  std::vector<char> code(code_size);
+  const hiprtcResult rc2 = hiprtcGetCode(prog, code.data());
+  (void)hiprtcDestroyProgram(&prog);
+  if (rc2 != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcGetCode failed");
+  hipError_t e = hipModuleLoadData(&m->user_module, code.data());
+  for (int mode = 0; mode < 4 && e == hipSuccess; ++mode) e = hipModuleGetFunction(&m->user_fn[mode], m->user_module, lowered[mode].c_str());
+  if (e != hipSuccess) return fail(GL_ELAUNCH, "loading the compiled user model failed: %s", hipGetErrorString(e));
+  return GL_OK;
+}
+
+}  // namespace glk
+
 extern "C" {
 
 int gl_user_profile_check(const char* body, int is_light, int n_params) {

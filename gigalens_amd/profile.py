@@ -21,7 +21,8 @@ class Parameterized(ABC):
     #     template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy);   (MassProfile;  p = params in order)
     #     template <class R> __device__ R    light(R x, R y, const R* p);                 (LightProfile; amplitude last)
     # It serves the plugin-level calls -- deriv / light on points, differentiable through torch.autograd (forward-mode duals
-    # inside) -- see include/gigalens_hip.h gl_user_profile_create; LensSimulator's pixel kernels take built-in kinds only.
+    # inside; include/gigalens_hip.h gl_user_profile_create) -- and, inside a PhysicalModel, LensSimulator's pixel kernels
+    # (gl_model_create_user: the likelihood path's interpreter kernel is compiled with the body in it; <= 16 parameters).
     hip_body: str = ""
 
     def __init__(self, *args, **kwargs):

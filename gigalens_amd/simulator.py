@@ -151,12 +151,13 @@ class LensSimulator(LensSimulatorInterface):
             from gigalens_amd.kernel_util import subgrid_kernel
             psf = np.asarray(subgrid_kernel(np.asarray(sim_config.kernel), ss, odd=True), dtype=np.float32)
         self.kernel = psf
-        comps = ([_native.component_of(p) for p in phys_model.lenses]
-                 + [_native.component_of(p) for p in phys_model.lens_light]
-                 + [_native.component_of(p) for p in phys_model.source_light])
+        bodies = []  # user-written profile bodies (profile.py `hip_body`): compiled into this model's kernels
+        comps = ([_native.component_of(p, bodies) for p in phys_model.lenses]
+                 + [_native.component_of(p, bodies) for p in phys_model.lens_light]
+                 + [_native.component_of(p, bodies) for p in phys_model.source_light])
         self._model = _native.Model(comps, len(phys_model.lenses), len(phys_model.lens_light),
                                     len(phys_model.source_light), Hs, Ws, ss, img_X, img_Y, pix_index,
-                                    self.conversion_factor, psf)
+                                    self.conversion_factor, psf, bodies=bodies)
         for i, lens in enumerate(phys_model.lenses):
             if getattr(lens, "_kind", 0) == 10:  # series expansion: the field must live on THIS pixel list
                 if lens.x is not self.img_X or lens._coefs is None:

@@ -59,11 +59,14 @@ typedef enum gl_kind {
                      parameters [theta_E, r_cut]; iparam = order (0..5); field attached with gl_model_set_series */
   GL_NFW_ELLIPSE = 11, /* tf/profiles/mass/nfw.py:100   [Rs,alpha_Rs,e1,e2,center_x,center_y] */
   GL_TNFW = 12,        /* tf/profiles/mass/tnfw.py:12   [Rs,alpha_Rs,r_trunc,center_x,center_y] */
+  GL_USER_MASS = 13,   /* profile.py:63-82 as an extension point: a body the user wrote (gl_model_create_user); iparam = parameter
+                          count, flags = index of the body */
   /* light profiles: LightProfile.light (profile.py:24-60) */
   GL_SERSIC = 16,         /* tf/profiles/light/sersic.py:23-24 [R_sersic,n_sersic,center_x,center_y,Ie] */
   GL_SERSIC_ELLIPSE = 17, /* sersic.py:68-69 [R_sersic,n_sersic,e1,e2,center_x,center_y,Ie] */
   GL_SHAPELETS = 18,      /* tf/profiles/light/shapelets.py:18,34-36 [beta,center_x,center_y,amp0..amp{L-1}] */
-  GL_CORE_SERSIC = 19     /* sersic.py:85-96 [R_sersic,n_sersic,Rb,alpha,gamma,e1,e2,center_x,center_y,Ie] */
+  GL_CORE_SERSIC = 19,    /* sersic.py:85-96 [R_sersic,n_sersic,Rb,alpha,gamma,e1,e2,center_x,center_y,Ie] */
+  GL_USER_LIGHT = 20      /* profile.py:24-60 as an extension point: a user-written light body (gl_model_create_user) */
 } gl_kind;
 
 #define GL_SHAPELETS_NMAX_CAP 20 /* largest n_max served (231 amplitudes); above 10 the runtime-order path of the interpreter kernel runs */
@@ -348,6 +351,12 @@ int gl_model_launch_shape(const gl_model* m, int B, int* chunk_px, int* n_chunks
  *   eval: x, y [n_pts] or [n_pts,B] (xy_batched), params [B,n_params], out0 (, out1 for mass profiles) [n_pts,B];
  *   jac_or_null [n_out][n_params + 2][n_pts,B]: d out / d (x, y, p_0 .. p_{n-1}) of the same pass (n_out = 2 mass, 1 light).
  * Plugin-level calls only: the pixel kernels of the likelihood path take built-in kinds (gl_model_create). */
+/* ... and inside a model: components of kind GL_USER_MASS / GL_USER_LIGHT (iparam = parameter count <= 16, flags = index into
+ * `bodies`) make gl_model_create_user compile the interpreter kernel of the likelihood path at run time with those bodies in it:
+ * simulate / log-likelihood / fused log-prob and their gradients (forward-mode duals of the body) work as for built-in kinds.
+ * Not served for such models: the linear-amplitude solve, the image-position likelihood, lens maps (typed refusals). */
+int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light, int n_src, const gl_grid* grid,
+                         const char* const* bodies, int n_bodies, gl_model** out);
 typedef struct gl_user_profile gl_user_profile;
 int gl_user_profile_check(const char* body, int is_light, int n_params);
 int gl_user_profile_create(const char* body, int is_light, int n_params, gl_user_profile** out);

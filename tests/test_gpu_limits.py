@@ -3,8 +3,8 @@
 The closed-world limits (INTEGRATION.md "What does not transfer"): shapelets ``n_max > 20`` (the reference takes any
 ``n_max``, shapelets.py:20-24), linear systems above 255 coefficients, ``ScalingRelation`` over profiles outside the dPIE
 family (scaling_relation.py:8-19 accepts any ``MassProfile``), user-defined ``deriv`` / ``light`` bodies inside a model
-(profile.py:58-82 are abstract extension points in the reference; here the pixel kernels take ``gl_kind``s the library implements --
-at the plugin level a user body written as a ``hip_body`` IS served, tests/test_gpu_user_profile.py)."""
+(profile.py:58-82 are abstract extension points in the reference; here a body written in Python cannot run -- one written as a
+``hip_body`` is compiled at run time and served at the plugin level and inside models, tests/test_gpu_user_profile.py)."""
 import ctypes
 
 import numpy as np

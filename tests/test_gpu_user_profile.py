@@ -84,18 +84,19 @@ def test_gradients_of_user_bodies_match_float64_autograd(gl):
         assert np.allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=3e-4, atol=3e-5 * float(b.grad.abs().max())), (a.grad, b.grad)
 
 
-def test_user_profiles_stay_out_of_the_pixel_kernels_with_a_clear_message(gl):
+def test_compile_errors_inside_a_model_come_back_verbatim(gl):
     from gigalens_amd import _native
     from gigalens_amd.model import PhysicalModel
     from gigalens_amd.profiles.light.sersic import Sersic
     from gigalens_amd.simulator import LensSimulator, SimulatorConfig
     UserSIS, _ = _profiles()
-    with pytest.raises(_native.NativeLibraryError, match="built-in kinds only"):
-        LensSimulator(PhysicalModel([UserSIS()], [], [Sersic()]), SimulatorConfig(delta_pix=0.1, num_pix=8), bs=1)
+
+    class Broken(UserSIS):
+        hip_body = "template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) { fx = nope; }"
     with pytest.raises(_native.NativeLibraryError, match="does not compile"):
-        class Broken(UserSIS):
-            hip_body = "template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) { fx = nope; }"
         Broken().deriv(torch.zeros(3, device="cuda"), torch.zeros(3, device="cuda"), theta_E=1.0, center_x=0.0, center_y=0.0)
+    with pytest.raises(_native.NativeLibraryError, match="does not compile"):
+        LensSimulator(PhysicalModel([Broken()], [], [Sersic()]), SimulatorConfig(delta_pix=0.1, num_pix=8), bs=1)
 
 
 def test_scaling_relation_over_any_base_profile(gl):
@@ -149,3 +150,62 @@ def test_scaling_relation_over_any_base_profile(gl):
         tot = tot + (tE * dx / rr).sum() + 2 * (tE * dy / rr).sum()
     tot.backward()
     assert np.allclose(th.grad.cpu().numpy(), th6.grad.numpy(), rtol=2e-4)
+
+
+SERSIC_BODY = """
+template <class R> __device__ R light(R x, R y, const R* p) {
+  // p = R_sersic, n_sersic, center_x, center_y, Ie   (src/gigalens/tf/profiles/light/sersic.py:23-66, spherical)
+  R dx = x - p[2], dy = y - p[3];
+  R r = sqrt(dx * dx + dy * dy);
+  R bn = 1.9992f * p[1] - 0.3271f;
+  return p[4] * exp(-bn * (pow(r / p[0], 1.f / p[1]) - 1.f));
+}
+"""
+
+
+def test_user_written_profiles_inside_a_model_equal_the_built_in_kinds(gl):
+    """The second half of the boundary: a PhysicalModel may hold user-written profiles; LensSimulator then compiles the
+    interpreter kernel of the likelihood path with their bodies (gl_model_create_user).  A model of a user-written SIS lens and a
+    user-written Sersic source must reproduce the model of the built-in kinds: image, image VJP, log-likelihood and its gradient."""
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profile import LightProfile
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.profiles.mass.sis import SIS
+    from gigalens_amd.simulator import LensSimulator, SimulatorConfig
+    UserSIS, _ = _profiles()
+
+    class UserSersic(LightProfile):
+        _name, _params, _amp = "USER_SERSIC", ["R_sersic", "n_sersic", "center_x", "center_y"], "Ie"
+        hip_body = SERSIC_BODY
+
+    cfg = SimulatorConfig(delta_pix=0.08, num_pix=40)
+    B = 6
+    sim_u = LensSimulator(PhysicalModel([UserSIS(), Shear()], [], [UserSersic()]), cfg, bs=B)
+    sim_b = LensSimulator(PhysicalModel([SIS(), Shear()], [], [Sersic()]), cfg, bs=B)
+    r = np.random.default_rng(5)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    params = {"lens_mass": [dict(theta_E=t(r.uniform(0.8, 1.2, B)), center_x=t(r.normal(0, 0.05, B)), center_y=t(r.normal(0, 0.05, B))),
+                            dict(gamma1=t(r.normal(0, 0.03, B)), gamma2=t(r.normal(0, 0.03, B)))],
+              "source_light": [dict(R_sersic=t(r.uniform(0.2, 0.4, B)), n_sersic=t(r.uniform(1.0, 3.0, B)),
+                                    center_x=t(r.normal(0.05, 0.1, B)), center_y=t(r.normal(0, 0.1, B)), Ie=t(r.uniform(20, 60, B)))]}
+    img_u, img_b = sim_u.simulate(params), sim_b.simulate(params)
+    assert img_u.shape == img_b.shape == (B, 40, 40)
+    top = float(img_b.abs().max())
+    assert torch.allclose(img_u, img_b, rtol=1e-4, atol=2e-5 * top), float((img_u - img_b).abs().max()) / top
+    pu, pb = sim_u.pack(params), sim_b.pack(params)
+    assert torch.equal(pu, pb)
+    mu, mb = sim_u._model, sim_b._model
+    obs = img_b[0] + 0.5 * t(r.normal(size=(40, 40)))
+    ll_u, c_u, g_u = mu.loglike(pu, obs, None, None, 0.5, 100.0, True)
+    ll_b, c_b, g_b = mb.loglike(pb, obs, None, None, 0.5, 100.0, True)
+    assert torch.allclose(ll_u, ll_b, rtol=2e-5) and torch.allclose(c_u, c_b, rtol=2e-5)
+    scale = g_b.abs().amax(dim=0, keepdim=True)
+    assert torch.all((g_u - g_b).abs() <= 2e-3 * scale + 1e-6), ((g_u - g_b).abs() / scale).max()
+    w = t(r.normal(size=(B, 40, 40)))
+    v_u, v_b = mu.simulate_bwd(pu, w), mb.simulate_bwd(pb, w)
+    vs = v_b.abs().amax(dim=0, keepdim=True)
+    assert torch.all((v_u - v_b).abs() <= 2e-3 * vs + 1e-6)
+    from gigalens_amd import _native
+    with pytest.raises(_native.NativeLibraryError, match="not built for models with user-written"):
+        mu.lens_maps(pu, None, None)
