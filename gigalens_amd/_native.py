@@ -376,6 +376,14 @@ def scaled_hessian(profile, x, y, scales):
 def profile_hessian(profile, x, y, kwargs):
     """MassProfile.hessian (tf/profile.py:9-27): ``(f_xx, f_xy, f_yx, f_yy)``."""
     dev = device()
+    up = user_profile_of(profile) if not profile._component()[0] else None
+    if up is not None:  # a user-written body: the derivative of its deflection from the same duals (d fx / d(x, y), d fy / d(x, y))
+        xb, yb, P, B, out_shape = _broadcast_points(profile, x, y, kwargs, list(profile.params), dev)
+        n_pts = xb.shape[0]
+        out0, out1 = torch.empty_like(xb), torch.empty_like(xb)
+        jac = torch.empty((2, up.n_params + 2, n_pts, B), dtype=torch.float32, device=dev)
+        _check(lib().gl_user_profile_eval(up._h, _ptr(xb), _ptr(yb), n_pts, B, 1, _ptr(P), _ptr(out0), _ptr(out1), _ptr(jac), _stream()))
+        return tuple(jac[i, j].reshape(out_shape) for i, j in ((0, 0), (0, 1), (1, 0), (1, 1)))
     comp = component_of(profile)
     xb, yb, P, B, out_shape = _broadcast_points(profile, x, y, kwargs, list(profile.params), dev)
     out = torch.empty((4,) + tuple(xb.shape), dtype=torch.float32, device=dev)

@@ -47,6 +47,10 @@ def test_user_written_sis_equals_the_built_in(gl):
     bx, by = SIS().deriv(x, y, **kw)
     assert ax.shape == bx.shape == (7, 9, B)
     assert torch.allclose(ax, bx, rtol=2e-6, atol=1e-7) and torch.allclose(ay, by, rtol=2e-6, atol=1e-7)
+    # hessian / convergence / shear (tf/profile.py:9-42) come from the same duals
+    for hu, hb in zip(UserSIS().hessian(x, y, **kw), SIS().hessian(x, y, **kw)):
+        assert torch.allclose(hu, hb, rtol=2e-5, atol=2e-6)
+    assert torch.allclose(UserSIS().convergence(x, y, **kw), SIS().convergence(x, y, **kw), rtol=2e-5, atol=2e-6)
 
 
 def test_gradients_of_user_bodies_match_float64_autograd(gl):
@@ -209,6 +213,14 @@ def test_user_written_profiles_inside_a_model_equal_the_built_in_kinds(gl):
     from gigalens_amd import _native
     with pytest.raises(_native.NativeLibraryError, match="not built for models with user-written"):
         mu.lens_maps(pu, None, None)
+    # ... the simulator forms the maps lens by lens instead (tf/simulator.py:72-107)
+    xs, ys = sim_b.img_X[:200, None], sim_b.img_Y[:200, None]
+    for fn in ("magnification", "convergence"):
+        a, b2 = getattr(sim_u, fn)(xs, ys, params["lens_mass"]), getattr(sim_b, fn)(xs, ys, params["lens_mass"])
+        assert a.shape == b2.shape == (200, B)
+        assert torch.allclose(a, b2, rtol=2e-4, atol=2e-5 * float(b2.abs().median()) + 1e-6), fn
+    ga, gb = sim_u.shear(xs, ys, params["lens_mass"]), sim_b.shear(xs, ys, params["lens_mass"])
+    assert torch.allclose(ga[0], gb[0], rtol=2e-4, atol=1e-5) and torch.allclose(ga[1], gb[1], rtol=2e-4, atol=1e-5)
 
 
 def test_log_prob_and_map_on_a_model_with_user_written_profiles(gl):
