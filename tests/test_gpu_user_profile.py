@@ -266,3 +266,43 @@ def test_log_prob_and_map_on_a_model_with_user_written_profiles(gl):
     lp_end, _ = pm.log_prob(LensSimulator(phys_u, cfg, bs=16), sol)
     lp_start, _ = pm.log_prob(LensSimulator(phys_u, cfg, bs=16), pm.bij.inverse(prior.sample(16, seed=1)).to("cuda"))
     assert float(lp_end.max()) > float(lp_start.max())
+
+
+def test_user_written_lens_light_beside_built_in_kinds(gl):
+    """A user-written profile mixes with built-in components: EPL + Shear lens (the wavefront-per-sample front end and the
+    cost-ordered dispatch run), a user-written Sersic as LENS LIGHT, a built-in Sersic source, one body shared by two components --
+    against the all-built-in twin."""
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profile import LightProfile
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.simulator import LensSimulator, SimulatorConfig
+
+    class UserSersic(LightProfile):
+        _name, _params, _amp = "USER_SERSIC", ["R_sersic", "n_sersic", "center_x", "center_y"], "Ie"
+        hip_body = SERSIC_BODY
+
+    cfg = SimulatorConfig(delta_pix=0.08, num_pix=36)
+    B = 5
+    sim_u = LensSimulator(PhysicalModel([EPL(), Shear()], [UserSersic()], [Sersic(), UserSersic()]), cfg, bs=B)
+    sim_b = LensSimulator(PhysicalModel([EPL(), Shear()], [Sersic()], [Sersic(), Sersic()]), cfg, bs=B)
+    r = np.random.default_rng(7)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    ser = lambda rs, ie: dict(R_sersic=t(r.uniform(0.8, 1.2, B) * rs), n_sersic=t(r.uniform(1.0, 3.0, B)), center_x=t(r.normal(0, 0.05, B)),
+                              center_y=t(r.normal(0, 0.05, B)), Ie=t(r.uniform(0.8, 1.2, B) * ie))
+    params = {"lens_mass": [dict(theta_E=t(r.uniform(0.9, 1.2, B)), gamma=t(r.uniform(1.8, 2.2, B)), e1=t(r.normal(0.1, 0.05, B)),
+                                 e2=t(r.normal(-0.05, 0.05, B)), center_x=t(r.normal(0, 0.03, B)), center_y=t(r.normal(0, 0.03, B))),
+                            dict(gamma1=t(r.normal(0, 0.03, B)), gamma2=t(r.normal(0, 0.03, B)))],
+              "lens_light": [ser(0.8, 30.0)], "source_light": [ser(0.25, 40.0), ser(0.15, 20.0)]}
+    img_u, img_b = sim_u.simulate(params), sim_b.simulate(params)
+    top = float(img_b.abs().max())
+    assert torch.allclose(img_u, img_b, rtol=1e-4, atol=3e-5 * top), float((img_u - img_b).abs().max()) / top
+    pu = sim_u.pack(params)
+    assert torch.equal(pu, sim_b.pack(params))
+    obs = img_b[0] + 0.5 * t(r.normal(size=(36, 36)))
+    ll_u, _, g_u = sim_u._model.loglike(pu, obs, None, None, 0.5, 100.0, True)
+    ll_b, _, g_b = sim_b._model.loglike(pu, obs, None, None, 0.5, 100.0, True)
+    assert torch.allclose(ll_u, ll_b, rtol=3e-5)
+    scale = g_b.abs().amax(dim=0, keepdim=True)
+    assert torch.all((g_u - g_b).abs() <= 3e-3 * scale + 1e-6), ((g_u - g_b).abs() / scale).max()
