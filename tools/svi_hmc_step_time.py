@@ -16,7 +16,9 @@ for name, kw, n in (("C2", dict(num_pix=60, batch=250), 250), ("C2", dict(), 102
     seq = ModellingSequence(wl.phys_model, pm, wl.sim_config)
     start = pm.bij.inverse(pm.prior.sample(2, seed=0))[0]
     for full in (True, False):
-        seq.SVI(Adam(1e-3), start, n_vi=n, num_steps=10, full_rank=full)
+        # warm-up long enough to take in the one-off host costs of a run (first refill of the pre-generated noise pool, allocator
+        # growth for this batch size: tens of ms that 200 timed steps would otherwise carry)
+        seq.SVI(Adam(1e-3), start, n_vi=n, num_steps=300, full_rank=full)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         (mean, L), losses = seq.SVI(Adam(1e-3), start, n_vi=n, num_steps=200, full_rank=full)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
