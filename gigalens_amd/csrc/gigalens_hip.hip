@@ -186,14 +186,22 @@ int run_galprep(const gl_model* m, const float* params, int B, const Workspace& 
   return GL_OK;
 }
 
+// the wavefront-per-sample front end (gl_prep_wave_kernel) carries the sort of the cost-ordered dispatch as one extra workgroup:
+// no launch of gl_order_kernel (one launch boundary less on every step)
+bool wave_front_end(const gl_model* m) { return m->has_epl && (int)m->comps.size() <= 64 && m->wave_prep; }
+bool order_in_front_end(const gl_model* m, int B) {
+  return wave_front_end(m) && m->use_order && m->order_fused && m->epl_comp >= 0 && B >= 2;
+}
+
 int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, hipStream_t stream) {
   int n_comp = (int)m->comps.size();
   int total = B * n_comp;
-  if (m->has_epl && n_comp <= 64 && m->wave_prep)  // one wavefront per sample: the EPL coefficient tables are built by a scan over its lanes
-    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, m->d_comps, n_comp, params, nullptr, 0,
-                       (const ZCol*)nullptr, (const int*)nullptr, (const float*)nullptr, m->P, B, (float*)nullptr, w.derived,
-                       m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
-  else
+  if (wave_front_end(m)) {  // one wavefront per sample: the EPL coefficient tables are built by a scan over its lanes
+    const bool ord = order_in_front_end(m, B);
+    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4 + (ord ? 1 : 0)), dim3(256), 0, stream, m->d_comps, n_comp, params, nullptr,
+                       0, (const ZCol*)nullptr, (const int*)nullptr, (const float*)nullptr, m->P, B, (float*)nullptr, w.derived,
+                       m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp, ord ? w.order : nullptr);
+  } else
     hipLaunchKernelGGL(gl_prep_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, params,
                        m->P, B, w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
   GL_HIP(hipGetLastError());
@@ -248,6 +256,10 @@ int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, co
 int run_order(const gl_model* m, int B, const Workspace& w, MainArgs* a, hipStream_t stream) {
   a->order = nullptr;
   if (!m->has_epl || !m->use_order || B < 2) return GL_OK;
+  if (order_in_front_end(m, B)) {  // the front end's extra workgroup has written it
+    a->order = w.order;
+    return GL_OK;
+  }
   hipLaunchKernelGGL(gl_order_kernel, dim3(1), dim3(ORDER_WG), 0, stream, m->d_comps, m->n_lens, w.derived, m->D, B,
                      w.order, m->epl_comp >= 0 ? w.cost : nullptr);
   GL_HIP(hipGetLastError());
@@ -641,6 +653,7 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   m->target_wgs_set = getenv("GIGALENS_HIP_TARGET_WGS") != nullptr;
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
+  m->order_fused = env_int("GIGALENS_HIP_ORDER_FUSED", 1) != 0;  // tests: 0 = the sort as a launch of its own (gl_order_kernel)
 #ifdef GL_EXPERIMENTS
   // dissection builds only (hipcc -DGL_EXPERIMENTS; never __graft_entry__.build()): work-skipping flags and a raw chunk size
   m->chunk_px_override = env_int("GIGALENS_HIP_CHUNK_PX", 0);
@@ -1556,11 +1569,12 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   int chunk, n_chunks;
   chunking(m, B, &chunk, &n_chunks);
   int n_comp = (int)m->comps.size();
-  if (m->has_epl && n_comp <= 64 && m->wave_prep)
-    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, m->d_comps, n_comp, (const float*)nullptr, z,
-                       m->d_z, (const ZCol*)m->d_zcols, (const int*)m->d_src, (const float*)m->d_const, m->P, B, w.params,
-                       w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
-  else
+  if (wave_front_end(m)) {
+    const bool ord = order_in_front_end(m, B);
+    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4 + (ord ? 1 : 0)), dim3(256), 0, stream, m->d_comps, n_comp,
+                       (const float*)nullptr, z, m->d_z, (const ZCol*)m->d_zcols, (const int*)m->d_src, (const float*)m->d_const, m->P,
+                       B, w.params, w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp, ord ? w.order : nullptr);
+  } else
     hipLaunchKernelGGL(gl_zprep_kernel, dim3((B * n_comp + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, z,
                        m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D,
                        m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);

@@ -259,6 +259,12 @@ GL_HD void ellip_chain(R theta_E, R e1, R e2, R cmax, R g_b, R g_q, R g_phi, R& 
 // float32 accumulation cannot register either -- and the f-derivative's tail (K + 1) f^K / (1 - f)^2 stays under 1 ulp.
 template <class R> GL_HD constexpr double epl_series_tol() { return sizeof(R) == 4 ? 1e-9 : 1e-12; }
 // scalars of the derived block (d[0..EPL_TAB)); returns the series length K and hands out f and 2 - t for the table
+// the trip count alone (what the cost-ordered dispatch sorts on): same arithmetic as epl_prep_head below
+template <class R> GL_HD int epl_cost(R e1, R e2, int cap) {
+  const R ee = p_sqrt(e1 * e1 + e2 * e2), c = fmin_(ee, (R)1), q = ((R)1 - c) / ((R)1 + c), f = ((R)1 - q) / ((R)1 + q);
+  const R niter = p_log((R)epl_series_tol<R>()) / p_log(f) + (R)2;
+  return niter > (R)1 ? (int)fmin_(-floor_(-niter) - (R)1, (R)cap) : 0;
+}
 template <class R> GL_HD int epl_prep_head(const R* p, int cap, R* d, R& f_out, R& two_mt_out) {
   R theta_E = p[0], gamma = p[1], e1 = p[2], e2 = p[3];
   Ellip<R> el = ellip_prep(e1, e2, (R)1);
