@@ -357,9 +357,9 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       gbx = -gbx;
       gby = -gby;
       // A tile none of whose pixels is inside the shapelet support sends no cotangent to the lens (the image does not depend on
-      // beta there: value 0, slope 0): without a lens light the lens VJPs of such a tile add exact zeros and are skipped
-      // (wave-uniform; 54 % of the wave-tiles on the C3 prior).
-      if (NLL > 0 || shp_live)
+      // beta there: value 0, slope 0; a lens light is evaluated on the grid, not at beta): the lens VJPs of such a tile add exact
+      // zeros and are skipped (wave-uniform; 54 % of the wave-tiles on the C3 prior).
+      if (shp_live)
       static_for([&](auto I) {
         constexpr int i = decltype(I)::value;
         constexpr int kind = LK::kinds[i];
