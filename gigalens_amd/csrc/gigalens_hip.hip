@@ -70,6 +70,39 @@ void chunking(const gl_model* m, int B, int* chunk, int* n_chunks) {
   *n_chunks = (int)(((long long)m->N + per - 1) / per);
 }
 
+// the wavefront-per-sample front end (gl_prep_wave_kernel) carries the sort of the cost-ordered dispatch as one extra workgroup:
+// no launch of gl_order_kernel (one launch boundary less on every step)
+bool wave_front_end(const gl_model* m) { return m->has_epl && (int)m->comps.size() <= 64 && m->wave_prep; }
+bool order_in_front_end(const gl_model* m, int B) {
+  return wave_front_end(m) && m->use_order && m->order_fused && m->epl_comp >= 0 && B >= 2;
+}
+
+// Tapered end of the cost-ordered dispatch (pair kernels, fused likelihood).  A launch is whole resident rounds of the chip
+// (256 CUs x the workgroups a CU holds) plus a remainder; the samples of the remainder -- the cheapest ones, dispatched last --
+// run as twice as many workgroups of half the pixels, so the last round is made of shorter workgroups (C2 at 1024 samples: two
+// rounds of 768 + 512 workgroups -> two rounds + 1024 half-size ones: -0.9 us of 87).  Splitting samples that are NOT the
+// remainder puts the boundary inside a round and costs 2-3 %, hence the exact count.  Returns the workgroups per tail sample
+// (0 = does not apply), the first tail rank and the partial rows per sample.
+int tail_plan(const gl_model* m, int B, int n_chunks, int* tail_from, int* n_rows) {
+  *tail_from = B;
+  *n_rows = n_chunks;
+  const bool pair_epl = m->pair && (m->static_id == ST_EPLSHEAR_SERSIC || m->static_id == ST_EPLSHEAR_SERSIC_SERSIC);
+  if (m->tail_rows == 0 || !pair_epl || m->has_post || !order_in_front_end(m, B) || B > 1024) return 0;
+  const int tiles = (m->N + 2 * WG - 1) / (2 * WG);
+  const int slots = 256 * (m->static_id == ST_EPLSHEAR_SERSIC ? 3 : 2);  // launch_static: waves per SIMD the kernel is budgeted for
+  int n_tail = m->tail_n, rows = m->tail_rows;
+  if (n_tail < 0) {  // the remainder beyond whole rounds, when it is a substantial part of a round
+    const long long wgs = (long long)B * n_chunks, rem = wgs % slots;
+    if (wgs < slots || rem * 4 < slots) return 0;
+    n_tail = (int)(rem / n_chunks);
+  }
+  if (rows < 0) rows = 2 * n_chunks;
+  if (n_tail <= 0 || n_tail > B || rows > tiles || rows == n_chunks) return 0;
+  *tail_from = B - n_tail;
+  *n_rows = std::max(n_chunks, rows);
+  return rows;
+}
+
 struct Workspace {
   float* derived;
   float* partial;
@@ -93,7 +126,9 @@ Workspace carve(const gl_model* m, int B, void* base) {
   w.derived = (float*)(p + off);
   off += align_up((size_t)B * m->D * sizeof(float), 256);
   w.partial = (float*)(p + off);
-  off += align_up((size_t)B * n_chunks * m->A * sizeof(float), 256);
+  int tail_from, n_rows;
+  tail_plan(m, B, n_chunks, &tail_from, &n_rows);
+  off += align_up((size_t)B * n_rows * m->A * sizeof(float), 256);
   w.params = (float*)(p + off);
   off += align_up((size_t)B * std::max(m->P, 1) * sizeof(float), 256);
   w.order = (int*)(p + off);
@@ -186,11 +221,18 @@ int run_galprep(const gl_model* m, const float* params, int B, const Workspace& 
   return GL_OK;
 }
 
-// the wavefront-per-sample front end (gl_prep_wave_kernel) carries the sort of the cost-ordered dispatch as one extra workgroup:
-// no launch of gl_order_kernel (one launch boundary less on every step)
-bool wave_front_end(const gl_model* m) { return m->has_epl && (int)m->comps.size() <= 64 && m->wave_prep; }
-bool order_in_front_end(const gl_model* m, int B) {
-  return wave_front_end(m) && m->use_order && m->order_fused && m->epl_comp >= 0 && B >= 2;
+// LDS of the wavefront front end: one parameter row per wavefront of the workgroup (0: rows too long, read back from global memory)
+size_t prep_row_bytes(const gl_model* m) {
+  const size_t bytes = (size_t)4 * m->P * sizeof(float);
+  return (m->prep_lds && bytes <= 48 * 1024) ? bytes : 0;
+}
+
+// the rank the sort must split deterministically (tail_plan): which samples run the tapered end may not depend on the order
+// the atomics of the counting sort leave inside a cost bin
+int prep_tail_from(const gl_model* m, int B) {
+  int chunk, n_chunks, tail_from, n_rows;
+  chunking(m, B, &chunk, &n_chunks);
+  return tail_plan(m, B, n_chunks, &tail_from, &n_rows) ? tail_from : -1;
 }
 
 int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, hipStream_t stream) {
@@ -198,9 +240,10 @@ int run_prep(const gl_model* m, const float* params, int B, const Workspace& w, 
   int total = B * n_comp;
   if (wave_front_end(m)) {  // one wavefront per sample: the EPL coefficient tables are built by a scan over its lanes
     const bool ord = order_in_front_end(m, B);
-    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4 + (ord ? 1 : 0)), dim3(256), 0, stream, m->d_comps, n_comp, params, nullptr,
+    const size_t rows = prep_row_bytes(m);
+    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4 + (ord ? 1 : 0)), dim3(256), rows, stream, m->d_comps, n_comp, params, nullptr,
                        0, (const ZCol*)nullptr, (const int*)nullptr, (const float*)nullptr, m->P, B, (float*)nullptr, w.derived,
-                       m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp, ord ? w.order : nullptr);
+                       m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp, ord ? w.order : nullptr, rows ? 1 : 0, prep_tail_from(m, B));
   } else
     hipLaunchKernelGGL(gl_prep_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, params,
                        m->P, B, w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp);
@@ -397,7 +440,7 @@ int render_ss(const gl_model* m, MainArgs a, int B, int n_chunks, const Workspac
 // statistics (-> transposes -> VJP).  Tells finalize where chi2 / normalisation come from.
 int run_likelihood(const gl_model* m, int B, const Workspace& w, int chunk, int n_chunks, const float* obs,
                    const float* err, const float* mask, float bg_rms, float exp_time, bool want_grad,
-                   hipStream_t stream, const float** extra_stats, int* use_partial) {
+                   hipStream_t stream, const float** extra_stats, int* use_partial, int* n_rows) {
   int rc;
   MainArgs a = base_args(m, w, chunk);
   a.obs = obs;
@@ -408,6 +451,12 @@ int run_likelihood(const gl_model* m, int B, const Workspace& w, int chunk, int 
   if ((rc = run_order(m, B, w, &a, stream))) return rc;
   *extra_stats = nullptr;
   *use_partial = 1;
+  *n_rows = n_chunks;
+  if (!m->has_post && a.order) {
+    a.tail_rows = tail_plan(m, B, n_chunks, &a.tail_from, &a.n_rows);
+    a.n_samples = B;
+    *n_rows = a.n_rows;
+  }
   if (!m->has_post) return want_grad ? launch_main<LL_GRAD>(m, a, B, n_chunks, stream) : launch_main<LL_FWD>(m, a, B, n_chunks, stream);
   if ((rc = render_ss(m, a, B, n_chunks, w, stream))) return rc;
   if ((rc = post_fwd(m, B, w.img_ss, w.img_tmp, stream))) return rc;
@@ -654,6 +703,9 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
   m->target_wgs_set = getenv("GIGALENS_HIP_TARGET_WGS") != nullptr;
   m->use_order = env_int("GIGALENS_HIP_ORDER", 1) != 0;
   m->order_fused = env_int("GIGALENS_HIP_ORDER_FUSED", 1) != 0;  // tests: 0 = the sort as a launch of its own (gl_order_kernel)
+  m->prep_lds = env_int("GIGALENS_HIP_PREP_LDS", 1) != 0;  // tests: 0 = the front end reads the parameter row back from global memory
+  m->tail_rows = env_int("GIGALENS_HIP_TAIL_ROWS", -1);  // -1: twice the chunks; 0: no tapered end; n: n workgroups per tail sample
+  m->tail_n = env_int("GIGALENS_HIP_TAIL_N", -1);        // -1: the remainder beyond whole rounds; n: the last n samples
 #ifdef GL_EXPERIMENTS
   // dissection builds only (hipcc -DGL_EXPERIMENTS; never __graft_entry__.build()): work-skipping flags and a raw chunk size
   m->chunk_px_override = env_int("GIGALENS_HIP_CHUNK_PX", 0);
@@ -885,8 +937,10 @@ int gl_model_launch_shape(const gl_model* m, int B, int* chunk_px, int* n_chunks
   int chunk = 0, nc = 0;
   chunking(m, B, &chunk, &nc);
   const Workspace w = carve(m, B, nullptr);
+  int tail_from, n_rows;
+  tail_plan(m, B, nc, &tail_from, &n_rows);
   if (chunk_px) *chunk_px = chunk;
-  if (n_chunks) *n_chunks = nc;
+  if (n_chunks) *n_chunks = n_rows;  // partial rows a sample owns (the chunks, or the workgroups of a tail sample if more: tail_plan)
   if (row_floats) *row_floats = m->A;
   if (partial_offset_bytes) *partial_offset_bytes = (size_t)((const char*)w.partial - (const char*)nullptr);
   return GL_OK;
@@ -1014,7 +1068,7 @@ int gl_loglike_fwd_bwd(const gl_model* m, const float* params, const float* obs,
   const float* extra = nullptr;
   int use_partial = 1;
   if ((rc = run_likelihood(m, B, w, chunk, n_chunks, obs, err_or_null, mask_or_null, bg_rms, exp_time,
-                           grad_params_or_null != nullptr, stream, &extra, &use_partial)))
+                           grad_params_or_null != nullptr, stream, &extra, &use_partial, &n_chunks)))
     return rc;
   return run_finalize(m, params, B, n_chunks, w, loglike, chi2, grad_params_or_null, stream, nullptr, nullptr, nullptr,
                       1.f, extra, use_partial);
@@ -1571,9 +1625,11 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   int n_comp = (int)m->comps.size();
   if (wave_front_end(m)) {
     const bool ord = order_in_front_end(m, B);
-    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4 + (ord ? 1 : 0)), dim3(256), 0, stream, m->d_comps, n_comp,
+    const size_t rows = prep_row_bytes(m);
+    hipLaunchKernelGGL(gl_prep_wave_kernel, dim3((B + 3) / 4 + (ord ? 1 : 0)), dim3(256), rows, stream, m->d_comps, n_comp,
                        (const float*)nullptr, z, m->d_z, (const ZCol*)m->d_zcols, (const int*)m->d_src, (const float*)m->d_const, m->P,
-                       B, w.params, w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp, ord ? w.order : nullptr);
+                       B, w.params, w.derived, m->D, m->epl_comp >= 0 ? w.cost : nullptr, m->epl_comp, ord ? w.order : nullptr,
+                       rows ? 1 : 0, prep_tail_from(m, B));
   } else
     hipLaunchKernelGGL(gl_zprep_kernel, dim3((B * n_comp + 127) / 128), dim3(128), 0, stream, m->d_comps, n_comp, z,
                        m->d_z, m->d_zcols, m->d_src, m->d_const, m->P, B, w.params, w.derived, m->D,
@@ -1585,7 +1641,7 @@ int gl_logprob_fwd_bwd(const gl_model* m, const float* z, const float* obs, cons
   // red_chi2 = (red_pix + red_pos) / n_chi  (tf/model.py:150-162)
   const float n_chi = (pix ? 1.f : 0.f) + (pos ? 1.f : 0.f);
   if (pix && (rc = run_likelihood(m, B, w, chunk, n_chunks, obs, err_or_null, mask_or_null, bg_rms, exp_time,
-                                  grad_z_or_null != nullptr, stream, &extra, &use_partial)))
+                                  grad_z_or_null != nullptr, stream, &extra, &use_partial, &n_chunks)))
     return rc;
   if (pos && (rc = run_positions(m, w.params, B, w, grad_z_or_null != nullptr, stream))) return rc;
   return run_finalize(m, w.params, B, n_chunks, w, loglike, chi2, nullptr, stream, z, logprob, grad_z_or_null,

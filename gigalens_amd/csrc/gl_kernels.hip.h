@@ -91,6 +91,9 @@ struct MainArgs {
   const float* shp_tab;
   int shp_stride;
   const int* order;  // cost-ordered dispatch: blockIdx.y -> sample index (heaviest first), or null
+  // tapered end of the cost-ordered dispatch (pair kernels): the samples from rank tail_from on run as tail_rows workgroups each
+  // (whole 512-pixel tiles dealt evenly) instead of gridDim.x chunks; every sample owns n_rows partial rows (tail_rows = 0: off)
+  int tail_rows, tail_from, n_rows, n_samples;
   unsigned parts;    // forward-only partial renders (tf/simulator.py:242-328): bit0 deflect, bit1 lens light, bit2 sources
   // galaxy catalogues (K_SCALED): per-galaxy static blocks [G][DP_NS], per-(sample, galaxy) blocks [B][G][GM_ND]
   const CatDev* cats;
@@ -373,12 +376,17 @@ __device__ __forceinline__ void epl_table_wave(float f, float two_mt, int K, flo
 // counting sort of the samples on their cost (<= 255), heaviest first, by ONE workgroup of NT threads: LDS histogram, one
 // wavefront's scan over the 256 bins in descending order (four bins per lane + a shuffle scan), scatter through the bins'
 // running offsets.  cost_of(b) is evaluated twice per sample (no staging array).
+// split_rank >= 0 (B <= 4 NT, NT = 256): the order inside the cost bin that straddles that rank is made the sample order instead
+// of the order of arrival of the atomics, so WHICH samples have a rank below split_rank is the same on every launch
+// (tail_plan: they are summed over other pixel chunks than the rest, and results stay bitwise reproducible).
 template <int NT, class F>
-__device__ __forceinline__ void gl_order_sort(F&& cost_of, int B, int* __restrict__ order) {
+__device__ __forceinline__ void gl_order_sort(F&& cost_of, int B, int* __restrict__ order, int split_rank = -1) {
   __shared__ int hist[256];
   __shared__ int offs[256];
+  __shared__ int s_split, s_group[4 * NT / 64];
   const int tid = threadIdx.x;
   for (int i = tid; i < 256; i += NT) hist[i] = 0;
+  if (tid == 0) s_split = -1;
   __syncthreads();
   // the first four samples of a thread stay in registers between the two passes (B <= 4 NT: all of them), their loads in flight together
   int mine[4];
@@ -409,9 +417,35 @@ __device__ __forceinline__ void gl_order_sort(F&& cost_of, int B, int* __restric
     offs[top - 3] = excl + h0 + h1 + h2;
   }
   __syncthreads();
+  int sb = -1;
+  if (split_rank >= 0 && NT == 256) {  // wave-uniform
+    if (offs[tid] < split_rank && split_rank < offs[tid] + hist[tid]) s_split = tid;  // at most one bin
+    __syncthreads();
+    sb = s_split;
+  }
+  if (sb >= 0) {
+    // stable ranks inside bin sb: samples 64 g .. 64 g + 63 are group g = 4 i + wavefront; per-group counts, then a prefix
+    const int lane = tid & 63, wv = tid >> 6;
+    int rk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned long long mk = __ballot(tid + i * NT < B && mine[i] == sb);
+      rk[i] = __popcll(mk & ((1ull << lane) - 1ull));
+      if (lane == 0) s_group[i * (NT / 64) + wv] = __popcll(mk);
+    }
+    __syncthreads();
+    const int base = offs[sb];  // no atomic touches this bin's counter below
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (tid + i * NT < B && mine[i] == sb) {
+        int pre = 0;
+        for (int g = 0; g < i * (NT / 64) + wv; ++g) pre += s_group[g];
+        order[base + pre + rk[i]] = tid + i * NT;
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    if (tid + i * NT < B) order[atomicAdd(&offs[mine[i]], 1)] = tid + i * NT;
+    if (tid + i * NT < B && mine[i] != sb) order[atomicAdd(&offs[mine[i]], 1)] = tid + i * NT;
   for (int b = tid + 4 * NT; b < B; b += NT) order[atomicAdd(&offs[max(0, min(cost_of(b), 255))], 1)] = b;
 }
 
@@ -423,7 +457,7 @@ __global__ void __launch_bounds__(256) gl_prep_wave_kernel(const CompDesc* __res
                                                            const int* __restrict__ src, const float* __restrict__ const_row,
                                                            int P, int B, float* __restrict__ params_out,
                                                            float* __restrict__ derived, int D, int* __restrict__ cost,
-                                                           int cost_comp, int* __restrict__ order) {
+                                                           int cost_comp, int* __restrict__ order, int row_lds, int split_rank) {
   // Cost-ordered dispatch without a launch of its own: with `order` the grid carries ONE extra workgroup that sorts the samples
   // by the trip count of their EPL series while the others build the samples' constants.  It needs no result of theirs: the count
   // depends on (e1, e2) alone (epl_cost), which it takes from the parameter rows -- or, on the z path, through the two columns'
@@ -451,28 +485,46 @@ __global__ void __launch_bounds__(256) gl_prep_wave_kernel(const CompDesc* __res
         e2 = k2 >= 0 ? z_eval_x(z2, z[(size_t)b * d_z + k2]) : k2c;
       }
       return epl_cost<float>(e1, e2, cap);
-    }, B, order);
+    }, B, order, split_rank);
     return;
   }
   const int b = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (b >= B) return;  // whole wavefronts leave together
   float f = 0.f, two_mt = 0.f;
   int K = 0;
+  // The constrained row of the sample goes to params_out (the finalize kernel reads it) AND, with row_lds, into the wavefront's own
+  // LDS row: the component lanes take their parameters from there instead of reading the global row back (a round trip through
+  // the L2 behind a store), and the component descriptors are requested before the bijector loads, not after them -- the
+  // front end is a chain of dependent memory round trips and nothing else (5.7 us at C2 with four of them in a row).
+  extern __shared__ float s_rows[];  // [4 wavefronts][P], or nothing
+  float* row = row_lds ? s_rows + (threadIdx.x >> 6) * P : nullptr;
+  CompDesc cd{};
+  if (lane < n_comp) cd = comps[lane];
   if (!params_in) {
     // z -> constrained row, one COLUMN per lane: the bijectors of a sample's columns are independent, so their loads
     // (column descriptor, z) and transcendentals overlap instead of forming one lane's chain of n_par dependent round trips
     float* po = params_out + (size_t)b * P;
     for (int k = lane; k < d_z; k += 64) {
       const ZCol zc = zcols[k];
-      po[zc.param_col] = z_eval_x(zc, z[(size_t)b * d_z + k]);
+      const float v = z_eval_x(zc, z[(size_t)b * d_z + k]);
+      po[zc.param_col] = v;
+      if (row) row[zc.param_col] = v;
     }
     for (int col = lane; col < P; col += 64)
-      if (src[col] < 0) po[col] = const_row[col];
-    __threadfence_block();  // the component lanes below read the row back (same wavefront, same L1)
+      if (src[col] < 0) {
+        const float v = const_row[col];
+        po[col] = v;
+        if (row) row[col] = v;
+      }
+    if (!row) __threadfence_block();  // the component lanes below read the global row back (same wavefront, same L1)
+  } else if (row) {
+    for (int col = lane; col < P; col += 64) row[col] = params_in[(size_t)b * P + col];
   }
+  // a wavefront's LDS accesses execute in order: the fence only keeps the compiler from moving the reads above the writes
+  if (row) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const float* prow = row ? row : (params_in ? params_in : params_out) + (size_t)b * P;
   if (lane < n_comp) {
-    const CompDesc cd = comps[lane];
-    const float* p = (params_in ? params_in : params_out) + (size_t)b * P + cd.p_off;
+    const float* p = prow + cd.p_off;
     float* d = derived + (size_t)b * D + cd.d_off;
     switch (cd.kind) {
       case K_EPL: K = epl_prep_head<float>(p, cd.iparam, d, f, two_mt); break;
@@ -497,10 +549,10 @@ __global__ void __launch_bounds__(256) gl_prep_wave_kernel(const CompDesc* __res
   }
   for (int c = 0; c < n_comp; ++c) {  // wave-uniform: every lane joins the amplitude blocks of every shapelet component
     if (comps[c].kind != K_SHAPELETS) continue;  // (one lane copying 66 + 144 values one by one: 18.6 us of prep at C3)
-    const CompDesc cd = comps[c];
-    const float* p = (params_in ? params_in : params_out) + (size_t)b * P + cd.p_off;
-    float* d = derived + (size_t)b * D + cd.d_off;
-    const int n_max = cd.iparam, L = sh_layers(n_max);
+    const CompDesc cs = comps[c];
+    const float* p = prow + cs.p_off;
+    float* d = derived + (size_t)b * D + cs.d_off;
+    const int n_max = cs.iparam, L = sh_layers(n_max);
     const int tri = n_max > SH_CAP ? ((SH_MAXLB + 3) & ~3) : ((SH_MAXL + 3) & ~3);
     for (int i = lane; i < tri; i += 64) d[SHP_AMP + i] = i < L ? p[3 + i] : 0.f;
     if (n_max <= SH_CAP)

@@ -102,6 +102,8 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
 template <int MODE>
 int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream) {
   dim3 grid(n_chunks, B), block(WG);
+  if (a.tail_rows > 0)  // tail_plan(): the tail samples' workgroups are dealt over whole rows of the grid
+    grid.y = a.tail_from + (unsigned)(((long long)(B - a.tail_from) * a.tail_rows + n_chunks - 1) / n_chunks);
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
   // every timing_stride-th main launch is bracketed by an event pair (an event record costs ~2.5 us of stream time)
   const bool timed = m->timing_slots && (m->timing_calls.fetch_add(1) % m->timing_stride) == 0;

@@ -97,6 +97,8 @@ struct gl_model {
   int epl_comp = -1;     // the model's only EPL component, or -1 (none / several)
   int fam = 0;  // family level of the interpreter variant (gl_main_kernel FAM): 1 dPIE family / catalogues / series, 2 gl_extra.h
   bool use_order = true;
+  int tail_rows = -1, tail_n = -1;  // tapered end of the cost-ordered dispatch (tail_plan); rows 0 = off, -1 = automatic
+  bool prep_lds = true;     // gl_prep_wave_kernel keeps each sample's parameter row in LDS
   bool order_fused = true;  // the front end's extra workgroup sorts (gl_prep_wave_kernel); else a launch of gl_order_kernel
   bool wave_prep = true;  // EPL models: one wavefront per sample in the front end (GIGALENS_HIP_WAVE_PREP=0: thread per component)
   int lstsq_wgs = 2048;     // workgroups the normal-matrix kernels of the linear solve aim for (pixel chunks per sample = this / B)

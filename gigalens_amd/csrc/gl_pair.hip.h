@@ -27,7 +27,23 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   float* s_d = smem;
   float* s_acc = smem + ((a.D + 3) & ~3);
   const int tid = threadIdx.x;
-  const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
+  // (sample rank, partial row, pixel range): see MainArgs::tail_rows
+  int rank = blockIdx.y, row = blockIdx.x, n_rows = gridDim.x, my_rows = gridDim.x;
+  int p0 = row * a.chunk, p1 = min(p0 + a.chunk, a.N);
+  if (a.tail_rows > 0) {
+    n_rows = a.n_rows;
+    if (rank >= a.tail_from) {
+      const int j = (rank - a.tail_from) * (int)gridDim.x + row;
+      rank = a.tail_from + j / a.tail_rows;
+      if (rank >= a.n_samples) return;  // the grid's last row may overhang
+      row = j % a.tail_rows;
+      my_rows = a.tail_rows;
+      const int tiles = (a.N + W * WG - 1) / (W * WG);
+      p0 = (int)((long long)row * tiles / a.tail_rows) * (W * WG);
+      p1 = min((int)((long long)(row + 1) * tiles / a.tail_rows) * (W * WG), a.N);
+    }
+  }
+  const int b = a.order ? a.order[rank] : rank;
   const CompDesc* __restrict__ comps = a.comps;
   const float* __restrict__ gder = a.derived + (size_t)b * a.D;
   if (!GL_DBG(a.dbg, 4)) {
@@ -60,8 +76,6 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   for (int i = 0; i < NLIGHT; ++i) dC[i] = s_d + comps[NL + i].d_off;
   const bool has_err = a.err != nullptr, has_mask = a.mask != nullptr, has_pix = a.pix != nullptr;
 
-  const int p0 = chunk * a.chunk;
-  const int p1 = min(p0 + a.chunk, a.N);
   // One tile = W*256 pixels.  CHECK=false is the steady state (whole tile inside the chunk, no pixel mask):
   // no validity selects, no weights.  CHECK=true handles the ragged last tile and img_region weights.
   // err_tag: 0 no error map, 1 error map (both compile the variance and the cotangent of their own case: as a run-time choice the
@@ -199,7 +213,9 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
     for (; base < p1; base += WG * W) tile(base, std::true_type{}, std::integral_constant<int, 2>{});
   }
   if (MODE == IMG_FWD) return;
-  float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
+  float* out = a.partial + ((size_t)b * n_rows + row) * a.A;
+  if (row == 0)  // the rows of the sample that no workgroup writes (the other kind of sample has more rows than this one)
+    for (int i = my_rows * a.A + tid; i < n_rows * a.A; i += WG) out[i] = 0.f;
   // ---- epilogue: per-sample scale factors deferred out of the pixel loop, lane sum, one reduction ----
   // accumulators live in registers for the whole chunk, so ONE full wave64 reduction per value per workgroup
   // is cheap: lane 63 of each wave stores its sums into the wave's own LDS row (no zero-fill, no read-modify-write)

@@ -333,7 +333,9 @@ int gl_model_last_main_ms(gl_model* m, float* ms);
 int gl_model_timing_drain(gl_model* m, float* ms, int cap, int* n);
 int gl_model_last_main_kernel(const gl_model* m, char* buf, size_t cap);
 /* Measurement aid: the work decomposition of a gradient call on B samples and where, inside a workspace of
- * gl_workspace_bytes(m, B), the per-(sample, chunk) partial rows [B][n_chunks][row_floats] live after the call.  Slots 2 and 3
+ * gl_workspace_bytes(m, B), the per-(sample, chunk) partial rows [B][n_chunks][row_floats] live after the call (n_chunks is the
+ * number of rows a sample owns: its pixel chunks, or more where the cheapest samples of a launch run as more, shorter
+ * workgroups -- rows a sample does not use are zero).  Slots 2 and 3
  * of a row are pads the finalize kernel never reads; the shapelet kernel (csrc/gl_shp.hip.h) leaves there how many of the
  * workgroup's wave-tiles ran the shapelet chains and how many it saw -- what bench.py's instruction model weights the
  * conditional blocks with. */

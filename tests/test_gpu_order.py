@@ -31,6 +31,8 @@ def test_front_end_sort_changes_no_bit(gl, monkeypatch, batch):
     packed = H.sample_packed(wl, sim, seed=3)
     pm = gl.ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time, include_positions=False)
     z = pm.bij.inverse(wl.prior.sample(batch, seed=3)).to("cuda")
+    # (the tapered end of the dispatch sums a tail sample's pixels over other chunks than an unordered launch does: off here)
+    monkeypatch.setenv("GIGALENS_HIP_TAIL_ROWS", "0")
     fused = _run(gl, wl, obs, err, packed, z)
     monkeypatch.setenv("GIGALENS_HIP_ORDER_FUSED", "0")  # read at model creation
     separate = _run(gl, wl, obs, err, packed, z)
@@ -65,3 +67,33 @@ def test_the_extra_workgroup_sorts_by_the_same_trip_counts(gl):
     assert sorted(order.tolist()) == list(range(B))
     assert np.all(np.diff(cost[order]) <= 0), "not sorted heaviest first"
     assert cost.min() >= 0 and cost.max() > cost.min()
+
+
+@pytest.mark.parametrize("batch,num_pix", [(1023, 32), (600, 64)])
+def test_tapered_end_of_the_dispatch(gl, monkeypatch, batch, num_pix):
+    """The cheapest samples of a launch -- the remainder beyond whole resident rounds -- run as twice as many workgroups of half
+    the pixels.  Which samples those are is decided by a deterministic split of the sort (bitwise reproducible results), their
+    partial sums are those of a finer chunking (a few ulps of the pixel sum), and every other sample keeps its bits."""
+    wl = gl.workloads.make("C2", num_pix=num_pix, batch=batch)
+    obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=batch)
+    packed = H.sample_packed(wl, sim, seed=11)
+    pm = gl.ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time, include_positions=False)
+    z = pm.bij.inverse(wl.prior.sample(batch, seed=11)).to("cuda")
+    runs = [_run(gl, wl, obs, err, packed, z) for _ in range(3)]
+    sim_t = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=batch)
+    sim_t._model.loglike(packed, obs, err, None, wl.background_rms, wl.exp_time, True)
+    rows_tapered = sim_t._model.partial_rows(batch).shape[1]
+    monkeypatch.setenv("GIGALENS_HIP_TAIL_ROWS", "0")
+    plain = _run(gl, wl, obs, err, packed, z)
+    sim_p = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=batch)
+    assert rows_tapered == 2 * sim_p._model.partial_rows(batch).shape[1], "the tapered end did not engage at this size"
+    for a, b, c in zip(*runs):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    n_same = 0
+    for a, p in zip(runs[0], plain):
+        assert torch.isfinite(a).all()
+        scale = p.abs().amax(0, keepdim=True) if p.dim() > 1 else p.abs()
+        assert ((a - p).abs() <= 2e-5 * scale.clamp_min(1e-30)).all()
+        n_same += int((a == p).reshape(batch, -1).all(1).sum())
+    assert n_same >= 5 * (batch // 2), "samples outside the tail changed"
