@@ -282,7 +282,7 @@ int run_finalize(const gl_model* m, const float* params, int B, int n_chunks, co
                  float* chi2, float* grad, hipStream_t stream, const float* z = nullptr, float* logprob = nullptr,
                  float* grad_z = nullptr, float chi2_scale = 1.f, const float* extra_stats = nullptr,
                  int use_partial = 1, bool with_positions = false, float pos_chi2_scale = 0.f) {
-  size_t shmem = (size_t)(((m->A + 3) & ~3) + ((m->P + 3) & ~3) + ((m->d_z + 3) & ~3) + 4 * m->d_z + 4) * sizeof(float);
+  size_t shmem = (size_t)(((m->A + 3) & ~3) + ((m->P + 3) & ~3) + ((m->d_z + 3) & ~3) + 4 * m->d_z + 4 + m->P) * sizeof(float);
   FinArgs f = fin_args(m, params, w, loglike, chi2, grad, z, logprob, grad_z, chi2_scale, extra_stats, use_partial,
                        with_positions, pos_chi2_scale);
   bool basic = true;

@@ -1324,19 +1324,18 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
   }
   const bool want_grad = f.grad != nullptr || f.grad_z != nullptr;
   CompDesc cd{};
-  constexpr int NPRE = 8;  // a component's parameters are fetched before the barrier too (every kind but shapelets fits)
-  float pre[NPRE];
-  if (want_grad && tid < f.n_comp) {
-    cd = comps[tid];
-    const float* pp = f.params + (size_t)b * P + cd.p_off;
-#pragma unroll
-    for (int j = 0; j < NPRE; ++j) pre[j] = j < cd.n_par ? pp[j] : 0.f;
+  // the sample's parameter row goes to LDS whole, requested together with everything else (the components' own slices would
+  // be a round trip that can only start once their descriptors have arrived)
+  float* s_p = s_e + 4 * d_z + 4;
+  if (want_grad) {
+    for (int k = tid; k < P; k += NT) s_p[k] = f.params[(size_t)b * P + k];
+    if (tid < f.n_comp) cd = comps[tid];
   }
   __syncthreads();
   if (want_grad) {
     for (int c = tid; c < f.n_comp; c += NT) {
       if (c != tid) cd = comps[c];
-      const float* p = (c == tid && cd.n_par <= NPRE) ? pre : f.params + (size_t)b * P + cd.p_off;
+      const float* p = s_p + cd.p_off;
       float* g = s_g + cd.p_off;
       const float* acc = s + cd.a_off;
       switch (cd.kind) {
@@ -1368,11 +1367,15 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
       for (int k = tid; k < P; k += NT) s_g[k] += f.pos_grad[(size_t)b * P + k];
       __syncthreads();
     }
+    // A NaN log-likelihood (sigma^2 = bg^2 + model / t < 0 somewhere: tf/model.py:96 takes its square root) has a NaN gradient
+    // in the reference -- the square root's derivative is NaN there and NaN x 0 stays NaN through every pixel sum -- while the
+    // cotangent the kernels form (from 1 / sigma^2) stays finite: the whole row follows the reference.
+    const float poison = (s[0] + s[1]) != (s[0] + s[1]) ? __int_as_float(0x7fc00000) : 0.f;
     if (f.grad)
-      for (int k = tid; k < P; k += NT) f.grad[(size_t)b * P + k] = s_g[k];
+      for (int k = tid; k < P; k += NT) f.grad[(size_t)b * P + k] = s_g[k] + poison;
     if (f.zcols && f.grad_z && tid >= ZT0)
       for (int k = tid - ZT0; k < d_z; k += NT - ZT0)
-        f.grad_z[(size_t)b * d_z + k] = (s_g[__float_as_int(s_e[3 * d_z + k])] + s_e[k]) * s_e[d_z + k] + s_e[2 * d_z + k];
+        f.grad_z[(size_t)b * d_z + k] = (s_g[__float_as_int(s_e[3 * d_z + k])] + s_e[k]) * s_e[d_z + k] + s_e[2 * d_z + k] + poison;
   }
   if (tid == 0 && f.loglike) {
     float ll = -0.5f * (s[0] + s[1]);  // tf/model.py:99
@@ -1394,7 +1397,7 @@ __device__ __forceinline__ void finalize_sample(const CompDesc* __restrict__ com
 template <bool BASIC>
 __global__ void __launch_bounds__(128) gl_finalize_kernel(const CompDesc* __restrict__ comps, FinArgs f,
                                                           const float* __restrict__ partial, int n_chunks) {
-  extern __shared__ float s[];  // [A] accumulators, [P] parameter gradients, [d_z] prior terms, [3][d_z] bijector / prior derivatives
+  extern __shared__ float s[];  // [A] accumulators, [P] parameter gradients, [d_z] prior terms, [4][d_z] bijector / prior derivatives, [P] parameters
 #ifdef GL_EXPERIMENTS
   if (n_chunks < 0) return;  // GIGALENS_HIP_DBGFLAGS & 8: the cost of the bare launch (results undefined)
 #endif

@@ -362,6 +362,28 @@ def test_nan_semantics_sie_circular(gl):
     assert np.all(img[0] == 0) and np.all(np.isfinite(img)) and img[1].max() > 0
 
 
+def test_negative_variance_is_nan_in_value_and_gradient(gl):
+    """sigma^2 = bg^2 + model / t below zero somewhere: the reference's sqrt makes the sample's log-likelihood NaN and, through
+    the square root's derivative, every entry of its gradient row (tf/model.py:96-99); the other samples are untouched."""
+    wl = gl.workloads.make("C2", num_pix=24, batch=4)
+    obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+    packed = H.sample_packed(wl, sim, seed=4)
+    packed[1, -1] = -packed[1, -1].abs()  # a source of negative amplitude: the model dips below -bg^2 t at its peak
+    ll_o, _, g_o, _ = H.oracle_loglike_and_grad(wl, packed.cpu().double(), obs.cpu().numpy(), None, wl.batch)
+    assert np.isnan(ll_o[1]) and np.isnan(g_o[1]).all() and np.isfinite(ll_o[[0, 2, 3]]).all()
+    pm = gl.ForwardProbModel(wl.prior, obs.cpu().numpy(), wl.background_rms, wl.exp_time, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, _ = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    g = p.grad.cpu().numpy()
+    assert np.array_equal(np.isnan(ll.detach().cpu().numpy()), np.isnan(ll_o))
+    assert np.array_equal(np.isnan(g), np.isnan(g_o))
+    keep = [0, 2, 3]
+    assert np.allclose(ll.detach().cpu().numpy()[keep], ll_o[keep], rtol=LL_RTOL)
+    assert H.grad_col_err(g[keep], g_o[keep]).max() <= GRAD_RTOL_COL
+
+
 def test_error_conventions(gl):
     from gigalens_amd import _native
     wl = gl.workloads.make("C2", num_pix=16, batch=2)
