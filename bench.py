@@ -209,7 +209,8 @@ def epl_series_stats(wl, x_struct):
         n += 1
     if not n:
         return None
-    return {"mean_terms": ks / n, "mean_four_term_groups": groups / n, "mean_pair_trips": 0.5 * groups / n, "frac_odd": 0.0}
+    # the kernels peel the first four-term group out of the loop (gl_vec.hip.h four_first): the two-group loop runs the others
+    return {"mean_terms": ks / n, "mean_four_term_groups": groups / n, "mean_pair_trips": 0.5 * (groups / n - 1.0), "frac_odd": 0.0}
 
 
 _ISA_CACHE = {}
@@ -464,7 +465,7 @@ def main():
             K = torch.ceil(math.log(EPL_SERIES_TOL) / torch.log(e.clamp(1e-30, 1 - 1e-12)) + 2.0) - 1
             pick = int(torch.argmin((K - round(s0["mean_terms"])).abs()))
             g = float(torch.ceil((K[pick] + 1) / 4))
-            series = {"mean_terms": float(K[pick]), "mean_four_term_groups": g, "mean_pair_trips": 0.5 * g, "frac_odd": 0.0}
+            series = {"mean_terms": float(K[pick]), "mean_four_term_groups": g, "mean_pair_trips": 0.5 * (g - 1.0), "frac_odd": 0.0}
         mu = z0[pick].to(dev).contiguous().clone()
         lpk = ginf.tril_pack(torch.eye(d, device=dev) * 1e-3)
         sv_params = torch.cat([mu, lpk]).contiguous()
