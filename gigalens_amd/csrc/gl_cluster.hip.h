@@ -85,10 +85,14 @@ __device__ __forceinline__ V sersic_fwd_c(const float* __restrict__ d, V x, V y,
     const float c = d[SER_C], s = d[SER_S];
     V xt1 = (dx * c + dy * s) * d[SER_SQ], xt2 = (dy * c - dx * s) * d[SER_ISQ];
     r2 = xt1 * xt1 + xt2 * xt2;
+  } else if (keepL2) {
+    // (a pixel exactly on the source centre: 1e-30 keeps the kept logarithm finite, see sersic_vjp5_c; added inside the fused
+    // multiply-adds -- below the last bit of any r2 > 1e-23 -- instead of two v_max per pixel pair)
+    r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, V(1e-30f)));
   } else {
     r2 = dx * dx + dy * dy;
   }
-  if (keepL2) r2 = vmax(r2, V(1e-30f));    // (a pixel exactly on the source centre: keeps the kept logarithm finite, see sersic_vjp5_c)
+  if (ELL && keepL2) r2 = vmax(r2, V(1e-30f));
   V L2 = log2_(r2) * 0.5f + d[SER_L2IRS];  // log2(R / R_sersic) without the square root
   if (keepL2) *keepL2 = L2;
   st.u = exp2_(L2 * d[SER_INVN]);
@@ -152,7 +156,7 @@ template <class V>
 __device__ __forceinline__ void sersic_vjp5_c(const float* __restrict__ d, V x, V y, const SerStateC<V>& st, V gI, V (&va)[S5_N],
                                               V& gpx, V& gpy) {
   V dx = x - d[SER_CX], dy = y - d[SER_CY];
-  V r2 = vmax(dx * dx + dy * dy, V(1e-30f));
+  V r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, V(1e-30f)));  // the forward pass's floor
   V L2 = log2_(r2) * 0.5f + d[SER_L2IRS];
   V w = gI * st.E;
   V wu = w * st.u;
