@@ -693,9 +693,10 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
       ell = ell || m->comps[i].kind == K_SERSIC_ELLIPSE;
     }
     // the kernel addresses the derived / accumulator blocks in closed form: component-major, fixed block sizes
-    for (int i = 0; i < n_lens && ok_c; ++i) ok_c = m->comps[i].d_off == 4 * i && m->comps[i].a_off == NSTAT + NFW_NACC * i;
+    constexpr int NFWP = (NFW_ND + 3) & ~3, SERP = (SER_NDX + 3) & ~3;  // the strides gl_cluster_kernel walks the derived row with
+    for (int i = 0; i < n_lens && ok_c; ++i) ok_c = m->comps[i].d_off == NFWP * i && m->comps[i].a_off == NSTAT + NFW_NACC * i;
     for (int i = 0; i < n_src && ok_c; ++i)
-      ok_c = m->comps[n_lens + i].d_off == 4 * n_lens + 12 * i && m->comps[n_lens + i].a_off == NSTAT + NFW_NACC * n_lens + SER_NACC * i;
+      ok_c = m->comps[n_lens + i].d_off == NFWP * n_lens + SERP * i && m->comps[n_lens + i].a_off == NSTAT + NFW_NACC * n_lens + SER_NACC * i;
     ok_c = ok_c && (size_t)64 * m->Apad * sizeof(float) + sizeof(float) * 2 * glh::kNfwNodes <= 64 * 1024;
     if (ok_c) m->cluster = ell ? 2 : 1;
   }

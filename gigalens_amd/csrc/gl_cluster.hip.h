@@ -167,7 +167,7 @@ __device__ __forceinline__ void sersic_vjp5_c(const float* __restrict__ d, V x, 
   va[S5_A] = wu;
   va[S5_D] = wu * L2;
   va[S5_B] = w;
-  const float c = d[SER_IE] * d[SER_BN] * d[SER_INVN];
+  const float c = d[SER_CG];
   gpx -= qx * c;  // d I / d beta = -c q (dx, dy)
   gpy -= qy * c;
 }
@@ -176,8 +176,7 @@ template <class V>
 __device__ __forceinline__ void sersic_vjp5_keep_c(const float* __restrict__ d, V x, V y, const SerStateC<V>& st, V L2, V gI,
                                                    V (&va)[S5_N], V& gpx, V& gpy) {
   V dx = x - d[SER_CX], dy = y - d[SER_CY];
-  const float irs = d[SER_INVRS];
-  V ir2 = exp2_(L2 * -2.f) * (irs * irs);  // finite: the forward pass of a kept source clamps r2 at 1e-30
+  V ir2 = exp2_(L2 * -2.f) * d[SER_IRS2];  // finite: the forward pass of a kept source clamps r2 at 1e-30
   V w = gI * st.E;
   V wu = w * st.u;
   V q = wu * ir2;
@@ -187,7 +186,7 @@ __device__ __forceinline__ void sersic_vjp5_keep_c(const float* __restrict__ d, 
   va[S5_A] = wu;
   va[S5_D] = wu * L2;
   va[S5_B] = w;
-  const float c = d[SER_IE] * d[SER_BN] * d[SER_INVN];
+  const float c = d[SER_CG];
   gpx -= qx * c;
   gpy -= qy * c;
 }
@@ -225,7 +224,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_cluster_kernel(MainArgs a, int n
   static_assert(MODE == IMG_BWD || MODE == LL_GRAD, "gradient modes only (forward modes: gl_main_kernel)");
   using V = v2f;
   constexpr int W = 2;
-  constexpr int SERP = (SER_ND + 2 + 3) & ~3, NFWP = (NFW_ND + 3) & ~3;
+  constexpr int SERP = (SER_NDX + 3) & ~3, NFWP = (NFW_ND + 3) & ~3;
   extern __shared__ float smem[];
   float* s_acc = smem;                  // [64][Apad]
   float* s_tab = smem + 64 * a.Apad;    // [NFW_TAB_NODES][2]: h(X), dh/du du

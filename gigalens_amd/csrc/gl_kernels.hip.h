@@ -1622,8 +1622,8 @@ __global__ void __launch_bounds__(256) gl_point_kernel(CompDesc cd, const float*
     case K_NFW_ELLIPSE: { float d[NFE_ND]; nfw_ell_prep<float>(p, d); nfw_ell_fwd<float>(d, px, py, o0, o1); } break;
     case K_TNFW: { float d[TNF_ND]; tnfw_prep<float>(p, d); tnfw_fwd<float>(d, px, py, o0, o1); } break;
     case K_CORE_SERSIC: { float d[CSR_ND]; core_sersic_prep<float>(p, d); o0 = core_sersic_fwd<float>(d, px, py); } break;
-    case K_SERSIC: { float d[SER_ND + 2]; sersic_prep<float>(p, false, d); o0 = sersic_fwd(d, px, py); } break;
-    case K_SERSIC_ELLIPSE: { float d[SER_ND + 2]; sersic_prep<float>(p, true, d); o0 = sersic_fwd(d, px, py); } break;
+    case K_SERSIC: { float d[SER_NDX]; sersic_prep<float>(p, false, d); o0 = sersic_fwd(d, px, py); } break;
+    case K_SERSIC_ELLIPSE: { float d[SER_NDX]; sersic_prep<float>(p, true, d); o0 = sersic_fwd(d, px, py); } break;
     case K_SHAPELETS: {
       if (cd.iparam > SH_CAP) {  // runtime-order path; amplitudes straight from the parameter row (same triangle order)
         float d[SHP_AMP];
@@ -1674,8 +1674,8 @@ __global__ void __launch_bounds__(256) gl_basis_point_kernel(CompDesc cd, const 
   float v = 0.f;
   switch (cd.kind) {
     case K_CORE_SERSIC: { float d[CSR_ND]; core_sersic_prep<float>(q, d); v = core_sersic_fwd<float>(d, px, py); } break;
-    case K_SERSIC: { float d[SER_ND + 2]; sersic_prep<float>(q, false, d); v = sersic_fwd(d, px, py); } break;
-    case K_SERSIC_ELLIPSE: { float d[SER_ND + 2]; sersic_prep<float>(q, true, d); v = sersic_fwd(d, px, py); } break;
+    case K_SERSIC: { float d[SER_NDX]; sersic_prep<float>(q, false, d); v = sersic_fwd(d, px, py); } break;
+    case K_SERSIC_ELLIPSE: { float d[SER_NDX]; sersic_prep<float>(q, true, d); v = sersic_fwd(d, px, py); } break;
   }
   out[i] = v;
 }

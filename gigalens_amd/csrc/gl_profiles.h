@@ -59,7 +59,8 @@ enum { SHR_NACC = 2 };
 enum { SIS_CX = 0, SIS_CY, SIS_TE, SIS_ND };
 enum { SIS_NACC = 3 };
 // SERSIC / SERSIC_ELLIPSE (one code path; the spherical profile is the e=0 member, sersic.py:52-55)
-enum { SER_CX = 0, SER_CY, SER_C, SER_S, SER_SQ, SER_ISQ, SER_INVRS, SER_INVN, SER_BN, SER_IE, SER_ND, SER_L2IRS = SER_ND /* log2(1/R_sersic) */ };
+enum { SER_CX = 0, SER_CY, SER_C, SER_S, SER_SQ, SER_ISQ, SER_INVRS, SER_INVN, SER_BN, SER_IE, SER_ND, SER_L2IRS = SER_ND /* log2(1/R_sersic) */,
+       SER_CG /* Ie bn / n */, SER_IRS2 /* 1 / R_sersic^2 */, SER_PAD, SER_NDX /* floats of the block */ };
 enum { SERA_CX = 0, SERA_CY, SERA_PHI, SERA_SQ, SERA_L, SERA_INVN, SERA_BN, SERA_IE, SER_NACC };
 // SHAPELETS
 enum { SHP_CX = 0, SHP_CY, SHP_IB, SHP_NMAX, SHP_AMP = 4 };
@@ -115,7 +116,7 @@ GL_HD int kind_num_derived(int kind, int iparam) {
     case K_TNFW: return 8;
     case K_CORE_SERSIC: return 16;
     case K_SERSIC:
-    case K_SERSIC_ELLIPSE: return SER_ND + 2;
+    case K_SERSIC_ELLIPSE: return SER_NDX;
     case K_SHAPELETS:  // n_max <= 10: amplitude triangle zero-padded to n_max = 10, then the square matrix; above: the triangle only
       return iparam <= SH_CAP ? SHP_SQ + SH_SQ * SH_SQ : SHP_AMP + ((SH_MAXLB + 3) & ~3);
     case K_USER_MASS:
@@ -704,7 +705,11 @@ template <class R> GL_HD void sersic_prep(const R* p, bool ellipse, R* d) {
   d[SER_BN] = (R)1.9992 * p[1] - (R)0.3271;  // sersic.py:33
   d[SER_IE] = rest[2];
   d[SER_L2IRS] = -p_log(p[0]) * (R)kLog2e;
-  d[SER_ND + 1] = (R)0;
+  // products of per-sample constants the cluster kernel's VJP multiplies pixel values with: wave-uniform, but there is no scalar
+  // float unit to form them on, so once here instead of four vector instructions per source and tile there
+  d[SER_CG] = d[SER_IE] * d[SER_BN] * d[SER_INVN];
+  d[SER_IRS2] = d[SER_INVRS] * d[SER_INVRS];
+  d[SER_PAD] = (R)0;
 }
 template <class R> GL_HD R sersic_fwd(const R* d, R x, R y) {
   R dx = x - d[SER_CX], dy = y - d[SER_CY];

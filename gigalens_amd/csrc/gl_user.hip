@@ -269,8 +269,9 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
     return fail(GL_ELAUNCH, "hiprtcCreateProgram failed");
   for (int mode = 0; mode < 4; ++mode) (void)hiprtcAddNameExpression(prog, names[mode].c_str());
   const std::string inc = "-I" + csrc_dir();
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
-  const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+  // (-fno-slp-vectorize: as for the interpreter of the library itself, gl_launch_generic.hip.h)
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", inc.c_str()};
+  const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t n = 0;
     (void)hiprtcGetProgramLogSize(prog, &n);

