@@ -350,8 +350,8 @@ def cluster_model(cfg, W=2):
     """gl_cluster_kernel (csrc/gl_cluster.hip.h) at full capacity (every compile-time component slot in use: BASELINE configs 4
     and 5).  The steady-state tile loop is the first hot top-level loop; its component bodies sit behind wave-uniform count
     guards (always taken at capacity).  The only blocks that do not run every trip are the lane-by-lane closed-form NFW
-    fallback (X outside the h(X) table or exactly 1: a handful of lanes per launch): conditional blocks of scalar-per-lane code
-    -- no scalar loads, no memory, at most two packed instructions, unlike every component body -- weighted 0.  Checked against
+    fallback (X outside the h(X) table or exactly 1: a handful of lanes per launch): the blocks entered as the fall-through of
+    an `s_cbranch_execz` (lane-masked code; the count guards are scalar-condition branches), weighted 0.  Checked against
     SQ_INSTS_VALU in profiles/ (C4: 1248 modelled vs 1242-1253 counted per pixel)."""
     tile = _hot_loops(cfg, 1000)[0]
     latches = [b for b in tile.blocks if tile.header in cfg.succ[b]]
@@ -360,10 +360,23 @@ def cluster_model(cfg, W=2):
         mandatory &= cfg.dom[lt]
     out = {k: float(v) for k, v in cfg.tally(mandatory).items()}
     n_fallback = 0
+    order = sorted(cfg.blocks)
+    nxt = {b: order[i + 1] for i, b in enumerate(order[:-1])}
+
+    def masked_entry(b):
+        """b is entered under a lane mask: every way into it is the fall-through of an `s_cbranch_execz` (the lanes that took
+        the closed-form NFW branch), as opposed to the wave-uniform count guards (scalar-condition branches)."""
+        preds = cfg.pred[b]
+        return bool(preds) and all(cfg.ins[cfg.blocks[q][-1]][1] == "s_cbranch_execz" and nxt.get(q) == b for q in preds)
+
+    entries = {b for b in tile.blocks - mandatory if masked_entry(b)}
+
+    def divergent(b):  # inside a lane-masked region: dominated by one of its entries
+        return bool(entries & cfg.dom[b])
+
     for b in sorted(tile.blocks - mandatory):
         t = cfg.tally([b])
-        fallback = t["smem"] == 0 and t["vmem"] == 0 and t["lds"] == 0 and t["packed"] <= 2 and t["valu"] >= 3
-        if fallback:
+        if divergent(b):
             n_fallback += 1
             continue
         for k in out:
