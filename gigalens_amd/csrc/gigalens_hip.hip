@@ -452,7 +452,7 @@ int run_likelihood(const gl_model* m, int B, const Workspace& w, int chunk, int 
   *extra_stats = nullptr;
   *use_partial = 1;
   *n_rows = n_chunks;
-  if (!m->has_post && a.order) {
+  if (!m->has_post && a.order && want_grad) {  // (the rounds are counted for the gradient kernels' occupancy; forward-only calls keep the plain grid)
     a.tail_rows = tail_plan(m, B, n_chunks, &a.tail_from, &a.n_rows);
     a.n_samples = B;
     *n_rows = a.n_rows;
