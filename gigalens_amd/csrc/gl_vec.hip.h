@@ -43,6 +43,10 @@ template <class V> __device__ __forceinline__ V vexp(V x) {  // exp with the pro
 }
 template <> __device__ __forceinline__ float vexp<float>(float x) { return glm::exp_(x); }
 template <class V> __device__ __forceinline__ V vlog(V x) { return log2_(x) * (float)kLn2; }
+__device__ __forceinline__ float floor_at(float a, float lo) { return __builtin_fmaxf(a, lo); }
+__device__ __forceinline__ v2f floor_at(v2f a, float lo) { return v2f{__builtin_fmaxf(a.x, lo), __builtin_fmaxf(a.y, lo)}; }
+__device__ __forceinline__ float clamp3(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
+__device__ __forceinline__ v2f clamp3(v2f a, float lo, float hi) { return v2f{__builtin_amdgcn_fmed3f(a.x, lo, hi), __builtin_amdgcn_fmed3f(a.y, lo, hi)}; }
 template <class V> __device__ __forceinline__ V vmin(V a, V b) { return a < b ? a : b; }
 template <class V> __device__ __forceinline__ V vmax(V a, V b) { return a > b ? a : b; }
 __device__ __forceinline__ float hsum(float a) { return a; }
@@ -78,7 +82,7 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   st.inv = pos ? r : V(0.f);
   st.Cs = pos ? X * r : V(1.f);
   st.Ss = st.yr * st.inv;
-  V iRc = vmin(vmax(r, V(1e-10f)), V(1e10f));
+  V iRc = clamp3(r, 1e-10f, 1e10f);  // one v_med3 per lane (a NaN gives the lower bound, like the two selects did)
   st.invc = (iRc == r) ? r : V(0.f);  // clip_by_value passes gradient only inside the clamp
   V twoc = (st.Cs * st.Cs - st.Ss * st.Ss) * 2.f;
   // scalar-loaded trip count and coefficients (wave-uniform address): SGPR operands, scalar loop control
@@ -270,12 +274,14 @@ template <class V, bool ELL = true> __device__ __forceinline__ V sersic_fwd_v(co
 }
 template <class V, bool SRC, bool ELL = true>
 __device__ __forceinline__ void sersic_vjp_v(const float* d, const SerStateV<V>& st, V gI, V* acc, V& gpx, V& gpy) {
-  auto pos = st.r2 > V(0.f);
+  // A pixel exactly on the centre (r2 = 0): u = 0 there, so g_u u and g_L are (signed) zeros and the reference's selects
+  // (`where(x > 0, ...)` in TF's pow gradient) only keep 0 x inf from becoming NaN.  Flooring r2 and log2(R / Rs) does the same
+  // with one v_max per lane each instead of a compare and two selects: 0 x (finite) = 0.
   V gE = gI * st.E;
   V tI = gE * d[SER_IE];
   V guu = -(tI * st.u) * d[SER_BN];
   V gL = guu * d[SER_INVN];
-  V k = pos ? gL * rcp(st.r2) : V(0.f);
+  V k = gL * rcp(floor_at(st.r2, 1e-37f));
   V gdx, gdy;
   if constexpr (ELL) {
     const float c = d[SER_C], s = d[SER_S], sq = d[SER_SQ], isq = d[SER_ISQ];
@@ -293,7 +299,7 @@ __device__ __forceinline__ void sersic_vjp_v(const float* d, const SerStateV<V>&
   acc[SERA_CX] -= gdx;
   acc[SERA_CY] -= gdy;
   acc[SERA_L] += gL;
-  acc[SERA_INVN] += pos ? guu * st.L2 : V(0.f);  // x ln2 in the epilogue
+  acc[SERA_INVN] += guu * floor_at(st.L2, -1e30f);  // x ln2 in the epilogue
   acc[SERA_BN] -= tI * (st.u - 1.f);
   acc[SERA_IE] += gE;
   if (SRC) { gpx += gdx; gpy += gdy; }
