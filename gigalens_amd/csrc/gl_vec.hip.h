@@ -62,7 +62,7 @@ __device__ __forceinline__ float hsum(v2f a) { return a.x + a.y; }
 // pair, against two for advancing E_n plus two per series when the terms e^{i(2n+1)theta} are formed explicitly: 6 instead
 // of 8 per term in gradient mode (three series), 2 instead of 4 forward-only.  The small terms are added first.
 template <class V> struct EplStateV {
-  V xr, yr, inv, invc, L2, P, Cs, Ss, Ox, Oy;
+  V xr, yr, inv, invc, L2, P, Cs, Ss, arx, ary;  // (arx, ary) = P Omega: the deflection in the lens frame
   V f0, f1, t0, t1;  // Clenshaw tails (b_0, b_1) of the d/df and d/dt series
 };
 
@@ -145,11 +145,12 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   }
   const V o0 = o1, ob = o2;  // b_0, b_1 of Omega
   if (GRAD) { st.f0 = f1; st.f1 = f2; st.t0 = t1; st.t1 = t2; }
-  st.Ox = (o0 - ob) * st.Cs;
-  st.Oy = (o0 + ob) * st.Ss;
+  const V Ox = (o0 - ob) * st.Cs, Oy = (o0 + ob) * st.Ss;
   st.L2 = log2_(iRc * d[EPL_B]);
   st.P = exp2_(st.L2 * d[EPL_TM1]) * d[EPL_P0];  // 2b/(1+q) (b/R)^(t-1), epl.py:55
-  V arx = st.P * st.Ox, ary = st.P * st.Oy;
+  const V arx = st.P * Ox, ary = st.P * Oy;
+  st.arx = arx;
+  st.ary = ary;
   bx -= arx * c - ary * s;
   by -= arx * s + ary * c;
 }
@@ -157,21 +158,20 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
 template <class V>
 __device__ __forceinline__ void epl_vjp_v(const float* d, V gx, V gy, const EplStateV<V>& st, V* acc) {
   const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q], tm1 = d[EPL_TM1];
-  V P = st.P;
-  V arx = P * st.Ox, ary = P * st.Oy;
+  const V P = st.P, arx = st.arx, ary = st.ary;
   V grx = gx * c + gy * s, gry = gy * c - gx * s;  // the cotangent in the lens frame
   V g_phi = gry * arx - grx * ary;                 // g x alpha is rotation invariant: no need for alpha in the sky frame
-  V gP = grx * st.Ox + gry * st.Oy;
+  const V cross = g_phi;                           // = gOy Ox - gOx Oy below (alpha_r = P Omega): formed once
+  V gW_W = grx * arx + gry * ary;                  // gP P with gP = g . Omega: the cotangent of W = (b/R)^(t-1), times W
   V gOx = P * grx, gOy = P * gry;
   // dot and cross products of (gOx, gOy) with a series (Sx, Sy) = ((b0 - b1) Cs, (b0 + b1) Ss) straight from its tails:
   //   gOx Sx + gOy Sy = b0 (A + B) + b1 (B - A),  gOy Sx - gOx Sy = b0 (C - D) - b1 (C + D)
   V A = gOx * st.Cs, B = gOy * st.Ss, C = gOy * st.Cs, D = gOx * st.Ss;
   V dotp = A + B, dotm = B - A, crsm = C - D, crsp = C + D;
   // d Omega/d theta = i S with S = sum (2n+1) c_n E_n = Omega + 2 f dOmega/df  (c_n ~ f^n): no separate S sum
-  V g_ang = (gOy * st.Ox - gOx * st.Oy) + (st.f0 * crsm - st.f1 * crsp) * d[EPL_F2];
+  V g_ang = cross + (st.f0 * crsm - st.f1 * crsp) * d[EPL_F2];
   V g_t = st.t0 * dotp + st.t1 * dotm;
   V g_f = st.f0 * dotp + st.f1 * dotm;
-  V gW_W = gP * P;
   g_t += gW_W * (st.L2 * (float)kLn2);
   V gR0 = -(gW_W * st.invc) * tm1;
   V gai = g_ang * st.inv;
