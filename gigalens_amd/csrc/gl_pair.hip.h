@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   for (int k = 0; k < NACC_L; ++k) accL[k] = V(0.f);
 #pragma unroll
   for (int k = 0; k < NACC_C; ++k) accC[k] = V(0.f);
-  V st0 = V(0.f), st1 = V(0.f);
+  V st0 = V(0.f), st1 = V(0.f);  // chi^2, and the normalisation as sum of w log2(sigma^2): x ln2 and + log(2 pi) sum w at the end
+  V wsum = V(0.f);                // sum of the weights over the ragged / masked tiles (whole tiles count their pixels)
+  int n_whole = 0;                // whole unmasked tiles of this workgroup
   const float* dL[NL > 0 ? NL : 1];
   const float* dC[NLIGHT > 0 ? NLIGHT : 1];
 #pragma unroll
@@ -159,12 +161,15 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
       V dmo = m - o;
       V s2 = herr ? e * e : m * a.inv_t + a.bg2;
       V is2 = rcp(s2);
-      V nm = vlog<V>(s2 * (float)(2 * kPi));  // NaN for sigma^2 < 0, like log(2 pi sqrt(.)^2) in the reference
+      // log(2 pi sigma^2) = ln2 (log2 sigma^2 + log2 2 pi): the pixel loop sums the bare log2 (NaN for sigma^2 < 0, like
+      // log(2 pi sqrt(.)^2) in the reference); the two constants join once per workgroup
+      V nm = log2_(s2);
       V c2 = __builtin_elementwise_fma(nm, V(0.f), dmo * dmo * is2);  // + 0 * nm: carries that NaN into chi^2
       if (CHECK) {  // invalid lanes carry weight 0; "x * 0" would keep a NaN, so select instead
         auto use = w != V(0.f);
         st0 += use ? c2 * w : V(0.f);
         st1 += use ? nm * w : V(0.f);
+        wsum += w;
       } else {
         st0 += c2;
         st1 += nm;
@@ -206,13 +211,15 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
     if (GL_DBG(a.dbg, 1)) base = p1;
     if (plain) {
       if (has_err)
-        for (; base + WG * W <= p1; base += WG * W) tile(base, std::false_type{}, std::integral_constant<int, 1>{});
+        for (; base + WG * W <= p1; base += WG * W, ++n_whole) tile(base, std::false_type{}, std::integral_constant<int, 1>{});
       else
-        for (; base + WG * W <= p1; base += WG * W) tile(base, std::false_type{}, std::integral_constant<int, 0>{});
+        for (; base + WG * W <= p1; base += WG * W, ++n_whole) tile(base, std::false_type{}, std::integral_constant<int, 0>{});
     }
     for (; base < p1; base += WG * W) tile(base, std::true_type{}, std::integral_constant<int, 2>{});
   }
   if (MODE == IMG_FWD) return;
+  // this lane's share of sum w log(2 pi sigma^2) from its sum of w log2 sigma^2 and its sum of w
+  auto norm_term = [](float l2sum, float w) { return (l2sum + w * 2.6514961294723187f) * (float)kLn2; };  // log2(2 pi)
   float* out = a.partial + ((size_t)b * n_rows + row) * a.A;
   if (row == 0)  // the rows of the sample that no workgroup writes (the other kind of sample has more rows than this one)
     for (int i = my_rows * a.A + tid; i < n_rows * a.A; i += WG) out[i] = 0.f;
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
 #pragma unroll
     for (int k = 0; k < NVP; ++k) vals[k] = 0.f;
     vals[0] = (MODE == LL_GRAD) ? hsum(st0) : 0.f;
-    vals[1] = (MODE == LL_GRAD) ? hsum(st1) : 0.f;
+    vals[1] = (MODE == LL_GRAD) ? norm_term(hsum(st1), hsum(wsum) + (float)(W * n_whole)) : 0.f;
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int kind = LK::kinds[i];
@@ -289,7 +296,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
     if (last_lane) s_row[idx] = v;
   };
   put((MODE == LL_FWD || MODE == LL_GRAD) ? hsum(st0) : 0.f, 0);
-  put((MODE == LL_FWD || MODE == LL_GRAD) ? hsum(st1) : 0.f, 1);
+  put((MODE == LL_FWD || MODE == LL_GRAD) ? norm_term(hsum(st1), hsum(wsum) + (float)(W * n_whole)) : 0.f, 1);
   if (last_lane) { s_row[2] = 0.f; s_row[3] = 0.f; }
   __syncthreads();
   for (int k = tid; k < a.A; k += WG) {
