@@ -1695,8 +1695,9 @@ int gl_adam_update(float* x, const float* grad, float* m, float* v, int64_t n, f
   if (!t_dev_or_null && t < 1) return fail(GL_EINVAL, "the step count t starts at 1");
   // t_dev layout: [0] the counter as a double, [1] 8 bytes of launch ticket (zero-initialised by the caller)
   unsigned* ticket = t_dev_or_null ? reinterpret_cast<unsigned*>(t_dev_or_null + 1) : nullptr;
+  const float c1 = (float)(1.0 - std::pow((double)beta1, (double)t)), c2 = (float)(1.0 - std::pow((double)beta2, (double)t));
   hipLaunchKernelGGL(gl_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, x, grad, m,
-                     v, (long long)n, grad_scale, lr, beta1, beta2, eps, (double)t, t_dev_or_null, ticket);
+                     v, (long long)n, grad_scale, lr, beta1, beta2, eps, (double)t, t_dev_or_null, ticket, c1, c2);
   GL_HIP(hipGetLastError());
   return GL_OK;
 }

@@ -1419,9 +1419,15 @@ __global__ void __launch_bounds__(256) gl_adam_kernel(float* __restrict__ x, con
                                                       float* __restrict__ m, float* __restrict__ v, long long n,
                                                       float grad_scale, float lr, float b1, float b2, float eps,
                                                       double t_host, double* __restrict__ t_dev,
-                                                      unsigned* __restrict__ ticket) {
+                                                      unsigned* __restrict__ ticket, float c1_host, float c2_host) {
+  // the bias corrections 1 - beta^t: from the host when it knows the step count (two double-precision pow per THREAD were most
+  // of this kernel's 4.5 us), on the device only under graph replay, where the count lives in t_dev
   const double t = (t_dev ? t_dev[0] : t_host) + (t_dev ? 1.0 : 0.0);
-  const float c1 = (float)(1.0 - ::pow((double)b1, t)), c2 = (float)(1.0 - ::pow((double)b2, t));
+  float c1 = c1_host, c2 = c2_host;
+  if (t_dev) {
+    c1 = (float)(1.0 - ::pow((double)b1, t));
+    c2 = (float)(1.0 - ::pow((double)b2, t));
+  }
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
     const float g = grad[i] * grad_scale;
