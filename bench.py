@@ -528,9 +528,12 @@ def main():
     # each rank's shard and NO collective -- how MAP and HMC shard (jax/inference.py:32-80,157-208) -- so that the cost of the
     # SVI step's extra launches and of its all-reduce can be read off the line
     sharded = None
+    kernel_ms_fg = []
     if world > 1 and mode == "svi":
         for _ in range(min(args.warmup, 20)):
             pm.log_prob_and_grad(sim, z)
+        if events:
+            model.set_timing(n_ev, stride)
         gdist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -540,6 +543,9 @@ def main():
         gdist.barrier()
         e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         gdist.allreduce_max_(e2)
+        if events:
+            kernel_ms_fg = sorted(model.timing_drain())
+            model.set_timing(0)
         sharded = {"value": round(B * world * args.steps / float(e2.item()), 1), "unit": "sims/s",
                    "ms_per_step": round(1e3 * float(e2.item()) / args.steps, 4),
                    "what": "ForwardProbModel.log_prob_and_grad on every rank's shard, no collective (MAP / HMC sharding)"}
@@ -550,10 +556,23 @@ def main():
             sys.exit(4)
         ms_per_step = 1e3 * elapsed / args.steps
         sims = B * world * args.steps / elapsed
+        # With several ranks and no --mode given, the line's `value` stays the metric BASELINE.json names at every N -- the
+        # forward+gradient step on every rank's shard of the samples, which has no data-path collective -- so that the per-N
+        # values compare like with like; the SVI driver's step, the one place the path exchanges data (one all-reduce of the
+        # fused [ELBO, gradient] buffer per step), is timed in the same run and reported beside it as `svi_step`.
+        svi_side = None
+        line_mode = mode
+        if world > 1 and args.mode == "auto" and sharded is not None:
+            svi_side = {"value": round(sims, 1), "unit": "particles/s", "ms_per_step": round(ms_per_step, 4),
+                        "allreduce_floats": n_coll, "backend": torch.distributed.get_backend(),
+                        "what": ("inference.svi_step_buffer (eps draw, gl_svi_sample, log_prob forward+gradient, gl_svi_grad, "
+                                 "all-reduce of the fused [ELBO, grad] buffer) + fused Adam launch (lr 0), particles sharded")}
+            sims, ms_per_step, line_mode = sharded["value"], sharded["ms_per_step"], "fwdgrad"
+            kernel_ms = kernel_ms_fg or kernel_ms
         roofline = None
         if kernel_ms:
             roofline, series_fg = roofline_of(model, wl, sim, x, kernel_ms, ms_per_step, err, stride)
-            if mode != "svi":
+            if line_mode != "svi":
                 series = series_fg
             roofline["note"] = ("path is VALU/transcendental-bound (SURVEY 8d): the HBM fraction is priced with the "
                                 "simulate()-boundary bytes B1 as the metric asks; the binding bound is the fp32 vector rate "
@@ -574,20 +593,26 @@ def main():
             "config": {"workload": f"{wl.name}: {wl.description}, {wl.sim_config.num_pix}x{wl.sim_config.num_pix} px, "
                                    f"batch {B} per GPU, fp32" + (" (BASELINE.json configs[1])" if wl.name == "C2" else "")
                                    + (" (BASELINE.json configs[4]: per-rank shard of the 2048-particle SVI)" if wl.name == "C5" else ""),
-                       "samples_per_gpu": B, "pixels": N, "params_per_sample": P, "z_dim": d, "mode": mode,
+                       "samples_per_gpu": B, "pixels": N, "params_per_sample": P, "z_dim": d, "mode": line_mode,
                        "untimed_preroll_steps": n_pre, "kernel_events_in_timed_loop": events,
                        "epl_series": series,
-                       "parallelism": (f"dp{world}: particle shards, one {n_coll}-float all-reduce per step "
-                                       f"(torch.distributed backend {torch.distributed.get_backend()}; nccl = RCCL over xGMI)"
-                                       if world > 1 else "single GPU"),
+                       "parallelism": ("single GPU" if world == 1 else
+                                       (f"dp{world}: particle shards, one {n_coll}-float all-reduce per step "
+                                        f"(torch.distributed backend {torch.distributed.get_backend()}; nccl = RCCL over xGMI)"
+                                        if line_mode == "svi" else
+                                        f"dp{world}: samples sharded over the ranks, no data-path collective in this step (barrier + "
+                                        f"max-over-ranks timing only); the SVI step with its {n_coll}-float all-reduce "
+                                        f"(backend {torch.distributed.get_backend()}; nccl = RCCL over xGMI) is `svi_step`")),
                        "step": ("inference.svi_step_buffer (eps draw, gl_svi_sample, log_prob forward+gradient, gl_svi_grad, all-reduce of "
-                                f"the fused {n_coll}-float [ELBO, grad] buffer) + fused Adam launch (lr 0)" if mode == "svi" else
+                                f"the fused {n_coll}-float [ELBO, grad] buffer) + fused Adam launch (lr 0)" if line_mode == "svi" else
                                 "ForwardProbModel.log_prob_and_grad: log_prob forward + gradient w.r.t. z (bijector, "
                                 "kernels, prior) in one native launch sequence")},
             "roofline": roofline,
             "oracle_spot_check": check,
         }
-        if sharded is not None:
+        if svi_side is not None:
+            out["svi_step"] = svi_side
+        elif sharded is not None:
             out["sharded_fwdgrad_without_collective"] = sharded
         if world == 1 and not args.no_configs and args.workload.upper() == "C2":
             del pm, sim, z
