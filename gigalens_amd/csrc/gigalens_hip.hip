@@ -699,6 +699,14 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
       ok_c = m->comps[n_lens + i].d_off == NFWP * n_lens + SERP * i && m->comps[n_lens + i].a_off == NSTAT + NFW_NACC * n_lens + SER_NACC * i;
     ok_c = ok_c && (size_t)64 * m->Apad * sizeof(float) + sizeof(float) * 2 * glh::kNfwNodes <= 64 * 1024;
     if (ok_c) m->cluster = ell ? 2 : 1;
+    // ... in its component-per-wave form (gl_clusterw.hip.h) when the model fills at least 60 % of the component slots of the
+    // instantiation that holds it (4 waves x (1 + 2), (2 + 3) or (2 + 5) halos + sources): an unused slot is evaluated all the same.
+    // GIGALENS_HIP_CLUSTER: 1 = the pixel-split kernel for every cluster model, 2 = the component-per-wave kernel for every one
+    if (m->cluster) {
+      const int cap = (n_lens <= 4 && n_src <= 8) ? 12 : (n_src <= 12 ? 20 : 28);
+      const int mode = env_int("GIGALENS_HIP_CLUSTER", -1);
+      m->cluster_w = mode == 2 || (mode != 1 && 10 * (n_lens + n_src) >= 6 * cap);
+    }
   }
   m->target_wgs = std::max(1, env_int("GIGALENS_HIP_TARGET_WGS", 2048));
   m->target_wgs_set = getenv("GIGALENS_HIP_TARGET_WGS") != nullptr;
@@ -758,6 +766,18 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
   if (m->has_nfw) {
     std::vector<float> tab;
     glh::build_nfw_table([](double X, double& g, double& gp) { glp::nfw_gw<double>(X, g, gp); }, tab);
+    // behind the table: the constant blocks of an unused component slot of gl_clusterw_kernel (zero amplitude, all else finite)
+    const float neutral_nfw[4] = {0.f, 0.f, 1.f, 0.f};  // NFW_CX, NFW_CY, NFW_INVRS, NFW_K0
+    float neutral_ser[16] = {0.f};
+    neutral_ser[glp::SER_C] = neutral_ser[glp::SER_SQ] = neutral_ser[glp::SER_ISQ] = neutral_ser[glp::SER_INVRS] = 1.f;
+    neutral_ser[glp::SER_INVN] = neutral_ser[glp::SER_IRS2] = 1.f;
+    neutral_ser[glp::SER_BN] = 1.6721f;  // n = 1; SER_IE = SER_CG = 0
+    tab.insert(tab.end(), neutral_nfw, neutral_nfw + 4);
+    tab.insert(tab.end(), neutral_ser, neutral_ser + 16);
+    // ... and the table of the same function in s = X^2 (gl_host_tables.h::build_nfw_table_s), [4][kNfwSIntervals]
+    std::vector<float> tab_s;
+    glh::build_nfw_table_s([](double X, double& g, double& gp) { glp::nfw_gw<double>(X, g, gp); }, tab_s);
+    tab.insert(tab.end(), tab_s.begin(), tab_s.end());
     ok = ok && up((void**)&m->d_nfw_tab, tab.data(), tab.size() * sizeof(float));
   }
   if (m->has_table) {

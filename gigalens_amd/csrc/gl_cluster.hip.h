@@ -42,8 +42,8 @@ template <class V> struct SerStateL { V L2; };
 // NFW forward on a pixel pair, leaving what the VJP needs (nfw_vjp_v written once, split at the state):
 //   a = K0 h;  cot(K0) = ga h;  gX0 = ga p, p = [X0 > 1e-6] K0 h';  t = gR0 / R0 = ga w, w = [R0 > 1e-7] p / (Rs R0);
 //   cot(Rs) = -gX0 X0 / Rs = -ga uu, uu = p X0 / Rs        (ga = g . (dx, dy))
-template <class V>
-__device__ __forceinline__ void nfw_fwd_c(const float* __restrict__ d, const float* __restrict__ s_tab, V x, V y, V& bx, V& by,
+template <class V, class P = const float*>
+__device__ __forceinline__ void nfw_fwd_c(P d, const float* __restrict__ s_tab, V x, V y, V& bx, V& by,
                                           NfwStateC<V>& st) {
   const float invrs = d[NFW_INVRS], K0 = d[NFW_K0];
   V dx = x - d[NFW_CX], dy = y - d[NFW_CY];
@@ -62,8 +62,8 @@ __device__ __forceinline__ void nfw_fwd_c(const float* __restrict__ d, const flo
   bx -= a * dx;
   by -= a * dy;
 }
-template <class V>
-__device__ __forceinline__ void nfw_vjp_c(const float* __restrict__ d, V x, V y, V gx, V gy, const NfwStateC<V>& st,
+template <class V, class P = const float*>
+__device__ __forceinline__ void nfw_vjp_c(P d, V x, V y, V gx, V gy, const NfwStateC<V>& st,
                                           V (&va)[NFW_NACC]) {
   V dx = x - d[NFW_CX], dy = y - d[NFW_CY];
   V ga = gx * dx + gy * dy;
@@ -77,8 +77,8 @@ __device__ __forceinline__ void nfw_vjp_c(const float* __restrict__ d, V x, V y,
 
 // Sersic forward / VJP with the state split (sersic_fwd_v / sersic_vjp_v of gl_vec.hip.h); ELL = false is the spherical
 // profile (sersic.py:23-66 passes e1 = e2 = 0: no rotation, no axis-ratio stretch, no ellipticity gradients)
-template <class V, bool ELL>
-__device__ __forceinline__ V sersic_fwd_c(const float* __restrict__ d, V x, V y, SerStateC<V>& st, V* keepL2 = nullptr) {
+template <class V, bool ELL, class P = const float*>
+__device__ __forceinline__ V sersic_fwd_c(P d, V x, V y, SerStateC<V>& st, V* keepL2 = nullptr) {
   V dx = x - d[SER_CX], dy = y - d[SER_CY];
   V r2;
   if constexpr (ELL) {
@@ -99,8 +99,8 @@ __device__ __forceinline__ V sersic_fwd_c(const float* __restrict__ d, V x, V y,
   st.E = vexp<V>((st.u - 1.f) * -d[SER_BN]);
   return st.E * d[SER_IE];
 }
-template <class V, bool ELL>
-__device__ __forceinline__ void sersic_vjp_c(const float* __restrict__ d, V x, V y, const SerStateC<V>& st, V gI,
+template <class V, bool ELL, class P = const float*>
+__device__ __forceinline__ void sersic_vjp_c(P d, V x, V y, const SerStateC<V>& st, V gI,
                                              V (&va)[SER_NACC], V& gpx, V& gpy) {
   V dx = x - d[SER_CX], dy = y - d[SER_CY];
   V gE = gI * st.E;
@@ -152,8 +152,8 @@ __device__ __forceinline__ void sersic_vjp_c(const float* __restrict__ d, V x, V
 // once per workgroup when the partial row is written (cluster_sersic5_finish).  r2 is clamped at 1e-30 (a pixel exactly on a
 // source centre: the reference's own gradient is 0 * inf there) instead of selected on.
 enum { S5_SX = 0, S5_SY, S5_A, S5_D, S5_B, S5_N };
-template <class V>
-__device__ __forceinline__ void sersic_vjp5_c(const float* __restrict__ d, V x, V y, const SerStateC<V>& st, V gI, V (&va)[S5_N],
+template <class V, class P = const float*>
+__device__ __forceinline__ void sersic_vjp5_c(P d, V x, V y, const SerStateC<V>& st, V gI, V (&va)[S5_N],
                                               V& gpx, V& gpy) {
   V dx = x - d[SER_CX], dy = y - d[SER_CY];
   V r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, V(1e-30f)));  // the forward pass's floor
@@ -172,8 +172,8 @@ __device__ __forceinline__ void sersic_vjp5_c(const float* __restrict__ d, V x, 
   gpy -= qy * c;
 }
 // the same with log2(R / Rs) kept from the forward pass: 1 / r2 = (1 / Rs^2) 2^(-2 L2)   (SER_INVRS = 1 / R_sersic)
-template <class V>
-__device__ __forceinline__ void sersic_vjp5_keep_c(const float* __restrict__ d, V x, V y, const SerStateC<V>& st, V L2, V gI,
+template <class V, class P = const float*>
+__device__ __forceinline__ void sersic_vjp5_keep_c(P d, V x, V y, const SerStateC<V>& st, V L2, V gI,
                                                    V (&va)[S5_N], V& gpx, V& gpy) {
   V dx = x - d[SER_CX], dy = y - d[SER_CY];
   V ir2 = exp2_(L2 * -2.f) * d[SER_IRS2];  // finite: the forward pass of a kept source clamps r2 at 1e-30

@@ -55,4 +55,44 @@ template <class GW> inline void build_nfw_table(GW gw, std::vector<float>& tab) 
     }
 }
 
+// ---- the same function tabulated in s = X^2 (gl_clusterw_kernel, round 4) -----------------------------------------------
+// H(s) = h(sqrt s).  The deflection and its VJP need  h  and  h'(X) / X = 2 dH/ds  only (gl_clusterw.hip.h::nfw_fwd_s), so with
+// s = r^2 / Rs^2 as the table variable the pixel loop takes no square root and no reciprocal.  Intervals follow the float format
+// of s: octaves [2^kNfwSLog2Lo, 2^kNfwSLog2Hi), kNfwSPerOctave equal mantissa steps each (64 steps in s = the 128 steps in X of
+// the table above), interval index = (bits >> 17) - base, position tau = the low 17 mantissa bits as an integer.  Per interval
+// the four coefficients of the cubic Hermite interpolant in tau (SoA planes [4][kNfwSIntervals]: a lane's two pixels load into
+// adjacent registers, no shuffles):  H = c0 + tau (c1 + tau (c2 + tau c3)),  dH/dtau by the same Horner steps.
+constexpr int kNfwSLog2Lo = -12, kNfwSLog2Hi = 12, kNfwSPerOctave = 64, kNfwSTauBits = 17;
+constexpr int kNfwSIntervals = (kNfwSLog2Hi - kNfwSLog2Lo) * kNfwSPerOctave;
+
+template <class GW> inline void build_nfw_table_s(GW gw, std::vector<float>& tab) {
+  tab.assign((size_t)4 * kNfwSIntervals, 0.f);
+  auto HdH = [&](double s, double& H, double& dH) {  // H(s), dH/ds
+    const double X = std::sqrt(s);
+    double g, gp;
+    gw(X, g, gp);
+    if (X == 1.0) {  // analytic value at X = 1 (the reference's g(1) = 1 applies to the single float X == 1: kernel fallback)
+      g = 1.0 - 0.693147180559945309417232121458;
+      gp = 1.0 / 3.0;
+    }
+    const double iX = 1.0 / X, h = g * iX * iX, hp = gp * iX * iX - 2.0 * h * iX;
+    H = h;
+    dH = hp * 0.5 * iX;
+  };
+  const double tau1 = std::ldexp(1.0, kNfwSTauBits);  // tau runs over [0, 2^17)
+  for (int e = kNfwSLog2Lo; e < kNfwSLog2Hi; ++e)
+    for (int j = 0; j < kNfwSPerOctave; ++j) {
+      const double ds = std::ldexp(1.0 / kNfwSPerOctave, e), s0 = std::ldexp(1.0 + (double)j / kNfwSPerOctave, e);
+      double H0, D0, H1, D1;
+      HdH(s0, H0, D0);
+      HdH(s0 + ds, H1, D1);
+      const double c1 = ds * D0, dd = H1 - H0, c2 = 3.0 * dd - ds * (2.0 * D0 + D1), c3 = -2.0 * dd + ds * (D0 + D1);
+      const size_t i = (size_t)(e - kNfwSLog2Lo) * kNfwSPerOctave + j;
+      tab[i] = (float)H0;
+      tab[(size_t)kNfwSIntervals + i] = (float)(c1 / tau1);
+      tab[(size_t)2 * kNfwSIntervals + i] = (float)(c2 / (tau1 * tau1));
+      tab[(size_t)3 * kNfwSIntervals + i] = (float)(c3 / (tau1 * tau1 * tau1));
+    }
+}
+
 }  // namespace glh

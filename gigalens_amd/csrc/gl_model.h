@@ -88,6 +88,7 @@ struct gl_model {
   int static_variant = 0;
   int pair = 1;        // pixel-pair (packed fp32) form of the specialised kernels
   bool light_spherical = false;  // every light profile is the spherical Sersic: the pair kernels take their fast path
+  int cluster_w = 0;   // ... in its component-per-wave form (gl_clusterw_kernel)
   int cluster = 0;     // gl_cluster_kernel serves the gradient modes: 1 = halos + spherical Sersic sources, 2 = elliptical sources
   // image-position likelihood (gl_model_set_positions)
   int pos_J = 0, pos_F = 0, lens_params = 0;

@@ -44,7 +44,7 @@ def main():
 
     buf = ginf.svi_step_buffer(mu, lpk, None, n_local, None, value_and_grad_fn=vg, full_rank=True, eps=eps_of(rank))
     res["buffer_floats"] = int(buf.numel())
-    assert "gl_cluster_kernel" in sim._model.last_main_kernel(), sim._model.last_main_kernel()
+    assert "gl_clusterw_kernel" in sim._model.last_main_kernel(), sim._model.last_main_kernel()
     # (1) the all-reduced buffer == the mean of the two shards' buffers computed in ONE process without a collective
     shards = [ginf.svi_step_buffer(mu, lpk, None, n_local, None, value_and_grad_fn=vg, full_rank=True, eps=eps_of(r), reduce=False)
               for r in range(world)]

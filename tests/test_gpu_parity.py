@@ -509,7 +509,7 @@ def test_cluster_kernel_matches_interpreter(gl, n_halos, n_sources, ellipse, num
     wl = gl.workloads.Workload("CL", phys, prior, SimulatorConfig(delta_pix=0.065, num_pix=num_pix), batch)
     obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
     res = {}
-    for flag in ("1", "0"):
+    for flag in ("2", "1", "0"):
         monkeypatch.setenv("GIGALENS_HIP_CLUSTER", flag)
         sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
         packed = H.sample_packed(wl, sim, seed=3)
@@ -521,16 +521,20 @@ def test_cluster_kernel_matches_interpreter(gl, n_halos, n_sources, ellipse, num
         p2 = packed.clone().requires_grad_(True)
         (sim.simulate(p2) * obs).sum().backward()
         res[flag] = (ll.detach(), p.grad.clone(), p2.grad.clone(), kern)
-    assert "gl_cluster_kernel" in res["1"][3] and "gl_main_kernel" in res["0"][3]
-    assert torch.allclose(res["1"][0], res["0"][0], rtol=2e-6)
-    for k in (1, 2):
-        a, b = res["1"][k], res["0"][k]
-        scale = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-6 * float(b.abs().max()))
-        assert float(((a - b).abs() / scale).max()) < 2e-4
-        assert float((a - b).abs().max()) > 0.0 or n_sources == 0  # two different kernels ran
+    assert "gl_cluster_kernel" in res["1"][3] and "gl_clusterw_kernel" in res["2"][3] and "gl_main_kernel" in res["0"][3]
+    for flag in ("1", "2"):
+        # (the component-per-wave kernel adds the deflections and the source images in another order and reads the NFW function
+        # from its own table: a rounding-level change of beta moves the log-likelihood of these steep, badly fitting models by a
+        # few 1e-6 -- it is held to the oracle tolerance here and against the oracle itself in the tests below)
+        assert torch.allclose(res[flag][0], res["0"][0], rtol=2e-6 if flag == "1" else LL_RTOL)
+        for k in (1, 2):
+            a, b = res[flag][k], res["0"][k]
+            scale = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-6 * float(b.abs().max()))
+            assert float(((a - b).abs() / scale).max()) < 2e-4, (flag, k)
+            assert float((a - b).abs().max()) > 0.0 or n_sources == 0  # two different kernels ran
 
 
-@pytest.mark.parametrize("cluster", ["1", "0"])
+@pytest.mark.parametrize("cluster", ["2", "1", "0"])
 def test_nfw_table_ranges_vs_oracle(gl, cluster, monkeypatch):
     """The main kernels read h(X) = g(X)/X^2 of the NFW deflection (nfw.py:26-52) from an LDS table on [2^-6, 2^6) and take
     the closed form outside it and at X == 1 (gl_vec.hip.h::nfw_h_pair).  Halos whose scale radius puts the image's pixels
@@ -571,7 +575,7 @@ def test_nfw_table_ranges_vs_oracle(gl, cluster, monkeypatch):
     p = packed.clone().requires_grad_(True)
     ll, _ = pm._pixel_stats_packed(sim, p)
     ll.sum().backward()
-    assert ("gl_cluster_kernel" if cluster == "1" else "gl_main_kernel") in sim._model.last_main_kernel()
+    assert {"2": "gl_clusterw_kernel", "1": "gl_cluster_kernel", "0": "gl_main_kernel"}[cluster] in sim._model.last_main_kernel()
     assert np.allclose(ll.detach().cpu().numpy(), ll_o, rtol=LL_RTOL)
     g = p.grad.cpu().numpy()
     bad = ~(H.grad_col_err(g, g_o) <= GRAD_RTOL_COL)
