@@ -10,7 +10,10 @@
 // components, so the split is exact up to summation order):
 //   * a wave's <= 2 halos x 4 + <= 5 sources x 5 (8 elliptical) sums are plain per-lane accumulators: one packed add per sum and
 //     pixel pair, no transposes, no selects; one wave reduction per sum per CHUNK;
-//   * its constants (<= 48 dwords) stay in SGPRs for the whole chunk: no spills, nothing reloaded per tile;
+//   * its constants (<= 48 dwords) arrive through scalar loads, a component at a time, from neutral-padded slots: no count guards
+//     in the pixel loop, 26 SGPR spills where the pixel-split kernel has 160;
+//   * the NFW function comes from a table in s = X^2 (nfw_fwd_s below): no square root, no reciprocal, ~30 instead of ~85
+//     vector instructions per halo and pixel pair, and a slope 80 x more accurate than the node-pair table's;
 //   * the three quantities that couple the components -- the deflection sum, the model image, the cotangent of beta -- are
 //     exchanged through LDS: each wave writes its partial (16 / 8 / 16 bytes per lane), one barrier, every wave reads the four
 //     partials and adds them in wave order (so all four hold bitwise the same beta, image and cotangent; fixed order:
@@ -26,27 +29,20 @@ constexpr int CW_PX = 128;  // pixels per step of a workgroup: 64 lanes x one pi
 // LDS of the exchange: alpha partials [4][64] float4, g_beta partials [4][64] float4, image partials [4][64] float2
 constexpr size_t CW_XCHG_FLOATS = 4 * 64 * 4 + 4 * 64 * 4 + 4 * 64 * 2;
 
-// a component's constant block as a pointer into CONSTANT memory (address space 4: nothing writes the derived rows while a main
-// kernel runs, and only such loads stay scalar next to an opaque asm; a laundered pointer is also opaque to the
-// compiler's address-space inference, and a flat pointer is loaded through the vector path)
+// A component's constant block as a pointer into CONSTANT memory (address space 4: nothing writes the derived rows while a main
+// kernel runs, and only such loads stay scalar next to an opaque asm; a laundered pointer is also opaque to the compiler's
+// address-space inference, and a flat pointer is loaded through the vector path).
 typedef const float __attribute__((address_space(4)))* cw_gptr;
-#ifdef CW_GUARDS  // experiment: wave-uniform count guards around every component body, pointers left to the compiler
-#define CW_ON(i, n) (wave + 4 * (i) < (n))
-#define CW_LAUNDER(p) (p)
-#else
-#define CW_ON(i, n) true
-#define CW_LAUNDER(p) cw_launder(p)
-#endif
-#ifndef CW_NOFENCE
-#define CW_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define CW_FENCE() ((void)0)
-#endif
 __device__ __forceinline__ cw_gptr cw_launder(cw_gptr p) {
   unsigned long long u = (unsigned long long)p;
   asm volatile("" : "+s"(u));
   return (cw_gptr)u;
 }
+#ifndef CW_NOFENCE
+#define CW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CW_FENCE() ((void)0)
+#endif
 
 // ---- NFW forward on a pixel pair from the table in s = X^2 (gl_host_tables.h::build_nfw_table_s) ----------------------------
 // alpha = K0 h(X) d with X = R / Rs, and the VJP needs h'(X) only through  w = K0 h'(X) / (Rs R) = 2 K0 H'(s) / Rs^2  (H(s) = h(sqrt s),
@@ -141,15 +137,19 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
   }
   for (int i = tid; i < a.A; i += WG) s_row[i] = 0.f;
   __syncthreads();
-  // this sample's derived constants: wave-uniform addresses -> scalar loads, live in SGPRs for the whole chunk
+  // this sample's derived constants: wave-uniform addresses -> scalar loads
   const float* __restrict__ gder = a.derived + (size_t)b * a.D;
   const float* __restrict__ dH = gder;
   const float* __restrict__ dS = gder + NFWP * n_h;
-  // A slot beyond the model's counts points at a neutral block (zero amplitude; appended to the NFW table by gl_model_create): it
-  // adds exact zeros to the deflection, the image and the cotangent of beta, and its own sums are never written -- so the pixel
-  // loop carries no count guards, and the scalar loads of a phase's components are requested together (behind a guard each body
-  // waited for its own load).  The pointers are laundered per step: left alone the compiler hoists all 48 constants out of the
-  // loop and spills them (178 SGPRs, 111 VGPRs)
+  // A slot beyond the model's counts points at a neutral block (zero amplitude; behind the NFW table): it adds exact zeros to
+  // the deflection, the image and the cotangent of beta, and its own sums are never written -- the pixel loop carries no count
+  // guards.  The pointers are laundered per step: left alone the compiler hoists all 48 constants out of the loop and spills
+  // them (178 SGPRs, 111 VGPRs).  Also tried and dropped (round 4, each built and measured at C4: 0.946 ms as shipped): the constants
+  // held in scalar registers for the whole chunk by hand-written s_load (148-176 spilled SGPRs: the scalar file also holds the
+  // plane bases, the packed instructions' literals and the lane masks); the sources' loads software-pipelined by hand, two
+  // buffers in turn, the load of source j + 1 in flight under source j's arithmetic (0.959 ms: the scalar round trips were not
+  // what the waves wait for); the next step's grid / observation lines pulled into L1 a phase ahead (0.986 ms); wave-uniform
+  // count guards instead of neutral blocks (1.05 ms).
   const float* neutral = a.nfw_tab + CW_NEUTRAL_OFF;  // [NFW block (4) | Sersic block (16)]
   cw_gptr pH[HPW], pS[SPW];
 #pragma unroll
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
   float st0 = 0.f, st1 = 0.f;  // (one wave's sums, updated behind a branch: as pairs the compiler spilled them)
   const int p0 = chunk * a.chunk;
   const int p1 = min(p0 + a.chunk, a.N);
-  const int my = wave * 64 + lane;
+  const int my = tid;  // = wave * 64 + lane
 
   auto step = [&](int base, auto check_tag) {
     constexpr bool CHECK = decltype(check_tag)::value;
@@ -187,17 +187,21 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
     const V x = V{ldf(a.gx, jo0), ldf(a.gx, jo1)}, y = V{ldf(a.gy, jo0), ldf(a.gy, jo1)};
     V vmask = V(1.f);
     if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
-    // ---- ray-shoot: this wave's halos (tf/simulator.py:72-78) ----
+    using PH = cw_gptr;
+    using PS = cw_gptr;
     cw_gptr cH[HPW], cS[SPW];
 #pragma unroll
-    for (int i = 0; i < HPW; ++i) cH[i] = CW_LAUNDER(pH[i]);
+    for (int i = 0; i < HPW; ++i) cH[i] = cw_launder(pH[i]);
 #pragma unroll
-    for (int j = 0; j < SPW; ++j) cS[j] = CW_LAUNDER(pS[j]);
+    for (int j = 0; j < SPW; ++j) cS[j] = cw_launder(pS[j]);
+    // ---- ray-shoot: this wave's halos (tf/simulator.py:72-78) ----
     NfwStateC<V> hst[HPW];
     V pax = V(0.f), pay = V(0.f);  // -(sum of this wave's alpha)
 #pragma unroll
-    for (int i = 0; i < HPW; ++i)
-    if (CW_ON(i, n_h)) { nfw_fwd_s<cw_gptr>(cH[i], s_tab, x, y, pax, pay, hst[i]); CW_FENCE(); }
+    for (int i = 0; i < HPW; ++i) {
+      nfw_fwd_s<PH>(cH[i], s_tab, x, y, pax, pay, hst[i]);
+      CW_FENCE();
+    }
     s_xa[my] = float4{pax.x, pax.y, pay.x, pay.y};
     __syncthreads();
     V bx = x, by = y;
@@ -207,8 +211,19 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
       bx += V{t.x, t.y};
       by += V{t.z, t.w};
     }
-    // the planes the statistics need: requested here, a phase ahead of their use (any earlier they hold registers through the
-    // halo phase: 5 spilled VGPRs at three waves per SIMD)
+    // ---- render this wave's sources at beta (tf/simulator.py:128-138) ----
+    SerStateC<V> sst[SPW];
+    V sL2[ELL ? 1 : SPW];
+    V pm = V(0.f);
+#pragma unroll
+    for (int j = 0; j < SPW; ++j) {
+      const PS d = cS[j];
+      pm += sersic_fwd_c<V, ELL, PS>(d, bx, by, sst[j], ELL ? nullptr : &sL2[ELL ? 0 : j]);
+      CW_FENCE();
+    }
+    s_xm[my] = float2{pm.x, pm.y};
+    __syncthreads();
+    // the planes the statistics need (requested here: any earlier they hold registers through the source phase)
     V o = V(0.f), wgt = vmask, e = V(1.f), gin = V(0.f);
     if (MODE == IMG_BWD) {
       const float* row = a.gimg + (size_t)b * a.img_stride;
@@ -218,15 +233,6 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
       if (CHECK && has_mask) wgt = wgt * V{ldf(a.mask, po0), ldf(a.mask, po1)};
       if (has_err) e = V{ldf(a.err, po0), ldf(a.err, po1)};
     }
-    // ---- render this wave's sources at beta (tf/simulator.py:128-138) ----
-    SerStateC<V> sst[SPW];
-    V sL2[ELL ? 1 : SPW];
-    V pm = V(0.f);
-#pragma unroll
-    for (int j = 0; j < SPW; ++j)
-    if (CW_ON(j, n_s)) { pm += sersic_fwd_c<V, ELL, cw_gptr>(cS[j], bx, by, sst[j], ELL ? nullptr : &sL2[ELL ? 0 : j]); CW_FENCE(); }
-    s_xm[my] = float2{pm.x, pm.y};
-    __syncthreads();
     V m = V(0.f);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -262,21 +268,21 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
     // ---- source VJPs: parameter gradients and this wave's part of the cotangent of beta ----
     V gbx = V(0.f), gby = V(0.f);
 #pragma unroll
-    for (int j = 0; j < SPW; ++j) if (CW_ON(j, n_s)) {
-        cw_gptr d = cS[j];
-        if constexpr (ELL) {
-          V va[SER_NACC];
-          sersic_vjp_c<V, true, cw_gptr>(d, bx, by, sst[j], gm, va, gbx, gby);
+    for (int j = 0; j < SPW; ++j) {
+      const PS d = cS[j];
+      if constexpr (ELL) {
+        V va[SER_NACC];
+        sersic_vjp_c<V, true, PS>(d, bx, by, sst[j], gm, va, gbx, gby);
 #pragma unroll
-          for (int k = 0; k < SER_NACC; ++k) accS[j][k] += va[k];
-        } else {
-          V va[S5_N];
-          sersic_vjp5_keep_c<V, cw_gptr>(d, bx, by, sst[j], sL2[ELL ? 0 : j], gm, va, gbx, gby);
+        for (int k = 0; k < SER_NACC; ++k) accS[j][k] += va[k];
+      } else {
+        V va[S5_N];
+        sersic_vjp5_keep_c<V, PS>(d, bx, by, sst[j], sL2[ELL ? 0 : j], gm, va, gbx, gby);
 #pragma unroll
-          for (int k = 0; k < S5_N; ++k) accS[j][k] += va[k];
-        }
-        CW_FENCE();
+        for (int k = 0; k < S5_N; ++k) accS[j][k] += va[k];
       }
+      CW_FENCE();
+    }
     s_xg[my] = float4{gbx.x, gbx.y, gby.x, gby.y};
     __syncthreads();
     V tgx = V(0.f), tgy = V(0.f);
@@ -289,19 +295,16 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
     // ---- halo VJPs with the cotangent -g_beta (beta = x - sum alpha) ----
     tgx = -tgx;
     tgy = -tgy;
-#ifndef CW_KEEP_XY  // the grid coordinates are read again (L1 hits) instead of holding four registers through the source phases
+    // the grid coordinates are read again (L1 hits) instead of holding four registers through the source phases
     const V xh = V{ldf(a.gx, jo0), ldf(a.gx, jo1)}, yh = V{ldf(a.gy, jo0), ldf(a.gy, jo1)};
-#else
-    const V xh = x, yh = y;
-#endif
 #pragma unroll
-    for (int i = 0; i < HPW; ++i) if (CW_ON(i, n_h)) {
-        V va[NFW_NACC];
-        nfw_vjp_c<V, cw_gptr>(cH[i], xh, yh, tgx, tgy, hst[i], va);
+    for (int i = 0; i < HPW; ++i) {
+      V va[NFW_NACC];
+      nfw_vjp_c<V, PH>(cH[i], xh, yh, tgx, tgy, hst[i], va);
 #pragma unroll
-        for (int k = 0; k < NFW_NACC; ++k) accH[i][k] += va[k];
-        CW_FENCE();
-      }
+      for (int k = 0; k < NFW_NACC; ++k) accH[i][k] += va[k];
+      CW_FENCE();
+    }
   };
   {
     const bool plain = !has_mask && !has_pix;

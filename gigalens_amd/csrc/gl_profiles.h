@@ -59,8 +59,10 @@ enum { SHR_NACC = 2 };
 enum { SIS_CX = 0, SIS_CY, SIS_TE, SIS_ND };
 enum { SIS_NACC = 3 };
 // SERSIC / SERSIC_ELLIPSE (one code path; the spherical profile is the e=0 member, sersic.py:52-55)
-enum { SER_CX = 0, SER_CY, SER_C, SER_S, SER_SQ, SER_ISQ, SER_INVRS, SER_INVN, SER_BN, SER_IE, SER_ND, SER_L2IRS = SER_ND /* log2(1/R_sersic) */,
-       SER_CG /* Ie bn / n */, SER_IRS2 /* 1 / R_sersic^2 */, SER_PAD, SER_NDX /* floats of the block */ };
+// (order: the eight constants of a spherical source first, then the four of the ellipse -- gl_clusterw_kernel fetches a source's
+// block with one 8-dword scalar load, plus a 4-dword one for elliptical sources)
+enum { SER_CX = 0, SER_CY, SER_INVN, SER_BN, SER_IE, SER_L2IRS /* log2(1/R_sersic) */, SER_CG /* Ie bn / n */, SER_IRS2 /* 1 / R_sersic^2 */,
+       SER_C, SER_S, SER_SQ, SER_ISQ, SER_INVRS, SER_PAD, SER_NDX /* floats of the block */, SER_ND = SER_NDX };
 enum { SERA_CX = 0, SERA_CY, SERA_PHI, SERA_SQ, SERA_L, SERA_INVN, SERA_BN, SERA_IE, SER_NACC };
 // SHAPELETS
 enum { SHP_CX = 0, SHP_CY, SHP_IB, SHP_NMAX, SHP_AMP = 4 };

@@ -202,6 +202,37 @@ void hm_chi2_f64(int n, const double* m, const double* o, const double* w, int h
 }
 int hm_num_params(int kind, int iparam) { return kind_num_params(kind, iparam); }
 
+// The NFW table in s = X^2 (gl_host_tables.h::build_nfw_table_s) read the way gl_clusterw.hip.h::nfw_fwd_s reads it, in float32
+// with fused multiply-adds: out_h = H(s), out_dhds = dH/ds for every s inside the table (NaN outside).
+void hm_nfw_table_s_f32(int n, const float* s, float* out_h, float* out_dhds) {
+  static std::vector<float> tab;
+  if (tab.empty()) glh::build_nfw_table_s([](double X, double& g, double& gp) { nfw_gw<double>(X, g, gp); }, tab);
+  const int N = glh::kNfwSIntervals;
+  for (int k = 0; k < n; ++k) {
+    uint32_t b;
+    std::memcpy(&b, &s[k], 4);
+    const uint32_t i = (b >> 17) - ((uint32_t)(127 + glh::kNfwSLog2Lo) << 6);
+    if (!(i < (uint32_t)N)) { out_h[k] = out_dhds[k] = NAN; continue; }
+    const float c0 = tab[i], c1 = tab[N + i], c2 = tab[2 * N + i], c3 = tab[3 * N + i], tau = (float)(b & 0x1FFFFu);
+    const float p1 = std::fmaf(c3, tau, c2), p2 = std::fmaf(p1, tau, c1), q2 = std::fmaf(c3, tau, p1);
+    out_h[k] = std::fmaf(p2, tau, c0);
+    const uint32_t sb = 0x8A800000u - (b & 0x7F800000u);
+    float dtds;
+    std::memcpy(&dtds, &sb, 4);
+    out_dhds[k] = std::fmaf(q2, tau, p2) * dtds;
+  }
+}
+// h(X) = g(X) / X^2 and h'(X) of the closed form in float64 (nfw_gw: the function both tables are built from)
+void hm_nfw_h_f64(int n, const double* X, double* h, double* hp) {
+  for (int k = 0; k < n; ++k) {
+    double g, gp;
+    nfw_gw<double>(X[k], g, gp);
+    const double iX = 1.0 / X[k];
+    h[k] = g * iX * iX;
+    hp[k] = gp * iX * iX - 2.0 * h[k] * iX;
+  }
+}
+
 void hm_lens_jet_f64(int kind, int iparam, const double* p, double x, double y, double* out) {
   switch (kind) {
     case K_EPL: lens_jet<6>(kind, iparam, p, x, y, out); break;

@@ -102,3 +102,31 @@ def test_get_coords_centres_the_grid():
     _, _, X2, Y2 = LensSimulatorInterface.get_coords(1, 9, T2)
     assert abs(X2.mean()) < 1e-6 and abs(Y2.mean()) < 1e-6
     assert np.isclose(X2[0, 1] - X2[0, 0], 0.03) and np.isclose(Y2[1, 0] - Y2[0, 0], 0.031)
+
+
+def test_nfw_table_in_s_reproduces_the_closed_form(hostmath):
+    """The NFW table of gl_clusterw_kernel (H(s) = h(sqrt s), s = X^2, intervals on the float format of s, cubic Hermite
+    coefficients per interval; csrc/gl_host_tables.h::build_nfw_table_s) read in float32 exactly as the kernel reads it
+    (csrc/gl_clusterw.hip.h::nfw_fwd_s: interval and position from the bits of s, Horner steps as fused multiply-adds, the
+    slope scaled by a power of two from the exponent) against the float64 closed form over the whole table: the value to
+    4e-7, the slope dH/ds = h'(X) / (2X) -- what the gradients w.r.t. centre and scale radius are made of -- to 2e-6 (the
+    node-pair table in X of the other kernels: 7e-5 in the slope).  Ref: tf/profiles/mass/nfw.py:26-52."""
+    import ctypes
+    from ctypes import POINTER, c_double, c_float, c_int
+    rng = np.random.default_rng(3)
+    X = np.exp2(rng.uniform(-6.0, 6.0, 400_000))
+    X = X[np.abs(X - 1.0) > 1e-6]
+    s = (X.astype(np.float32) ** 2).astype(np.float32)
+    Xs = np.sqrt(s.astype(np.float64))  # the X the float32 s stands for
+    ok = (Xs >= 2.0 ** -6) & (Xs < 2.0 ** 6)
+    s, Xs = np.ascontiguousarray(s[ok]), np.ascontiguousarray(Xs[ok])
+    H, dH = np.zeros_like(s), np.zeros_like(s)
+    hostmath.hm_nfw_table_s_f32(c_int(len(s)), s.ctypes.data_as(POINTER(c_float)), H.ctypes.data_as(POINTER(c_float)),
+                                dH.ctypes.data_as(POINTER(c_float)))
+    h, hp = np.zeros_like(Xs), np.zeros_like(Xs)
+    hostmath.hm_nfw_h_f64(c_int(len(Xs)), Xs.ctypes.data_as(POINTER(c_double)), h.ctypes.data_as(POINTER(c_double)),
+                          hp.ctypes.data_as(POINTER(c_double)))
+    assert np.isfinite(H).all() and np.isfinite(dH).all()
+    assert np.max(np.abs(H - h) / np.abs(h)) < 4e-7
+    dHds = hp / (2.0 * Xs)
+    assert np.max(np.abs(dH - dHds) / np.abs(dHds)) < 2e-6

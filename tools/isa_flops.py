@@ -346,14 +346,14 @@ def shp_model(cfg, mean_series_pairs, p_live, W=2):
     return per_pixel, detail
 
 
-def cluster_model(cfg, W=2):
+def cluster_model(cfg, W=2, min_valu=1000):
     """gl_cluster_kernel (csrc/gl_cluster.hip.h) at full capacity (every compile-time component slot in use: BASELINE configs 4
     and 5).  The steady-state tile loop is the first hot top-level loop; its component bodies sit behind wave-uniform count
     guards (always taken at capacity).  The only blocks that do not run every trip are the lane-by-lane closed-form NFW
     fallback (X outside the h(X) table or exactly 1: a handful of lanes per launch): the blocks entered as the fall-through of
     an `s_cbranch_execz` (lane-masked code; the count guards are scalar-condition branches), weighted 0.  Checked against
     SQ_INSTS_VALU in profiles/ (C4: 1248 modelled vs 1242-1253 counted per pixel)."""
-    tile = _hot_loops(cfg, 1000)[0]
+    tile = _hot_loops(cfg, min_valu)[0]
     latches = [b for b in tile.blocks if tile.header in cfg.succ[b]]
     mandatory = set(tile.blocks)
     for lt in latches:
@@ -394,13 +394,22 @@ def execution_model(co, name, md, series, p_live=None):
     weights = "v_pk_fma 4, v_pk_mul/add 2, v_fma 2, v_mul/add/sub 1, transcendental 1, other 0 (per lane)"
     ms = re.search(r"gl_shp_kernel<(\d+),", name)
     mc = re.search(r"gl_cluster_kernel<(\d+),", name)
-    if ms or mc:
-        if int((ms or mc).group(1)) in (0,):
+    mw = re.search(r"gl_clusterw_kernel<(\d+),", name)
+    if ms or mc or mw:
+        if int((ms or mc or mw).group(1)) in (0,):
             return None
         cfg = CFG(disassemble(md["co"], md["symbol"]))
         s_ = series or {}
         if ms:
             per_pixel, detail = shp_model(cfg, float(s_.get("mean_pair_trips", 0.0)), 1.0 if p_live is None else float(p_live))
+        elif mw:
+            # gl_clusterw_kernel (csrc/gl_clusterw.hip.h): the four waves of a workgroup walk the SAME 128 pixels of a step (64
+            # lanes x one pixel pair each), every wave with a quarter of the components -- a pixel is served by one lane of each
+            # of the four waves, so the per-pixel counts are 4 x (one wave's loop body / 2 pixels per lane).  Same block rules as
+            # the pixel-split kernel: everything except the lane-masked closed-form NFW fallback runs every step.
+            per_lane, detail = cluster_model(cfg, W=2, min_valu=200)
+            per_pixel = {k: 4.0 * v for k, v in per_lane.items()}
+            detail = dict(detail, waves_per_pixel=4, per_pixel=per_pixel)
         else:
             per_pixel, detail = cluster_model(cfg)
         out = dict(flops_per_pixel=round(per_pixel["flops"], 2), valu_insts_per_pixel=round(per_pixel["valu"], 2),

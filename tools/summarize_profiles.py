@@ -32,7 +32,7 @@ def stats_table(d, out, top=12):
     return rows
 
 
-def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_kernel<3", "gl_cluster_kernel<3", "gl_shp_kernel<3")):
+def pmc(d, kernel_filter=("gl_pair_kernel<3", "gl_static_kernel<3", "gl_main_kernel<3", "gl_cluster_kernel<3", "gl_clusterw_kernel<3", "gl_shp_kernel<3")):
     f = sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     if not f:
         return {}
@@ -54,7 +54,7 @@ for w in ("C2", "C3", "C3direct", "C3D", "C4", "C5", "C6", "C3L", "simpair", "de
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mix", "pmc_clk"):
     summary[d] = pmc(d)
 summary["pmc_C6"] = pmc("pmc_C6", kernel_filter=("gl_main_kernel<3",))
-summary["pmc_C4"] = pmc("pmc_C4", kernel_filter=("gl_cluster_kernel<3", "gl_main_kernel<3"))
+summary["pmc_C4"] = pmc("pmc_C4", kernel_filter=("gl_clusterw_kernel<3", "gl_cluster_kernel<3", "gl_main_kernel<3"))
 c4 = summary["pmc_C4"]
 if c4.get("SQ_ACTIVE_INST_VALU") and c4.get("GRBM_GUI_ACTIVE"):
     c4["valu_busy_frac"] = c4["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * c4["GRBM_GUI_ACTIVE"] / 8.0)
