@@ -22,17 +22,22 @@ One "step" = one pass of the hot path over one batch.
 Defaults: 1000 timed steps after 100 warm-up steps.  The chip needs a few tens of milliseconds of sustained load to settle
 at its working clock, so an untimed pre-roll of 0.15 s of steps precedes the W warm-up steps whatever W and K are.
 
-Refuses to run (exit 3) with any GIGALENS_HIP_* kernel override in the environment, checks four samples of the batch it is
-about to time against the float64 oracle (exit 4 on a mismatch or a non-finite result), and at N = 1 adds a `configs` array:
-the other BASELINE.json configs (C1 at batch 1 and 1024, C3 table and direct, C4, C5's per-rank shard), each timed for a
-fraction of a second with the same event ring and priced with the same two fractions (B1 bytes against HBM peak, ISA-counted
-flops of the dispatched kernel against the fp32 vector peak).
+Refuses to run (exit 3) with any GIGALENS_HIP_* kernel override in the environment.  EVERY rank checks four samples of the shard
+it is about to time against the float64 oracle and its last timed step for finite outputs; the flags are MIN-all-reduced and
+all ranks exit 4 together on a failure anywhere.  At N = 1 the line carries a `configs` array: the other BASELINE.json configs
+(C1 at batch 1 and 1024, C3 table and direct, C4, C5's per-rank shard) and the SURVEY 8f workloads C6 (catalogue members) and
+C3L (linear solve), each timed for a fraction of a second with the same event ring and priced with the same two fractions (B1
+bytes against HBM peak, ISA-counted flops of the dispatched kernel against the fp32 vector peak).  At N > 1 `configs` holds
+BASELINE.json configs[4] itself: the 2048-particle cluster-model SVI with 2048 / N particles per rank -- forward+gradient on
+the shard and the real SVI step with its 8 911-float all-reduce, timed with the same barrier / max-over-ranks protocol.
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) with two extra objects:
-  roofline     -- the dominant kernel, timed INSIDE the timed loop by a ring of HIP-event pairs the library records on the
-                  launch stream around every main-kernel launch (no host sync; read back after the loop), plus the
-                  ISA-counted fp32 flop rate of the dispatched instantiation against the 157.3 TFLOP/s vector peak
-                  (tools/isa_flops.py disassembles the shipped code object; the binding bound of this path)
+  roofline     -- the dominant kernel, timed by HIP-event pairs that ride on its own dispatch packets (hipExtLaunchKernel, on
+                  the launch stream, no host sync) in a pass of >= 20 further steps of the same loop right after the timed
+                  region -- not inside it: a timed launch costs ~5 us of its step (12.5 -> 11.8 M sims/s with every launch
+                  timed), and the line's `value` must not pay for its own instrumentation --, plus the ISA-counted fp32 flop
+                  rate of the dispatched instantiation against the 157.3 TFLOP/s vector peak (tools/isa_flops.py
+                  disassembles the shipped code object; the binding bound of this path)
   cpu_baseline -- the oracle (reference algorithm restated op-for-op on torch-CPU, float32 + autograd) timed on 256 of
                   the workload's samples on this box's host cores: median and p10 / p90 over the timed passes
 """
@@ -244,6 +249,7 @@ def oracle_spot_check(wl, pm, sim, z, obs, err, n=4):
     from oracle import ref_torch as ref
     from tests.helpers import struct_from_packed
     import numpy as np
+    n = max(1, min(n, z.shape[0]))
     ll = pm.log_like(sim, z).detach().double().cpu().numpy()[:n]
     lp, _, g = pm.log_prob_and_grad(sim, z)
     finite = bool(torch.isfinite(lp).all() and torch.isfinite(g).all())
@@ -278,16 +284,21 @@ def roofline_of(model, wl, sim, x, kernel_ms, ms_per_step, err, stride):
     k_mean = sum(kernel_ms) / len(kernel_ms)
     achieved = bytes_b1 * B / (k_mean * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "traffic_source": None,
             "kernel_ms": round(k_mean, 5), "kernel_ms_p10": round(_pct(kernel_ms, 0.1), 5),
             "kernel_ms_p50": round(_pct(kernel_ms, 0.5), 5), "kernel_ms_p90": round(_pct(kernel_ms, 0.9), 5),
             "kernel_launches_timed": len(kernel_ms), "kernel_event_stride": stride,
+            "kernel_timing": ("HIP-event pairs on the main kernel's own dispatch packets (hipExtLaunchKernel) in a pass of further steps of "
+                              "the same loop right after the timed region; not inside it: an event pair costs ~5 us of a step"),
             "kernel_share_of_step": round(k_mean / ms_per_step, 4),
             "algorithmic_bytes_per_sim_B1": bytes_b1, "algorithmic_bytes_per_sim_B2": round(bytes_b2, 1),
             "kernel_sims_per_s": round(B / (k_mean * 1e-3), 1)}
     series = epl_series_stats(wl, x)
     p_live = None
-    symbol = model.last_main_kernel()
+    try:
+        symbol = model.last_main_kernel()
+    except Exception:  # evidence only: a model whose kernel has no name to report still gets its line
+        symbol = ""
     if "gl_shp_kernel" in symbol:  # the share of wave-tiles that ran the shapelet chains, counted by the kernel itself
         rows = model.partial_rows(B)
         seen = float(rows[:, :, 3].sum())
@@ -313,7 +324,7 @@ def roofline_of(model, wl, sim, x, kernel_ms, ms_per_step, err, stride):
 
 
 def timed_steps(step, model, steps, warmup, preroll_s, stride, sync_barrier=None):
-    """W warm-up steps, then K timed steps with the library's event ring around every stride-th main launch."""
+    """Pre-roll, W warm-up steps, K timed steps (no events inside), then the kernel pass (see kernel_pass)."""
     t_pre, n_pre = time.perf_counter(), 0
     while time.perf_counter() - t_pre < preroll_s:
         for _ in range(20):
@@ -322,17 +333,149 @@ def timed_steps(step, model, steps, warmup, preroll_s, stride, sync_barrier=None
         n_pre += 20
     for _ in range(warmup):
         step()
-    n_ev = (steps + stride - 1) // stride
-    model.set_timing(n_ev, stride)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sorted(model.timing_drain())
-    model.set_timing(0)
+    kernel_ms = kernel_pass(step, model, max(20, min(steps, 100)), stride)
     return elapsed, kernel_ms, n_pre
+
+
+def all_ranks_ok(ok, dev):
+    """MIN over ranks of a validity flag: every rank learns whether ANY rank failed, so that all exit together (a rank leaving
+    on its own would strand the others in the next collective until the launcher kills them)."""
+    from gigalens_amd import dist as gdist
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    gdist.allreduce_min_(flag)
+    return bool(flag.item() > 0.5)
+
+
+def make_svi_step(wl, pm, sim, B, dev, rank):
+    """The real SVI iteration on this rank's particle shard (inference.svi_step_buffer + the fused Adam launch with learning
+    rate 0, so that every step of the measurement sees the same state).  Surrogate state: the reference's SVI start
+    (tf/inference.py:47-72: mean = a MAP-like point, scale 1e-3 I); the mean is the prior draw whose EPL series length is closest
+    to the batch mean, so that a particle costs what an average sample costs (identical on every rank: rank 0's stream).
+    Returns (step, series of the surrogate's mean or None)."""
+    import math
+    from gigalens_amd import dist as gdist
+    from gigalens_amd import inference as ginf
+    x0 = wl.prior.sample(B, generator=gdist.rank_generator(0, 0))
+    z0 = pm.bij.inverse(x0)
+    d = z0.shape[1]
+    pick, series = 0, None
+    s0 = epl_series_stats(wl, x0)
+    if s0 is not None:
+        e = None
+        for prof, p in zip(wl.phys_model.lenses, x0["lens_mass"]):
+            if getattr(prof, "_kind", 0) == 1:
+                e = torch.sqrt(torch.as_tensor(p["e1"], dtype=torch.float64) ** 2 + torch.as_tensor(p["e2"], dtype=torch.float64) ** 2)
+                break
+        K = torch.ceil(math.log(EPL_SERIES_TOL) / torch.log(e.clamp(1e-30, 1 - 1e-12)) + 2.0) - 1
+        pick = int(torch.argmin((K - round(s0["mean_terms"])).abs()))
+        g = float(torch.ceil((K[pick] + 1) / 4))
+        series = {"mean_terms": float(K[pick]), "mean_four_term_groups": g, "mean_pair_trips": 0.5 * (g - 1.0), "frac_odd": 0.0}
+    mu = z0[pick].to(dev).contiguous().clone()
+    lpk = ginf.tril_pack(torch.eye(d, device=dev) * 1e-3)
+    sv_params = torch.cat([mu, lpk]).contiguous()
+    opt = ginf.Adam(lr=0.0)
+    gen = gdist.rank_generator(2, rank, device=dev)
+
+    def vg(zz):
+        lp_, _, g_ = pm.log_prob_and_grad(sim, zz)
+        return lp_, g_
+
+    pool = ginf.NormalPool(gen, B, d, device=dev)  # the driver's own draw schedule (ModellingSequence.SVI)
+
+    def step():
+        buf = ginf.svi_step_buffer(sv_params[:d], sv_params[d:], None, B, gen, value_and_grad_fn=vg, full_rank=True, eps=pool.next())
+        opt.step(sv_params, buf[1:])
+        return buf
+
+    return step, series
+
+
+def kernel_pass(step, model, n, stride=1):
+    """The main kernel's launch durations from HIP events: `n` further steps of the very loop that was just timed, same stream,
+    same clock state, every stride-th launch carrying an event pair (sorted ms).  A pass of its own because an event pair is not
+    free: on the dispatch packet (hipExtLaunchKernel) it costs ~5 us per step, as two event records ~2.5 us each -- inside the
+    timed region it would lower the very `value` the line is about (12.5 -> 11.8 M sims/s at C2 with every launch timed)."""
+    n_ev = (n + stride - 1) // stride
+    model.set_timing(n_ev, stride)
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = sorted(model.timing_drain())
+    model.set_timing(0)
+    return ms
+
+
+def timed_region(step, model, steps, warmup, events, stride, dev):
+    """W warm-up steps, then K steps between barrier + synchronize pairs and the MAX over ranks of the elapsed time (no events
+    inside: see kernel_pass); then the kernel pass -- max(20, min(K, 200)) more steps with their main launches timed.  Returns
+    (elapsed, sorted kernel ms, last timed step's outputs)."""
+    from gigalens_amd import dist as gdist
+    for _ in range(warmup):
+        step()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    gdist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    gdist.allreduce_max_(tmax)
+    kernel_ms = kernel_pass(step, model, max(20, min(steps, 200)), stride) if events else []
+    return float(tmax.item()), kernel_ms, last
+
+
+def outputs_finite(last):
+    outs = last if isinstance(last, (tuple, list)) else (last,)
+    return all(bool(torch.isfinite(t).all()) for t in outs if torch.is_tensor(t))
+
+
+def measure_c5_sharded(dev, rank, world, steps, warmup, events, stride):
+    """BASELINE.json configs[4] on the line of an N > 1 run: the 2048-particle cluster-model SVI, 2048 / N particles per rank --
+    forward+gradient on the shard (no collective) and the real SVI iteration with its 8 911-float all-reduce, each for `steps`
+    steps with the same barrier / max-over-ranks timing as the headline.  Every rank checks its own shard; the flags are
+    reduced by the caller."""
+    from gigalens_amd import workloads
+    from gigalens_amd.model import ForwardProbModel
+    from gigalens_amd.simulator import LensSimulator
+    total = 2048
+    B = max(1, total // world)
+    wl, obs, err, pm, sim, x, z = build_case("C5", dict(batch=B), workloads, ForwardProbModel, LensSimulator, dev, rank)
+    model = sim._model
+    d = z.shape[1]
+    check = oracle_spot_check(wl, pm, sim, z, obs, err, n=2)
+    ok = check["ok"]
+    e_fg, k_fg, last = timed_region(lambda: pm.log_prob_and_grad(sim, z), model, steps, warmup, events, stride, dev)
+    ok = ok and outputs_finite(last)
+    svi, _ = make_svi_step(wl, pm, sim, B, dev, rank)
+    e_svi, k_svi, last = timed_region(svi, model, steps, warmup, events, stride, dev)
+    ok = ok and outputs_finite(last)
+    ms_fg = 1e3 * e_fg / steps
+    out = {"config": "BASELINE.json configs[4]: full SVI, 2048 particles, cluster model (8 NFW + 20 Sersic) 256x256 px, particles sharded "
+                     f"over {world} ranks",
+           "workload": f"{wl.name}: {wl.description}", "particles_total": B * world, "particles_per_rank": B, "pixels": model.N,
+           "z_dim": d, "steps": steps, "warmup": warmup,
+           "fwdgrad": {"ms_per_step": round(ms_fg, 4), "sims_per_s": round(B * world * steps / e_fg, 1),
+                       "what": "ForwardProbModel.log_prob_and_grad on every rank's shard, no collective"},
+           "svi_step": {"ms_per_step": round(1e3 * e_svi / steps, 4), "particles_per_s": round(B * world * steps / e_svi, 1),
+                        "allreduce_floats": 1 + d + d * (d + 1) // 2, "backend": torch.distributed.get_backend() if world > 1 else None,
+                        "what": ("inference.svi_step_buffer (eps draw, gl_svi_sample, log_prob forward+gradient, gl_svi_grad, all-reduce of "
+                                 "the fused [ELBO, grad] buffer) + fused Adam launch (lr 0)")},
+           "oracle_spot_check_rank0": check if rank == 0 else None}
+    if k_fg:
+        roof, _ = roofline_of(model, wl, sim, x, k_fg, ms_fg, err, stride)
+        out.update({"kernel": roof.get("isa", {}).get("kernel"), "kernel_ms": roof["kernel_ms"], "hbm_frac_B1": roof["frac"],
+                    "valu_flop_frac": roof.get("valu_flop_frac"), "valu_insts_per_pixel": roof.get("isa", {}).get("valu_insts_per_pixel")})
+    del pm, sim, z
+    torch.cuda.empty_cache()
+    return out, ok
 
 
 EXTRA_CONFIGS = [  # the other BASELINE.json configs, measured after the headline line's loop (N = 1 only), a fraction of a second each
@@ -342,7 +485,47 @@ EXTRA_CONFIGS = [  # the other BASELINE.json configs, measured after the headlin
     ("C3", dict(interpolate=False), "configs[2], direct (Hermite recurrence) mode"),
     ("C4", dict(), "BASELINE.json configs[3]: 8 NFW halos + 20 Sersic sources, 256x256 px, batch 512"),
     ("C5", dict(), "BASELINE.json configs[4]: per-rank shard (256 particles) of the 2048-particle cluster-model SVI, forward+gradient"),
+    ("C6", dict(), "SURVEY 8f-3 (the cluster-lens workload): dPIE halo + 200 catalogue member galaxies (DPIESubhalo) + 20 Sersic sources, "
+                   "256x256 px, batch 128"),
 ]
+
+
+def measure_c3l(dev, seconds=0.25):
+    """the linear amplitude solve (lstsq_simulate) at C3L -- 1024 samples, 128 x 128 px, one shapelet source
+    n_max = 10 solved linearly (66 + 1 channels): ms per gl_lstsq_fwd (normal matrix straight from the bases + Cholesky
+    attempt), HIP-event timed."""
+    from gigalens_amd import workloads
+    from gigalens_amd.simulator import LensSimulator
+    try:
+        wl = workloads.make("C3L")
+        c2 = workloads.make("C2", num_pix=wl.sim_config.num_pix, batch=1)
+        obs, _, _ = workloads.synthetic_observation(c2, LensSimulator)
+        errm = torch.sqrt(wl.background_rms ** 2 + obs.clamp_min(0) / wl.exp_time).contiguous()
+        sim = LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+        packed = sim.pack(wl.prior.sample(wl.batch, seed=0)).contiguous()
+        m = sim._model
+        for _ in range(3):
+            (coeffs,) = m.lstsq(packed, obs, errm, 7, want="coeffs")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.lstsq(packed, obs, errm, 7, want="coeffs")
+        torch.cuda.synchronize()
+        iters = int(min(400, max(20, seconds / max(time.perf_counter() - t0, 1e-5))))
+        e0.record()
+        for _ in range(iters):
+            (coeffs,) = m.lstsq(packed, obs, errm, 7, want="coeffs")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        return {"config": "SURVEY 8f-4: lstsq_simulate at C3L (1024 samples, 128x128 px, shapelets n_max = 10 solved linearly, 66 + 1 channels)",
+                "workload": f"{wl.name}: {wl.description}", "batch": wl.batch, "pixels": m.N, "linear_channels": m.num_linear(),
+                "steps": iters, "ms_per_step": round(ms, 4), "solves_per_s": round(wl.batch / (ms * 1e-3), 1),
+                "coefficients_finite": bool(torch.isfinite(coeffs).all()),
+                "what": "gl_lstsq_fwd (coefficients): front end, gl_shp_normal_kernel (exact-fp32 MFMA normal matrix from the bases), "
+                        "gl_chol_solve_kernel; timed end to end with HIP events"}
+    except Exception as exc:
+        return {"config": "SURVEY 8f-4: lstsq_simulate at C3L", "error": repr(exc)}
 
 
 def measure_extra_configs(dev, steps_cap=200):
@@ -360,9 +543,9 @@ def measure_extra_configs(dev, steps_cap=200):
             torch.cuda.synchronize()
             per = max((time.perf_counter() - probe_t) / 3, 1e-5)
             steps = int(min(steps_cap, max(20, 0.25 / per)))
-            elapsed, kernel_ms, _ = timed_steps(lambda: pm.log_prob_and_grad(sim, z), sim._model, steps, max(5, steps // 10), 0.05, 4)
+            elapsed, kernel_ms, _ = timed_steps(lambda: pm.log_prob_and_grad(sim, z), sim._model, steps, max(5, steps // 10), 0.05, 1)
             ms = 1e3 * elapsed / steps
-            roof, series = roofline_of(sim._model, wl, sim, x, kernel_ms, ms, err, 4)
+            roof, series = roofline_of(sim._model, wl, sim, x, kernel_ms, ms, err, 1)
             out.append({"config": what, "workload": f"{wl.name}: {wl.description}", "batch": wl.batch, "pixels": sim._model.N,
                         "params_per_sample": sim._model.P, "steps": steps, "ms_per_step": round(ms, 4),
                         "sims_per_s": round(wl.batch * steps / elapsed, 1), "kernel": roof.get("isa", {}).get("kernel"),
@@ -391,10 +574,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (the `configs` array of the line)")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not record the per-launch event pairs inside the timed loop (roofline is then null)")
-    ap.add_argument("--kernel-event-stride", type=int, default=8,
-                    help="bracket every k-th main-kernel launch of the timed loop with a HIP-event pair (an event record "
-                         "costs ~2.5 us of stream time: k = 1 slows a 0.12 ms step by 4.6 %%, k = 8 by 0.6 %%)")
+                    help="skip the kernel pass after the timed region (roofline is then null)")
+    ap.add_argument("--kernel-event-stride", type=int, default=1,
+                    help="time every k-th main-kernel launch of the kernel pass that follows the timed region (event pairs on the "
+                         "kernels' own dispatch packets)")
     ap.add_argument("--preroll-seconds", type=float, default=0.15,
                     help="untimed sustained load before the warm-up steps (clock settling); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -427,6 +610,10 @@ def main():
     if not os.path.exists(_native.lib_path()):
         ge.build()
 
+    if world > 1 and torch.distributed.get_backend() == "nccl" and torch.cuda.device_count() < world:
+        # (the parent's sysfs count can exceed what a device cgroup lets the ranks open: then every rank says so and leaves)
+        sys.stderr.write(f"bench.py: rank {rank}: {world} ranks but only {torch.cuda.device_count()} GPU(s) can be opened\n")
+        sys.exit(2)
     if world > 1:  # bring the communicator up (RCCL builds its rings / trees on the first collective: seconds) before anything is timed
         warm = torch.ones(8, device=dev)
         gdist.allreduce_mean_(warm)
@@ -440,49 +627,18 @@ def main():
     series = epl_series_stats(wl, x)
     d = z.shape[1]
     n_coll = 1 + d + d * (d + 1) // 2
-    # the batch the loop will run, checked against the float64 oracle BEFORE anything is timed (4 samples; a wrong or
-    # non-finite result ends the run: a line is never printed for numbers nobody looked at)
-    check = oracle_spot_check(wl, pm, sim, z, obs, err, n=2 if N > 16384 else 4) if rank == 0 else None
-    if check is not None and not check["ok"]:
-        sys.stderr.write(f"bench.py: the timed batch does not match the oracle: {check}\n")
+    # the batch the loop will run, checked against the float64 oracle BEFORE anything is timed -- on EVERY rank, each on its own
+    # shard (4 samples; 2 at the 256 x 256 configs); the flags are reduced with a MIN all-reduce and a wrong or non-finite
+    # result on any rank ends the run on all of them: a line is never printed for numbers nobody looked at
+    check = oracle_spot_check(wl, pm, sim, z, obs, err, n=2 if N > 16384 else 4)
+    if not all_ranks_ok(check["ok"], dev):
+        sys.stderr.write(f"bench.py: rank {rank}: the timed batch does not match the oracle on some rank (this rank: {check})\n")
         sys.exit(4)
 
     if mode == "svi":
-        # surrogate state: the reference's SVI start (tf/inference.py:47-72: mean = a MAP-like point, scale 1e-3 I).  The mean
-        # is the prior draw whose EPL series length is closest to the batch mean, so a particle costs what an average
-        # sample of the fwdgrad batch costs (identical on every rank: drawn with rank 0's stream).
-        x0 = wl.prior.sample(B, generator=gdist.rank_generator(0, 0))
-        z0 = pm.bij.inverse(x0)
-        pick = 0
-        s0 = epl_series_stats(wl, x0)
-        if s0 is not None:
-            import math
-            e = None
-            for prof, p in zip(wl.phys_model.lenses, x0["lens_mass"]):
-                if getattr(prof, "_kind", 0) == 1:
-                    e = torch.sqrt(torch.as_tensor(p["e1"], dtype=torch.float64) ** 2 + torch.as_tensor(p["e2"], dtype=torch.float64) ** 2)
-                    break
-            K = torch.ceil(math.log(EPL_SERIES_TOL) / torch.log(e.clamp(1e-30, 1 - 1e-12)) + 2.0) - 1
-            pick = int(torch.argmin((K - round(s0["mean_terms"])).abs()))
-            g = float(torch.ceil((K[pick] + 1) / 4))
-            series = {"mean_terms": float(K[pick]), "mean_four_term_groups": g, "mean_pair_trips": 0.5 * (g - 1.0), "frac_odd": 0.0}
-        mu = z0[pick].to(dev).contiguous().clone()
-        lpk = ginf.tril_pack(torch.eye(d, device=dev) * 1e-3)
-        sv_params = torch.cat([mu, lpk]).contiguous()
-        opt = ginf.Adam(lr=0.0)
-        gen = gdist.rank_generator(2, rank, device=dev)
-
-        def vg(zz):
-            lp_, _, g_ = pm.log_prob_and_grad(sim, zz)
-            return lp_, g_
-
-        pool = ginf.NormalPool(gen, B, d, device=dev)  # the driver's own draw schedule (ModellingSequence.SVI)
-
-        def step():
-            buf = ginf.svi_step_buffer(sv_params[:d], sv_params[d:], None, B, gen, value_and_grad_fn=vg, full_rank=True,
-                                       eps=pool.next())
-            opt.step(sv_params, buf[1:])
-            return buf
+        step, series_svi = make_svi_step(wl, pm, sim, B, dev, rank)
+        if series_svi is not None:
+            series = series_svi
     else:
         def step():
             return pm.log_prob_and_grad(sim, z)
@@ -499,61 +655,34 @@ def main():
         torch.cuda.synchronize()
         n_pre += 50
     events = not args.no_kernel_events
+    # the kernel pass after the timed region times every main launch (event pairs on the dispatch packets, csrc/gl_launch.hip.h);
+    # --kernel-event-stride thins it out if asked to
     stride = max(1, min(args.kernel_event_stride, args.steps))
-    n_ev = (args.steps + stride - 1) // stride
-    for _ in range(args.warmup):
-        step()
-    if events:
-        # ring of ceil(K / stride) event pairs around every stride-th main launch, armed after the warm-up: what it holds
-        # after the loop are launches of the timed region only (allocating the events is host work, no GPU call)
-        model.set_timing(n_ev, stride)
-    gdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    gdist.barrier()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    gdist.allreduce_max_(tmax)
-    elapsed = float(tmax.item())
-    kernel_ms = sorted(model.timing_drain()) if events else []  # the most recent n_ev recorded launches
-    if events:
-        model.set_timing(0)
-    # the last timed step's outputs must be finite numbers (a NaN or an untouched buffer would print the same line)
-    outs = last if isinstance(last, (tuple, list)) else (last,)
-    finite_after = all(bool(torch.isfinite(t).all()) for t in outs if torch.is_tensor(t))
+    elapsed, kernel_ms, last = timed_region(step, model, args.steps, args.warmup, events, stride, dev)
+    # the last timed step's outputs must be finite numbers on every rank (a NaN or an untouched buffer would print the same line)
+    finite_after = outputs_finite(last)
     # beside the line's value (not part of it): with several ranks, the same K steps of the plain forward+gradient call on
     # each rank's shard and NO collective -- how MAP and HMC shard (jax/inference.py:32-80,157-208) -- so that the cost of the
     # SVI step's extra launches and of its all-reduce can be read off the line
     sharded = None
     kernel_ms_fg = []
     if world > 1 and mode == "svi":
-        for _ in range(min(args.warmup, 20)):
-            pm.log_prob_and_grad(sim, z)
-        if events:
-            model.set_timing(n_ev, stride)
-        gdist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            pm.log_prob_and_grad(sim, z)
-        torch.cuda.synchronize()
-        gdist.barrier()
-        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        gdist.allreduce_max_(e2)
-        if events:
-            kernel_ms_fg = sorted(model.timing_drain())
-            model.set_timing(0)
-        sharded = {"value": round(B * world * args.steps / float(e2.item()), 1), "unit": "sims/s",
-                   "ms_per_step": round(1e3 * float(e2.item()) / args.steps, 4),
+        e2, kernel_ms_fg, last2 = timed_region(lambda: pm.log_prob_and_grad(sim, z), model, args.steps, min(args.warmup, 20), events,
+                                               stride, dev)
+        finite_after = finite_after and outputs_finite(last2)
+        sharded = {"value": round(B * world * args.steps / e2, 1), "unit": "sims/s", "ms_per_step": round(1e3 * e2 / args.steps, 4),
                    "what": "ForwardProbModel.log_prob_and_grad on every rank's shard, no collective (MAP / HMC sharding)"}
+    # BASELINE.json configs[4] rides on the N > 1 line: the 2048-particle cluster-model SVI sharded over the ranks
+    c5 = None
+    c5_ok = True
+    if world > 1 and args.mode == "auto" and args.workload.upper() == "C2" and not args.no_configs:
+        c5, c5_ok = measure_c5_sharded(dev, rank, world, min(args.steps, 200), min(max(args.warmup, 5), 20), events, stride)
+    if not all_ranks_ok(finite_after and c5_ok, dev):
+        sys.stderr.write(f"bench.py: rank {rank}: a timed loop returned non-finite values or the C5 shard failed its check on some rank "
+                         f"(this rank: finite {finite_after}, C5 ok {c5_ok})\n")
+        sys.exit(4)
 
     if rank == 0:
-        if not finite_after:
-            sys.stderr.write("bench.py: the timed loop's last step returned non-finite values\n")
-            sys.exit(4)
         ms_per_step = 1e3 * elapsed / args.steps
         sims = B * world * args.steps / elapsed
         # With several ranks and no --mode given, the line's `value` stays the metric BASELINE.json names at every N -- the
@@ -577,12 +706,20 @@ def main():
             roofline["note"] = ("path is VALU/transcendental-bound (SURVEY 8d): the HBM fraction is priced with the "
                                 "simulate()-boundary bytes B1 as the metric asks; the binding bound is the fp32 vector rate "
                                 "(valu_flop_frac)")
-            try:  # PMC traffic of an earlier profiled run of the same kernel, named as such (not a measurement of this run)
+            try:
+                # HBM bytes per launch of this kernel are a PMC figure (2 x FETCH_SIZE + WRITE_SIZE, separate counter passes of
+                # tools/collect_profiles.sh): the committed summary of the newest profiled run of the same workload, named beside it
                 prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
                 if prof and args.workload.upper() == "C2" and B == 1024:
                     summ = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
-                    roofline["traffic_profiled"] = {"file": f"profiles/{prof[-1]}",
-                                                    "hbm_bytes_per_launch": summ.get("traffic_bytes_per_launch")}
+                    t = summ.get("traffic_bytes_per_launch")
+                    if t:
+                        roofline["traffic"] = round(float(t), 1)
+                        roofline["traffic_source"] = (f"profiles/{prof[-1]}::traffic_bytes_per_launch (rocprofv3 --pmc FETCH_SIZE / "
+                                                      "WRITE_SIZE passes of tools/collect_profiles.sh on tools/prof_kernel.py, same "
+                                                      "workload and kernel; not a measurement of this run)")
+                        roofline["traffic_over_B2"] = round(float(t) / (roofline["algorithmic_bytes_per_sim_B2"] * B), 2)
+                        roofline["traffic_over_B1"] = round(float(t) / (roofline["algorithmic_bytes_per_sim_B1"] * B), 4)
             except Exception:
                 pass
         out = {
@@ -594,7 +731,7 @@ def main():
                                    f"batch {B} per GPU, fp32" + (" (BASELINE.json configs[1])" if wl.name == "C2" else "")
                                    + (" (BASELINE.json configs[4]: per-rank shard of the 2048-particle SVI)" if wl.name == "C5" else ""),
                        "samples_per_gpu": B, "pixels": N, "params_per_sample": P, "z_dim": d, "mode": line_mode,
-                       "untimed_preroll_steps": n_pre, "kernel_events_in_timed_loop": events,
+                       "untimed_preroll_steps": n_pre, "kernel_events_in_timed_loop": False, "kernel_pass_after_timed_loop": events,
                        "epl_series": series,
                        "parallelism": ("single GPU" if world == 1 else
                                        (f"dp{world}: particle shards, one {n_coll}-float all-reduce per step "
@@ -610,14 +747,22 @@ def main():
             "roofline": roofline,
             "oracle_spot_check": check,
         }
+        out["oracle_spot_check"] = dict(check, ranks_checked=world, all_ranks_ok=True)
         if svi_side is not None:
             out["svi_step"] = svi_side
         elif sharded is not None:
             out["sharded_fwdgrad_without_collective"] = sharded
+        if c5 is not None:
+            out["configs"] = [c5]
+        if world > 1:
+            out["multi_gpu_note"] = (f"backend {torch.distributed.get_backend()}: until a SCALE_rNN.json of the driver exists, no N > 1 line "
+                                     "of this repository has been measured over RCCL / xGMI (the builder's boxes have one GPU; rehearsals "
+                                     "run two gloo ranks on it, profiles/*_2rank_gloo_rehearsal.json)")
         if world == 1 and not args.no_configs and args.workload.upper() == "C2":
             del pm, sim, z
             torch.cuda.empty_cache()
             out["configs"] = measure_extra_configs(dev)  # the other BASELINE configs, each with both fractions
+            out["configs"].append(measure_c3l(dev))
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             n_cpu = args.cpu_samples or (256 if N <= 16384 else 32)
             out["cpu_baseline"] = cpu_baseline(wl, obs, seconds=args.cpu_seconds, sample_batch=min(n_cpu, B))

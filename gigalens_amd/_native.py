@@ -95,6 +95,7 @@ SYMBOLS = {
                                   c_void_p, c_int, c_void_p, c_void_p]),
     "gl_profile_eval": (c_int, [POINTER(gl_component), c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
+    "gl_user_model_compile_count": (ctypes.c_longlong, []),
     "gl_user_profile_check": (c_int, [ctypes.c_char_p, c_int, c_int]),
     "gl_user_profile_create": (c_int, [ctypes.c_char_p, c_int, c_int, POINTER(c_void_p)]),
     "gl_user_profile_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,

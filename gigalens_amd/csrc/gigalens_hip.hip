@@ -946,6 +946,11 @@ int gl_model_timing_drain(gl_model* m, float* ms, int cap, int* n_out) {
 
 int gl_model_last_main_kernel(const gl_model* m, char* buf, size_t cap) {
   if (!m || !buf || cap == 0) return fail(GL_EINVAL, "bad argument");
+  if (m->last_main_user >= 0) {  // a model with user-written profiles: the run-time compiled interpreter (gl_user.hip)
+    snprintf(buf, cap, "gl_main_kernel<%d, 2, %s, %d> [run-time compiled with the model's user-written profile bodies]", m->last_main_user.load(),
+             m->has_shapelets ? "true" : "false", m->fam);
+    return GL_OK;
+  }
   if (!m->last_main_fn) return fail(GL_EINVAL, "no main kernel has been launched on this model yet");
   const char* name = hipKernelNameRefByPtr(m->last_main_fn.load(), nullptr);
   if (!name) return fail(GL_ELAUNCH, "hipKernelNameRefByPtr returned no name");

@@ -1,5 +1,5 @@
 // one mode of the generic launcher (interpreter, cluster kernel) per translation unit, built with -fno-slp-vectorize: LL_FWD
 #include "gl_launch_generic.hip.h"
 namespace glk {
-template int launch_generic<LL_FWD>(const gl_model*, const MainArgs&, dim3, dim3, size_t, hipStream_t);
+template int launch_generic<LL_FWD>(const gl_model*, const MainArgs&, dim3, dim3, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 }

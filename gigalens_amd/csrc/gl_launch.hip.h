@@ -3,6 +3,8 @@
 // gl_launch_mode*.hip translation units, each of which instantiates it for ONE mode so that the kernel families compile
 // in parallel.
 #pragma once
+#include <hip/hip_ext.h>
+
 #include "gl_model.h"
 #include "gl_static.hip.h"
 #include "gl_pair.hip.h"
@@ -14,12 +16,12 @@ namespace glk {
 // SERSIC and SERSIC_ELLIPSE share one device code path (the spherical profile is the e = 0 member), so
 // signatures are matched after folding SERSIC_ELLIPSE -> SERSIC.
 template <int MODE>
-bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
+bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   const int T = (MODE == IMG_BWD || MODE == LL_GRAD) ? m->tile_grad : m->tile;
 #define GL_PAIR(WW, LK, CK, SK)                                                           \
   do {                                                                                    \
     m->last_main_fn = (const void*)&gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>;            \
-    hipLaunchKernelGGL((gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>), grid, block, shmem, stream, a); \
+    hipExtLaunchKernelGGL((gl_pair_kernel<MODE, v2f, WW, LK, CK, SK>), grid, block, (std::uint32_t)(shmem), stream, ev0, ev1, 0, a); \
   } while (0)
   if (m->pair) {
     // waves/SIMD the register budget is declared for: gradient modes keep the EPL / Sersic state of a pixel
@@ -56,7 +58,7 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
 #define GL_SHP2(LLK_, I_, R_)                                                                                 \
   do {                                                                                                        \
     m->last_main_fn = (const void*)&gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_, R_>;                     \
-    hipLaunchKernelGGL((gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_, R_>), grid, block, sh, stream, a);   \
+    hipExtLaunchKernelGGL((gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_, R_>), grid, block, (std::uint32_t)(sh), stream, ev0, ev1, 0, a);   \
   } while (0)
 #define GL_SHP(LLK_, I_) do { if (ragged) GL_SHP2(LLK_, I_, true); else GL_SHP2(LLK_, I_, false); } while (0)
     if (m->static_id == ST_EPLSHEAR_SHAPELETS) { if (interp) GL_SHP(C_None, true); else GL_SHP(C_None, false); }
@@ -68,7 +70,7 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
 #define GL_LAUNCH(TT, WW, LK, CK, SK)                                                        \
   do {                                                                                       \
     m->last_main_fn = (const void*)&gl_static_kernel<MODE, TT, WW, LK, CK, SK>;              \
-    hipLaunchKernelGGL((gl_static_kernel<MODE, TT, WW, LK, CK, SK>), grid, block, shmem, stream, a); \
+    hipExtLaunchKernelGGL((gl_static_kernel<MODE, TT, WW, LK, CK, SK>), grid, block, (std::uint32_t)(shmem), stream, ev0, ev1, 0, a); \
   } while (0)
   switch (m->static_id) {
     case ST_EPLSHEAR_SERSIC:
@@ -101,7 +103,7 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
 // the interpreter and the cluster kernel live in translation units of their own (gl_launch_generic.hip.h, built without the
 // SLP vectoriser): everything that is not a compile-time-specialised composition
 template <int MODE>
-int launch_generic(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream);
+int launch_generic(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 
 template <int MODE>
 int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream) {
@@ -109,22 +111,28 @@ int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipSt
   if (a.tail_rows > 0)  // tail_plan(): the tail samples' workgroups are dealt over whole rows of the grid
     grid.y = a.tail_from + (unsigned)(((long long)(B - a.tail_from) * a.tail_rows + n_chunks - 1) / n_chunks);
   size_t shmem = (size_t)(((m->D + 3) & ~3) + m->ncols * m->Apad) * sizeof(float) + m->nfw_lds;
-  // every timing_stride-th main launch is bracketed by an event pair (an event record costs ~2.5 us of stream time)
+  // Every timing_stride-th main launch carries an event pair ON ITS OWN DISPATCH PACKET (hipExtLaunchKernel: the runtime writes
+  // the kernel's start and end timestamps into them when it completes) -- no extra packets on the stream.  Until round 4 the
+  // pair was two hipEventRecord calls around the launch, ~2.5 us of stream time each: bracketing every launch slowed a 0.085 ms
+  // step by 5 %, which is why the ring had a stride at all.
   const bool timed = m->timing_slots && (m->timing_calls.fetch_add(1) % m->timing_stride) == 0;
   const int slot = timed ? (int)(m->timing_count.fetch_add(1) % m->timing_slots) : 0;  // the slot is claimed here
-  if (timed) GL_HIP(hipEventRecord(m->evs[2 * slot], stream));
+  const hipEvent_t ev0 = timed ? m->evs[2 * slot] : nullptr, ev1 = timed ? m->evs[2 * slot + 1] : nullptr;
   // models with user-written profiles, shapelets above n_max = 10, the cluster models in the gradient modes and the basis stack
   // go to the generic launcher first; then the specialised compositions; then the interpreter
   constexpr bool GRADM = (MODE == IMG_BWD || MODE == LL_GRAD);
   const bool generic_first = m->has_user || m->shp_big || (GRADM && m->cluster && a.parts == 7u) || MODE == IMG_BASIS;
-  if (!generic_first && m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream)) {
+  m->last_main_user = -1;
+  if (!generic_first && m->static_id && a.parts == 7u && launch_static<MODE>(m, a, grid, block, shmem, stream, ev0, ev1)) {
     // specialised kernel launched
   } else {
-    const int rc = launch_generic<MODE>(m, a, grid, block, shmem, stream);
-    if (rc) return rc;
-  }
-  if (timed) {
-    GL_HIP(hipEventRecord(m->evs[2 * slot + 1], stream));
+    const int rc = launch_generic<MODE>(m, a, grid, block, shmem, stream, ev0, ev1);
+    if (rc) {
+      // no kernel went out: the claimed ring slot must still hold a complete pair, or a drain would wait on (or read) events
+      // of an earlier lap -- both are recorded here, back to back (a ~0 duration)
+      if (timed) { (void)hipEventRecord(ev0, stream); (void)hipEventRecord(ev1, stream); }
+      return rc;
+    }
   }
   GL_HIP(hipGetLastError());
   return GL_OK;

@@ -7,6 +7,8 @@
 // of its time -- while the specialised kernels are written in packed form by hand and keep it (their direct-mode shapelet
 // variant spills SGPRs to scratch without it).
 #pragma once
+#include <hip/hip_ext.h>
+
 #include "gl_model.h"
 #include "gl_kernels.hip.h"
 #include "gl_cluster.hip.h"
@@ -15,11 +17,11 @@
 namespace glk {
 
 template <int MODE>
-int launch_generic(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
+int launch_generic(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, size_t shmem, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
 #define GL_MAIN(TT, S_, F_)                                                              \
   do {                                                                                   \
     m->last_main_fn = (const void*)&gl_main_kernel<MODE, TT, S_, F_>;                    \
-    hipLaunchKernelGGL((gl_main_kernel<MODE, TT, S_, F_>), grid, block, shmem, stream, a); \
+    hipExtLaunchKernelGGL((gl_main_kernel<MODE, TT, S_, F_>), grid, block, (std::uint32_t)(shmem), stream, ev0, ev1, 0, a); \
   } while (0)
 #define GL_MAIN_FAM(TT, S_) \
   do { if (m->fam == 2) GL_MAIN(TT, S_, 2); else if (m->fam == 1) GL_MAIN(TT, S_, 1); else GL_MAIN(TT, S_, 0); } while (0)
@@ -29,12 +31,13 @@ int launch_generic(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     MainArgs args = a;
     void* kargs[] = {(void*)&args};
     m->last_main_fn = nullptr;
-    GL_HIP(hipModuleLaunchKernel(m->user_fn[MODE], grid.x, grid.y, 1, block.x, 1, 1, (unsigned)shmem, stream, kargs, nullptr));
+    m->last_main_user = MODE;  // gl_model_last_main_kernel names it "gl_main_kernel<MODE, 2, ..., user>" (no host function to look up)
+    GL_HIP(hipExtModuleLaunchKernel(m->user_fn[MODE], grid.x * block.x, grid.y, 1, block.x, 1, 1, (unsigned)shmem, stream, kargs, nullptr, ev0, ev1, 0));
     done = true;
   }
   if (!done && m->shp_big) {  // shapelets above n_max = 10: the runtime-order interpreter variant (basic profile families, T = 2)
     m->last_main_fn = (const void*)&gl_main_kernel<MODE, 2, true, 0, true>;
-    hipLaunchKernelGGL((gl_main_kernel<MODE, 2, true, 0, true>), grid, block, shmem, stream, a);
+    hipExtLaunchKernelGGL((gl_main_kernel<MODE, 2, true, 0, true>), grid, block, (std::uint32_t)(shmem), stream, ev0, ev1, 0, a);
     done = true;
   }
   if constexpr (MODE == IMG_BWD || MODE == LL_GRAD) {
@@ -43,7 +46,7 @@ int launch_generic(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
 #define GL_CLUSTERW(HPW_, SPW_, E_, W_)                                                                  \
   do {                                                                                                 \
     m->last_main_fn = (const void*)&gl_clusterw_kernel<MODE, HPW_, SPW_, E_, W_>;                        \
-    hipLaunchKernelGGL((gl_clusterw_kernel<MODE, HPW_, SPW_, E_, W_>), grid, block, sh, stream, a, m->n_lens, m->n_src); \
+    hipExtLaunchKernelGGL((gl_clusterw_kernel<MODE, HPW_, SPW_, E_, W_>), grid, block, (std::uint32_t)(sh), stream, ev0, ev1, 0, a, m->n_lens, m->n_src); \
   } while (0)
       const int size = (m->n_lens <= 4 && m->n_src <= 8) ? 0 : (m->n_src <= 12 ? 1 : 2);
       if (m->cluster == 2) { if (size == 0) GL_CLUSTERW(1, 2, true, 4); else if (size == 1) GL_CLUSTERW(2, 3, true, 3); else GL_CLUSTERW(2, 5, true, 2); }
@@ -56,7 +59,7 @@ int launch_generic(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
 #define GL_CLUSTER(NH_, NS_, E_, W_)                                                                     \
   do {                                                                                                 \
     m->last_main_fn = (const void*)&gl_cluster_kernel<MODE, NH_, NS_, E_, W_>;                          \
-    hipLaunchKernelGGL((gl_cluster_kernel<MODE, NH_, NS_, E_, W_>), grid, block, sh, stream, a, m->n_lens, m->n_src); \
+    hipExtLaunchKernelGGL((gl_cluster_kernel<MODE, NH_, NS_, E_, W_>), grid, block, (std::uint32_t)(sh), stream, ev0, ev1, 0, a, m->n_lens, m->n_src); \
   } while (0)
       const bool small = m->n_lens <= 4 && m->n_src <= 8;
       if (m->cluster == 2) { if (small) GL_CLUSTER(4, 8, true, 3); else GL_CLUSTER(8, 20, true, 2); }

@@ -112,6 +112,7 @@ struct gl_model {
   mutable std::atomic<long long> timing_count{0}, timing_calls{0};
   std::vector<hipEvent_t> evs;  // 2 * timing_slots
   mutable std::atomic<const void*> last_main_fn{nullptr};
+  mutable std::atomic<int> last_main_user{-1};  // mode of the run-time compiled kernel the most recent main launch dispatched, or -1
   // galaxy catalogues of the GL_SCALED components (gl_model_set_catalogue)
   struct Cat { CatDev dev; std::vector<float> table; };
   std::vector<Cat> cats;

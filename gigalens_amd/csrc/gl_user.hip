@@ -16,6 +16,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -189,27 +192,29 @@ int compile_user_profile(const char* body, int is_light, int n_params, std::vect
 }  // namespace
 
 // ---- user bodies inside a model: the interpreter kernel compiled with them ----------------------------------------------------
-#include <dlfcn.h>
-
 #include "gl_kernels.hip.h"  // MainArgs, Mode, kinds (host view; the device code of this translation unit is unused)
 
 namespace glk {
 
-// the directory of the kernel headers: next to the library (gigalens_amd/lib/ -> gigalens_amd/csrc/), or GIGALENS_HIP_CSRC
-static std::string csrc_dir() {
-  if (const char* e = getenv("GIGALENS_HIP_CSRC")) return e;
-  Dl_info info{};
-  if (dladdr((const void*)&gl_version, &info) && info.dli_fname) {
-    std::string p = info.dli_fname;
-    const size_t a = p.rfind('/');
-    if (a != std::string::npos) {
-      p.resize(a);  // .../lib
-      const size_t b = p.rfind('/');
-      if (b != std::string::npos) return p.substr(0, b) + "/csrc";
-    }
-  }
-  return "gigalens_amd/csrc";
+// The kernel headers the run-time compile includes travel INSIDE the library: __graft_entry__.build() writes every csrc/*.h into
+// build/gl_embedded_headers.inc as string literals (kEmbeddedNames / kEmbeddedSources / kEmbeddedCount) and hiprtcCreateProgram
+// gets them as named headers -- an installed library needs no source checkout.  GIGALENS_HIP_CSRC=<dir> (development) reads the
+// headers from a directory instead.
+#include "gl_embedded_headers.inc"
+
+// one compiled interpreter per distinct program text (user bodies, parameter counts, shapelet / family switches are all part
+// of the text): ModellingSequence builds a LensSimulator per stage and per batch size, each calling gl_model_create_user with
+// the same bodies -- the seconds of hiprtc are paid once per process, a model only loads the code object
+struct UserCode {
+  std::vector<char> code;
+  std::string lowered[4];
+};
+static std::mutex g_user_mu;
+static std::map<std::string, std::shared_ptr<const UserCode>>& user_cache() {
+  static std::map<std::string, std::shared_ptr<const UserCode>> c;
+  return c;
 }
+static std::atomic<long long> g_user_compiles{0};
 
 int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
   // which body serves which kind, with how many parameters (a body used by several components must agree with itself)
@@ -264,44 +269,60 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
     names[mode] = "glk::gl_main_kernel<" + std::to_string(mode) + ", 2, " + (m->has_shapelets ? "true" : "false") + ", " + std::to_string(m->fam) + ", false>";
     src += "template __global__ void " + names[mode] + "(glk::MainArgs);\n";
   }
-  hiprtcProgram prog = nullptr;
-  if (hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-    return fail(GL_ELAUNCH, "hiprtcCreateProgram failed");
-  for (int mode = 0; mode < 4; ++mode) (void)hiprtcAddNameExpression(prog, names[mode].c_str());
-  const std::string inc = "-I" + csrc_dir();
-  // (-fno-slp-vectorize: as for the interpreter of the library itself, gl_launch_generic.hip.h)
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", inc.c_str()};
-  const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
-  if (rc != HIPRTC_SUCCESS) {
-    size_t n = 0;
-    (void)hiprtcGetProgramLogSize(prog, &n);
-    std::string log(n ? n : 1, '\0');
-    if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
-    (void)hiprtcDestroyProgram(&prog);
-    const size_t at = log.find("error");
-    const size_t from = at == std::string::npos ? 0 : log.rfind('\n', at) == std::string::npos ? 0 : log.rfind('\n', at) + 1;
-    return fail(GL_EINVAL, "user profile does not compile (%s; kernel headers from %s):\n%.330s", hiprtcGetErrorString(rc), csrc_dir().c_str(), log.c_str() + from);
-  }
-  std::string lowered[4];
-  for (int mode = 0; mode < 4; ++mode) {
-    const char* ln = nullptr;
-    if (hiprtcGetLoweredName(prog, names[mode].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+  const char* dev_dir = getenv("GIGALENS_HIP_CSRC");
+  std::shared_ptr<const UserCode> uc;
+  {
+    std::lock_guard<std::mutex> lock(g_user_mu);  // (also serialises concurrent compiles of the same text: the second finds the first's)
+    const std::string key = src + (dev_dir ? std::string("\n//csrc=") + dev_dir : std::string());
+    auto it = user_cache().find(key);
+    if (it != user_cache().end()) {
+      uc = it->second;
+    } else {
+      hiprtcProgram prog = nullptr;
+      const hiprtcResult rcc = dev_dir ? hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", 0, nullptr, nullptr)
+                                       : hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", kEmbeddedCount, kEmbeddedSources, kEmbeddedNames);
+      if (rcc != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcCreateProgram failed");
+      for (int mode = 0; mode < 4; ++mode) (void)hiprtcAddNameExpression(prog, names[mode].c_str());
+      const std::string inc = std::string("-I") + (dev_dir ? dev_dir : ".");
+      // (-fno-slp-vectorize: as for the interpreter of the library itself, gl_launch_generic.hip.h)
+      const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", inc.c_str()};
+      const hiprtcResult rc = hiprtcCompileProgram(prog, dev_dir ? 5 : 4, opts);
+      if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        (void)hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n ? n : 1, '\0');
+        if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+        (void)hiprtcDestroyProgram(&prog);
+        const size_t at = log.find("error");
+        const size_t from = at == std::string::npos ? 0 : log.rfind('\n', at) == std::string::npos ? 0 : log.rfind('\n', at) + 1;
+        return fail(GL_EINVAL, "user profile does not compile (%s; kernel headers %s):\n%.330s", hiprtcGetErrorString(rc),
+                    dev_dir ? dev_dir : "embedded in the library", log.c_str() + from);
+      }
+      auto fresh = std::make_shared<UserCode>();
+      for (int mode = 0; mode < 4; ++mode) {
+        const char* ln = nullptr;
+        if (hiprtcGetLoweredName(prog, names[mode].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+          (void)hiprtcDestroyProgram(&prog);
+          return fail(GL_ELAUNCH, "hiprtcGetLoweredName failed for %s", names[mode].c_str());
+        }
+        fresh->lowered[mode] = ln;
+      }
+      size_t code_size = 0;
+      if (hiprtcGetCodeSize(prog, &code_size) != HIPRTC_SUCCESS || !code_size) {
+        (void)hiprtcDestroyProgram(&prog);
+        return fail(GL_ELAUNCH, "hiprtcGetCodeSize failed");
+      }
+      fresh->code.resize(code_size);
+      const hiprtcResult rc2 = hiprtcGetCode(prog, fresh->code.data());
       (void)hiprtcDestroyProgram(&prog);
-      return fail(GL_ELAUNCH, "hiprtcGetLoweredName failed for %s", names[mode].c_str());
+      if (rc2 != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcGetCode failed");
+      g_user_compiles.fetch_add(1);
+      user_cache()[key] = fresh;
+      uc = fresh;
     }
-    lowered[mode] = ln;
   }
-  size_t code_size = 0;
-  if (hiprtcGetCodeSize(prog, &code_size) != HIPRTC_SUCCESS || !code_size) {
-    (void)hiprtcDestroyProgram(&prog);
-    return fail(GL_ELAUNCH, "hiprtcGetCodeSize failed");
-  }
-  std::vector<char> code(code_size);
-  const hiprtcResult rc2 = hiprtcGetCode(prog, code.data());
-  (void)hiprtcDestroyProgram(&prog);
-  if (rc2 != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcGetCode failed");
-  hipError_t e = hipModuleLoadData(&m->user_module, code.data());
-  for (int mode = 0; mode < 4 && e == hipSuccess; ++mode) e = hipModuleGetFunction(&m->user_fn[mode], m->user_module, lowered[mode].c_str());
+  hipError_t e = hipModuleLoadData(&m->user_module, uc->code.data());
+  for (int mode = 0; mode < 4 && e == hipSuccess; ++mode) e = hipModuleGetFunction(&m->user_fn[mode], m->user_module, uc->lowered[mode].c_str());
   if (e != hipSuccess) return fail(GL_ELAUNCH, "loading the compiled user model failed: %s", hipGetErrorString(e));
   return GL_OK;
 }
@@ -309,6 +330,8 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
 }  // namespace glk
 
 extern "C" {
+
+long long gl_user_model_compile_count(void) { return glk::g_user_compiles.load(); }
 
 int gl_user_profile_check(const char* body, int is_light, int n_params) {
   std::vector<char> code;

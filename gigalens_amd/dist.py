@@ -27,6 +27,7 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        _decide_avg()
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
     return rank, local_rank, world
@@ -49,20 +50,46 @@ def rank_generator(seed: int, rank: int, device="cpu") -> torch.Generator:
     return g
 
 
-_AVG_OK = [True]  # ReduceOp.AVG is an RCCL feature; a build that rejects it is served by SUM + one division (same result)
+_AVG_OK = [False]  # ReduceOp.AVG (an RCCL feature): decided ONCE, by all ranks together, when the process group comes up
+
+
+def _decide_avg():
+    """Every rank tries ``ReduceOp.AVG`` on a one-element tensor and the ranks agree on the outcome with a MIN all-reduce, so
+    that no rank can ever issue a different collective from the others.  (Until round 4 a ``RuntimeError`` from the AVG call
+    itself switched THAT rank to SUM + division for the rest of the process: a failure on one rank only -- a timeout, an
+    asynchronous communicator error surfacing at this call -- would have left the ranks issuing different collectives.)"""
+    _AVG_OK[0] = False
+    if not (dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl" and torch.cuda.is_available()):
+        return
+    ok = 1.0
+    try:
+        t = torch.ones(1, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        torch.cuda.synchronize()
+        if abs(float(t.item()) - 1.0) > 1e-6:
+            ok = 0.0
+    except RuntimeError:  # "unsupported reduction": raised on every rank alike, before anything is enqueued
+        ok = 0.0
+    flag = torch.tensor([ok], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    _AVG_OK[0] = bool(flag.item() > 0.5)
 
 
 def allreduce_mean_(buf: torch.Tensor) -> torch.Tensor:
-    """In-place mean over ranks (== lax.pmean). One collective for the whole fused buffer."""
+    """In-place mean over ranks (== lax.pmean). One collective for the whole fused buffer.  Errors propagate: a failed
+    collective is never papered over with a different one."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        if buf.is_cuda and dist.get_backend() == "nccl" and _AVG_OK[0]:
-            try:
-                dist.all_reduce(buf, op=dist.ReduceOp.AVG)  # RCCL averages inside the collective kernel: no second launch
-                return buf
-            except RuntimeError:  # raised before anything is enqueued (unsupported reduction op): buf is untouched
-                _AVG_OK[0] = False
+        if buf.is_cuda and _AVG_OK[0]:
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG)  # RCCL averages inside the collective kernel: no second launch
+            return buf
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         buf.div_(dist.get_world_size())
+    return buf
+
+
+def allreduce_min_(buf: torch.Tensor) -> torch.Tensor:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.MIN)
     return buf
 
 

@@ -359,6 +359,11 @@ int gl_model_launch_shape(const gl_model* m, int B, int* chunk_px, int* n_chunks
  * Not served for such models: the linear-amplitude solve, the image-position likelihood, lens maps (typed refusals). */
 int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light, int n_src, const gl_grid* grid,
                          const char* const* bodies, int n_bodies, gl_model** out);
+/* The compiled interpreter is cached per process, keyed on the program text (bodies, parameter counts, shapelet / family
+ * switches): models created with the same bodies -- one LensSimulator per stage and batch size of a modelling sequence -- share
+ * one hiprtc compile.  The kernel headers the compile includes are embedded in the library (no source checkout needed).
+ * gl_user_model_compile_count: hiprtc compiles of model kernels this process has paid for so far (diagnostics, tests). */
+long long gl_user_model_compile_count(void);
 typedef struct gl_user_profile gl_user_profile;
 int gl_user_profile_check(const char* body, int is_light, int n_params);
 int gl_user_profile_create(const char* body, int is_light, int n_params, gl_user_profile** out);

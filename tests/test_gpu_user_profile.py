@@ -306,3 +306,39 @@ def test_user_written_lens_light_beside_built_in_kinds(gl):
     assert torch.allclose(ll_u, ll_b, rtol=3e-5)
     scale = g_b.abs().amax(dim=0, keepdim=True)
     assert torch.all((g_u - g_b).abs() <= 3e-3 * scale + 1e-6), ((g_u - g_b).abs() / scale).max()
+
+
+def test_models_with_the_same_bodies_share_one_compile_and_need_no_source_tree(gl, tmp_path, monkeypatch):
+    """gl_model_create_user compiles the interpreter with the model's bodies through hiprtc (seconds).  A modelling sequence builds a
+    LensSimulator per stage and per batch size: models with the same program text must share ONE compile per process
+    (csrc/gl_user.hip: code-object cache keyed on the text), and the kernel headers the compile includes come from inside the
+    library (embedded by __graft_entry__.build()), not from a source checkout -- the compile below runs with the working
+    directory somewhere else and no GIGALENS_HIP_CSRC.  Ref: src/gigalens/profile.py:58-82 (the extension point),
+    src/gigalens/tf/inference.py:17-302 (one simulator per stage)."""
+    from gigalens_amd import _native
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profile import MassProfile
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.simulator import LensSimulator, SimulatorConfig
+
+    class UserSIS2(MassProfile):  # a body no other test compiles (its text differs by a comment): the first model must compile
+        _name, _params = "USER_SIS2", ["theta_E", "center_x", "center_y"]
+        hip_body = "// cache test\n" + SIS_BODY
+
+    monkeypatch.delenv("GIGALENS_HIP_CSRC", raising=False)
+    monkeypatch.chdir(tmp_path)
+    L = _native.lib()
+    n0 = L.gl_user_model_compile_count()
+    cfg = SimulatorConfig(delta_pix=0.08, num_pix=24)
+    sims = [LensSimulator(PhysicalModel([UserSIS2()], [], [Sersic()]), cfg, bs=b) for b in (3, 3, 7)]
+    assert L.gl_user_model_compile_count() == n0 + 1
+    r = np.random.default_rng(2)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    imgs = []
+    for s in sims[:2]:
+        params = {"lens_mass": [dict(theta_E=t([1.0, 1.1, 0.9]), center_x=t([0.0, 0.02, -0.03]), center_y=t([0.01, 0.0, 0.02]))],
+                  "source_light": [dict(R_sersic=t([0.3, 0.25, 0.35]), n_sersic=t([1.5, 2.0, 1.0]), center_x=t([0.05, 0.0, -0.05]),
+                                        center_y=t([0.0, 0.03, 0.02]), Ie=t([30.0, 40.0, 50.0]))]}
+        imgs.append(s.simulate(params))
+    assert torch.isfinite(imgs[0]).all() and torch.equal(imgs[0], imgs[1])
+    assert "run-time compiled" in sims[0]._model.last_main_kernel()

@@ -15,7 +15,7 @@ for o in $R/build/*.o; do
 done
 for u in $UNITS; do
   extra=""; case $u in *noslp*) extra="-fno-slp-vectorize";; esac
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I $R/include $extra $FLAGS -c $R/gigalens_amd/csrc/$u.hip -o $R/build/exp/${NAME}_$u.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I $R/include -I $R/build $extra $FLAGS -c $R/gigalens_amd/csrc/$u.hip -o $R/build/exp/${NAME}_$u.o &
   OBJS="$OBJS $R/build/exp/${NAME}_$u.o"
 done
 wait
