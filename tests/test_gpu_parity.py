@@ -24,7 +24,8 @@ IMG_RTOL = 2e-5
 LL_RTOL = 1e-5
 GRAD_RTOL = 2e-3          # per element, relative to max(|g|, 1e-2 column scale): the dPIE / extra-profile suites
 GRAD_RTOL_COL = 3e-4      # per element, relative to its column's scale: reduced-size cases
-GRAD_RTOL_COL_FULL = 1.5e-3  # the same at the full BASELINE sizes (65 536-term sums with cancellation)
+GRAD_RTOL_COL_FULL = 7e-4  # the same at the full BASELINE sizes (65 536-term sums with cancellation); elements beyond it must lie
+                           # within 4 x the float32 conditioning bound of the oracle's own gradient (helpers.grad_gate)
 
 
 @pytest.fixture(scope="module")
@@ -427,13 +428,16 @@ def test_full_size_properties(gl, name, kw):
                                                 None if err is None else err.cpu().numpy(), n_o)
     assert np.allclose(ll.detach()[:n_o].cpu().numpy(), ll_o, rtol=LL_RTOL)
     assert np.allclose(ll_img[:n_o].cpu().numpy(), ll_o, rtol=LL_RTOL)
-    # every element of the checked rows against the scale of its own parameter column; at full size the column scale is taken
-    # over the WHOLE batch (the product's own gradient serves as the scale only: four oracle rows alone make a noisy maximum)
+    # every element of the checked rows against the scale of its own parameter column, taken from the ORACLE rows (until round
+    # 4: from the product's own batch-wide maximum -- an inflated product column would have loosened its own bound); elements
+    # beyond the tolerance must be explained by the float32 conditioning of the oracle's own gradient (helpers.grad_gate)
     g_all = p.grad.cpu().numpy()
-    S_col = np.maximum(np.abs(g_all).max(axis=0, keepdims=True), 1e-3 * np.abs(g_all).max())
-    col_err = np.abs(g_all[:n_o] - g_o) / S_col
-    print(f"{name} {kw}: worst gradient error relative to the column scale {col_err.max():.2e}")
-    assert col_err.max() <= GRAD_RTOL_COL_FULL, (col_err.max(), np.unravel_index(col_err.argmax(), col_err.shape))
+    err_np = None if err is None else err.cpu().numpy()
+    p64c = packed[:n_o].double().cpu()
+    ok, rep = H.grad_gate(g_all[:n_o], g_o, GRAD_RTOL_COL_FULL,
+                          lambda S: H.float32_conditioning_bound(wl_o, p64c, obs.cpu().numpy(), err_np, n_o, g_o, S))
+    print(f"{name} {kw}: gradient gate {rep}")
+    assert ok, rep
     # (2) batch independence: a sub-batch gives the same rows (another batch size means another pixel chunking, i.e. another
     # fixed summation order of the fp32 partial sums: a few ulps of the 65 536-term sum)
     sim_small = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=7)
@@ -532,6 +536,60 @@ def test_cluster_kernel_matches_interpreter(gl, n_halos, n_sources, ellipse, num
             scale = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-6 * float(b.abs().max()))
             assert float(((a - b).abs() / scale).max()) < 2e-4, (flag, k)
             assert float((a - b).abs().max()) > 0.0 or n_sources == 0  # two different kernels ran
+
+
+@pytest.mark.parametrize("case", ["psf", "c2"])
+def test_gradient_error_distribution_vs_float32_reference(gl, case):
+    """Is the HIP gradient systematically further from the float64 truth than the reference's OWN algorithm evaluated in float32
+    (the oracle at dtype float32, torch.autograd through the restated TF graph)?  A single ill-conditioned row cannot tell (see
+    helpers.float32_conditioning_bound); 128 samples can: per row e = max over columns of |g - g_f64| / column scale, and the
+    quantiles of the two error distributions are compared.  Measured over 256 samples (tools/dev/grad_error_distribution.py,
+    profiles/r4_grad_error_distribution.jsonl): ratio HIP / float32-reference of p50 0.52 / 0.70, p90 0.86 / 1.40, max
+    0.83 / 1.18 (PSF geometry / C2 model); the cluster model: 6e-4 (the float32 reference's NFW closed form cancels).
+    Ref: src/gigalens/tf/model.py:89-101, tf/inference.py:33-39."""
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import SersicEllipse
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.simulator import SimulatorConfig
+    from oracle import ref_torch as ref
+    from tests.test_prior_host import default_prior
+    n = 128
+    if case == "psf":
+        phys, prior = PhysicalModel([EPL(), Shear()], [SersicEllipse()], [SersicEllipse()]), default_prior()
+        cfg, psf = SimulatorConfig(delta_pix=0.08, num_pix=60, supersample=1), _gauss_psf(13, 1.2)
+    else:
+        w2 = gl.workloads.make("C2", num_pix=64, batch=n)
+        phys, prior, cfg, psf = w2.phys_model, w2.prior, w2.sim_config, None
+    wl = gl.workloads.Workload("DIST", phys, prior, cfg, n)
+    sim = gl.LensSimulator(phys, cfg, bs=n, supersampled_kernel=psf)
+    packed = H.sample_packed(wl, sim, seed=4)
+    rs1 = ref.RefSimulator(phys, cfg, 1, dtype=torch.float64, supersampled_kernel=psf)
+    img0 = rs1.simulate(H.struct_from_packed(phys, packed[:1].cpu().double())).detach().numpy().reshape(cfg.num_pix, cfg.num_pix)
+    obs = (img0 + 0.3 * np.random.default_rng(1).normal(size=img0.shape)).astype(np.float32)
+    pm = gl.ForwardProbModel(prior, obs, 0.2, 100.0, include_positions=False)
+    p = packed.clone().requires_grad_(True)
+    ll, _ = pm._pixel_stats_packed(sim, p)
+    ll.sum().backward()
+    g = p.grad.double().cpu().numpy()
+
+    def oracle(dt):
+        out = []
+        for i0 in range(0, n, 32):
+            q = packed[i0:i0 + 32].cpu().to(dt).requires_grad_(True)
+            rs = ref.RefSimulator(phys, cfg, q.shape[0], dtype=dt, supersampled_kernel=psf)
+            l, _ = ref.stats_pixels(rs, H.struct_from_packed(phys, q), obs, 0.2, 100.0)
+            out.append(torch.autograd.grad(l.sum(), q)[0].double().numpy())
+        return np.concatenate(out)
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    ok = np.isfinite(g64).all(axis=1) & np.isfinite(g32).all(axis=1)
+    assert ok.sum() >= n - 4 and np.isfinite(g[ok]).all()
+    S = np.abs(g64[ok]).max(axis=0, keepdims=True)
+    e_h, e_3 = (np.abs(g[ok] - g64[ok]) / S).max(axis=1), (np.abs(g32[ok] - g64[ok]) / S).max(axis=1)
+    q = lambda a, f: float(np.quantile(a, f))
+    rep = dict(hip=(q(e_h, .5), q(e_h, .9), float(e_h.max())), f32_reference=(q(e_3, .5), q(e_3, .9), float(e_3.max())))
+    assert q(e_h, 0.5) <= 1.5 * q(e_3, 0.5) and q(e_h, 0.9) <= 2.0 * q(e_3, 0.9) and e_h.max() <= 4.0 * e_3.max(), rep
+    assert q(e_h, 0.5) <= 2e-6, rep
 
 
 @pytest.mark.parametrize("cluster", ["2", "1", "0"])
@@ -668,26 +726,34 @@ def test_psf_supersample_vs_oracle(gl, ss, ksize, n, B, monkeypatch):
     assert np.allclose(ll.detach().cpu().numpy(), ll_o.detach().numpy(), rtol=LL_RTOL)
     assert np.allclose(red.detach().cpu().numpy(), red_o.detach().numpy(), rtol=LL_RTOL)
     g, go = p.grad.cpu().numpy(), g_o.numpy()
-    # Per row, the gate is the column-scale bound -- unless the reference's own algorithm evaluated in float32 (the oracle at
-    # dtype float32) is itself further than that from the float64 truth on this row: a sample whose source centre sits on a
-    # pixel sums terms ~ R^(1/n - 2) of both signs, and float32 evaluation of ANY formulation loses digits there (seed 4,
-    # row 1 of the 60 x 60 cases: float32 oracle 3.4e-4, HIP 3.8e-3, every other row 3e-7).  Such a row is held to 15 x the
-    # float32 oracle's own distance (tools/dev/psf_grad_probe.py).
-    rs32 = ref.RefSimulator(phys, cfg, B, dtype=torch.float32, supersampled_kernel=psf)
-    p32 = packed.cpu().float().requires_grad_(True)
-    ll_32, _ = ref.stats_pixels(rs32, H.struct_from_packed(phys, p32), obs, 0.2, 100.0)
-    (g_32,) = torch.autograd.grad(ll_32.sum(), p32)
-    e_hip, e_32 = H.grad_col_err(g, go), H.grad_col_err(g_32.numpy(), go)
-    tol_row = np.maximum(GRAD_RTOL_COL, 15.0 * e_32.max(axis=1, keepdims=True))
-    assert np.all(e_hip <= tol_row), (e_hip.max(axis=1), e_32.max(axis=1))
+    # The gate: every element within GRAD_RTOL_COL of its column's scale (oracle rows), or -- a sample whose source centre maps
+    # next to a pixel has gradients with a condition number of 1e3-1e4 in the rounding of beta = x - alpha, whatever the
+    # formulation (seed 4, row 1 of the 60 x 60 cases: HIP 3.8e-3, the reference's algorithm in float32 3.4e-4, every other row
+    # 3e-7) -- within 4 x what one float32 rounding of beta does to that element of the ORACLE's gradient
+    # (helpers.float32_conditioning_bound).  That HIP draws from the same error distribution as the reference's algorithm in
+    # float32 over hundreds of samples is test_gradient_error_distribution_vs_float32_reference below.
+    p64c = packed.cpu().double()
+    ok, rep = H.grad_gate(g, go, GRAD_RTOL_COL, lambda S: H.float32_conditioning_bound(
+        wl, p64c, obs, None, B, go, S, bg=(0.2, 100.0), supersampled_kernel=psf))
+    assert ok, rep
     # image-boundary pair through autograd (gl_simulate_bwd with the transposed PSF / pooling)
     p2 = packed.clone().requires_grad_(True)
     w = torch.as_tensor(r.normal(size=(B, n, n)).astype(np.float32), device=p2.device)
     (sim.simulate(p2) * w).sum().backward()
     (g2_o,) = torch.autograd.grad((rs.simulate(H.struct_from_packed(phys, p64)) * w.cpu().double()).sum(), p64)
-    (g2_32,) = torch.autograd.grad((rs32.simulate(H.struct_from_packed(phys, p32)) * w.cpu()).sum(), p32)
-    e2_hip, e2_32 = H.grad_col_err(p2.grad.cpu().numpy(), g2_o.numpy()), H.grad_col_err(g2_32.numpy(), g2_o.numpy())
-    assert np.all(e2_hip <= np.maximum(GRAD_RTOL_COL, 15.0 * e2_32.max(axis=1, keepdims=True))), (e2_hip.max(axis=1), e2_32.max(axis=1))
+
+    def bound2(S):  # the same yardstick for the linear functional sum(w * image)
+        out = np.zeros_like(g2_o.numpy())
+        d = float(np.spacing(np.float32(float(rs.img_X.abs().max()))))
+        for sx, sy in ((d, d), (d, -d)):
+            rs_p = ref.RefSimulator(phys, cfg, B, dtype=torch.float64, supersampled_kernel=psf)
+            rs_p.img_X, rs_p.img_Y = rs_p.img_X + sx, rs_p.img_Y + sy
+            pp = packed.cpu().double().requires_grad_(True)
+            (gp,) = torch.autograd.grad((rs_p.simulate(H.struct_from_packed(phys, pp)) * w.cpu().double()).sum(), pp)
+            out = np.maximum(out, np.abs(gp.numpy() - g2_o.numpy()) / S)
+        return out
+    ok2, rep2 = H.grad_gate(p2.grad.cpu().numpy(), g2_o.numpy(), GRAD_RTOL_COL, bound2)
+    assert ok2, rep2
     # the z-space entry uses the same path
     z = pm.bij.inverse(prior.sample(B, seed=9)).to("cuda")
     lp, red2, gz = pm.log_prob_and_grad(sim, z)

@@ -64,3 +64,41 @@ ll2.sum().backward()
 e_b = H.grad_col_err(p2.grad.cpu().double().numpy(), go)
 print("HIP image + float64 likelihood + HIP backward: worst", e_b.max(), "rows", e_b.max(1))
 print("fused-path rows", e_hip.max(1), "f32 oracle rows", e_32.max(1))
+
+# ---- round 4: (c) the backward alone -- HIP VJP of simulate() against the float64 VJP for the SAME float64 cotangent ----
+im64 = rs64.simulate(H.struct_from_packed(phys, packed.cpu().double())).detach()
+o64 = torch.as_tensor(obs).double()
+s2 = 0.2 ** 2 + im64 / 100.0
+cot = (-(im64 - o64) / s2 + (im64 - o64) ** 2 / (2 * s2 * s2 * 100.0) - 1.0 / (2 * s2 * 100.0))  # d loglike / d image at the float64 image
+p3 = packed.clone().requires_grad_(True)
+(sim.simulate(p3) * cot.float().to(p3.device)).sum().backward()
+p64b = packed.cpu().double().requires_grad_(True)
+(g_lin,) = torch.autograd.grad((rs64.simulate(H.struct_from_packed(phys, p64b)) * cot).sum(), p64b)
+p32b = packed.cpu().float().requires_grad_(True)
+(g_lin32,) = torch.autograd.grad((rs32.simulate(H.struct_from_packed(phys, p32b)) * cot.float()).sum(), p32b)
+S = np.abs(go).max(axis=0, keepdims=True)
+e_c = np.abs(p3.grad.cpu().double().numpy() - g_lin.numpy()) / S
+e_c32 = np.abs(g_lin32.double().numpy() - g_lin.numpy()) / S
+print("(c) VJP with the float64 cotangent, error / column scale of the likelihood gradient: HIP rows", e_c.max(1), " f32 oracle rows", e_c32.max(1))
+# ---- (d) how much of the row's error is the cotangent: d(gradient) for the cotangent error of each path ----
+for tag, imx in (("hip", img_h), ("f32", img_32)):
+    s2x = 0.2 ** 2 + imx / 100.0
+    cotx = (-(imx - o64) / s2x + (imx - o64) ** 2 / (2 * s2x * s2x * 100.0) - 1.0 / (2 * s2x * 100.0))
+    (gd,) = torch.autograd.grad((rs64.simulate(H.struct_from_packed(phys, p64b)) * (cotx - cot)).sum(), p64b)
+    print(f"(d) gradient change from the {tag} image's cotangent error (float64 VJP), / column scale, rows", (np.abs(gd.numpy()) / S).max(1))
+# ---- (e) the image error where it matters: relative error at the brightest pixels of row 1 ----
+b = 1
+idx = np.argsort(-img_o[b].numpy().ravel())[:12]
+rel_h = ((img_h[b] - img_o[b]) / img_o[b]).numpy().ravel()[idx]
+rel_3 = ((img_32[b] - img_o[b]) / img_o[b]).numpy().ravel()[idx]
+print("(e) row 1, 12 brightest pixels: value", img_o[b].numpy().ravel()[idx][:4], "rel err hip", np.abs(rel_h).max(), "f32", np.abs(rel_3).max())
+print("    hip", rel_h[:6], "\n    f32", rel_3[:6])
+# ---- (f) the same without a PSF (the unconvolved image): relative error at the brightest pixels ----
+sim0 = LensSimulator(phys, cfg, bs=B)
+i0 = sim0.simulate(packed).double().cpu()
+r0 = ref.RefSimulator(phys, cfg, B, dtype=torch.float64).simulate(H.struct_from_packed(phys, packed.cpu().double())).detach()
+r032 = ref.RefSimulator(phys, cfg, B, dtype=torch.float32).simulate(H.struct_from_packed(phys, packed.cpu().float())).detach().double()
+idx = np.argsort(-r0[b].numpy().ravel())[:12]
+print("(f) no PSF, row 1 brightest: value", r0[b].numpy().ravel()[idx][:4], "rel err hip", np.abs(((i0[b] - r0[b]) / r0[b]).numpy().ravel()[idx]).max(),
+      "f32", np.abs(((r032[b] - r0[b]) / r0[b]).numpy().ravel()[idx]).max())
+print("    packed row 1:", packed[b].cpu().numpy())
