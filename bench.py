@@ -304,9 +304,10 @@ def roofline_of(model, wl, sim, x, kernel_ms, ms_per_step, err, stride):
         seen = float(rows[:, :, 3].sum())
         p_live = float(rows[:, :, 2].sum()) / seen if seen > 0 else 1.0
         roof["shapelet_live_wave_tile_share"] = round(p_live, 4)
+    n_members = sum(int(getattr(l, "n_galaxy", 0)) for l in wl.phys_model.lenses)  # galaxy catalogues (ScalingRelation / DPIESubhalo)
     try:
         # (the steady-state tile of the likelihood kernels is compiled once per variance model: tell the ISA model which ran)
-        acct = isa_account(symbol, dict(series or {}, error_map=err is not None), p_live)
+        acct = isa_account(symbol, dict(series or {}, error_map=err is not None, **({"n_members": n_members} if n_members else {})), p_live)
     except Exception as exc:  # the accounting is evidence, never a reason to lose the line
         acct = {"error": repr(exc)}
     if acct:

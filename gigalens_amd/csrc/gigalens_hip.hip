@@ -183,6 +183,7 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.partial = w.partial;
   a.shp_tab = m->d_shp_tab;
   a.nfw_tab = m->d_nfw_tab;
+  a.neutral = m->d_nfw_tab ? m->d_nfw_tab + 2 * glh::kNfwNodes : nullptr;
   a.dbg = m->dbg_flags;
   a.shp_stride = m->shp_stride;
   a.parts = 7u;
@@ -764,6 +765,7 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
     ok = ok && up((void**)&m->d_pix, grid->pix_index, sizeof(int) * m->N);
   }
   if (m->has_nfw) {
+    // [h(X) node table | neutral blocks | H(s) cubics]: the layout gl_clusterw_kernel addresses (CW_NEUTRAL_OFF, CW_TABS_OFF)
     std::vector<float> tab;
     glh::build_nfw_table([](double X, double& g, double& gp) { glp::nfw_gw<double>(X, g, gp); }, tab);
     // behind the table: the constant blocks of an unused component slot of gl_clusterw_kernel (zero amplitude, all else finite)

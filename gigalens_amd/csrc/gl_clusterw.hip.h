@@ -116,31 +116,91 @@ __device__ __forceinline__ void nfw_fwd_s(P d, const float* __restrict__ s_tab, 
   by -= a * dy;
 }
 
-template <int MODE, int HPW, int SPW, bool ELL, int WAVES>
-__global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int n_h, int n_s) {
+// ---- lens policies: what a wave does in the two lens phases of a step -----------------------------------------------------------
+// init (before the first barrier of the kernel), fwd (adds MINUS this wave's share of the deflection of the pixel pair), vjp (with
+// the cotangent of alpha = -d loglike / d beta, summed over the waves), finish (parks the wave's sums in the workgroup's row or in
+// the 16-float scratch), finish2 (after a barrier: sums that need all four waves).
+
+// N x NFW halos (BASELINE configs 4 / 5): halo h = wave + 4 i, constants through scalar loads from neutral-padded slots
+template <int HPW> struct CwLensNfw {
+  using V = v2f;
+  static constexpr int kLdsFloats = 4 * NFWS_N;  // the cubics of H(s), coefficient planes
+  static constexpr int NFWP = (NFW_ND + 3) & ~3;
+  cw_gptr pH[HPW];
+  NfwStateC<V> hst[HPW];
+  V acc[HPW][NFW_NACC];
+  const float* s_tab;
+  __device__ __forceinline__ void init(const MainArgs& a, float* lds, int tid, int wave, int b, int n_lens, const float* gder) {
+    s_tab = lds;
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.nfw_tab + CW_TABS_OFF);  // (16-byte aligned: CW_TABS_OFF % 4 == 0)
+    for (int i = tid; i < NFWS_N; i += WG) reinterpret_cast<float4*>(lds)[i] = src[i];
+    const float* neutral = a.neutral;
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+      pH[i] = (cw_gptr)(wave + 4 * i < n_lens ? gder + NFWP * (wave + 4 * i) : neutral);
+#pragma unroll
+      for (int k = 0; k < NFW_NACC; ++k) acc[i][k] = V(0.f);
+    }
+  }
+  __device__ __forceinline__ void fwd(V x, V y, V& pax, V& pay) {
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+      nfw_fwd_s<cw_gptr>(cw_launder(pH[i]), s_tab, x, y, pax, pay, hst[i]);
+      CW_FENCE();
+    }
+  }
+  __device__ __forceinline__ void vjp(V x, V y, V gx, V gy) {
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+      V va[NFW_NACC];
+      nfw_vjp_c<V, cw_gptr>(cw_launder(pH[i]), x, y, gx, gy, hst[i], va);
+#pragma unroll
+      for (int k = 0; k < NFW_NACC; ++k) acc[i][k] += va[k];
+      CW_FENCE();
+    }
+  }
+  __device__ __forceinline__ void finish(const MainArgs&, float* s_row, float*, int wave, bool last, int n_lens) {
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+      const int h = wave + 4 * i;
+#pragma unroll
+      for (int k = 0; k < NFW_NACC; ++k) {
+        const float v = wave_sum63(acc[i][k].x + acc[i][k].y);
+        if (last && h < n_lens) s_row[NSTAT + NFW_NACC * h + k] = v;
+      }
+    }
+  }
+  __device__ __forceinline__ void finish2(float*, const float*, int) {}
+};
+
+// (Round 4 also built a policy for the cluster-lens workload C6 -- free-standing dPIE halos + one galaxy catalogue with its 200
+// members dealt over the four waves, tangents contracted per wave -- and measured it SLOWER than the interpreter: 4.54 vs 4.31 ms
+// per 128 samples.  The member loop is 143 vector instructions per member and pixel pair in both kernels = 89 % of the
+// interpreter's 16 100 instructions per pixel, so serving the 20 sources efficiently can save 6 % at most, and the interpreter
+// runs that loop at four waves per SIMD (120 VGPRs, VALU busy 0.90) where this kernel's per-wave accumulators leave two.)
+
+template <int MODE, class LENS, int SPW, bool ELL, int WAVES>
+__global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int n_lens, int n_s) {
   static_assert(MODE == IMG_BWD || MODE == LL_GRAD, "gradient modes only (forward modes: gl_main_kernel)");
   using V = v2f;
-  constexpr int SERP = (SER_NDX + 3) & ~3, NFWP = (NFW_ND + 3) & ~3;
+  constexpr int NFWP = (NFW_ND + 3) & ~3;
   constexpr int NSA = ELL ? SER_NACC : S5_N;  // sums per source
   extern __shared__ float smem[];
   float4* s_xa = reinterpret_cast<float4*>(smem);  // [4][64]: -(sum of this wave's alpha) of the lane's pixel pair (x0, x1, y0, y1)
   float4* s_xg = s_xa + 4 * 64;                    // [4][64]: this wave's part of d loglike / d beta
   float2* s_xm = reinterpret_cast<float2*>(s_xg + 4 * 64);  // [4][64]: this wave's part of the model image
-  float* s_tab = reinterpret_cast<float*>(s_xm + 4 * 64);  // [4][NFWS_N]: the cubics of H(s), coefficient planes
-  float* s_row = s_tab + 4 * NFWS_N;                        // [A]: the workgroup's accumulator row (epilogue)
+  float* s_lens = reinterpret_cast<float*>(s_xm + 4 * 64);  // the lens policy's tables
+  float* s_aux = s_lens + LENS::kLdsFloats;                  // [16]: sums that need all four waves
+  float* s_row = s_aux + 16;                                  // [A]: the workgroup's accumulator row (epilogue)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = a.order ? a.order[blockIdx.y] : blockIdx.y, chunk = blockIdx.x;
-  {
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.nfw_tab + CW_TABS_OFF);  // (16-byte aligned: CW_TABS_OFF % 4 == 0)
-    for (int i = tid; i < NFWS_N; i += WG) reinterpret_cast<float4*>(s_tab)[i] = src[i];
-  }
-  for (int i = tid; i < a.A; i += WG) s_row[i] = 0.f;
-  __syncthreads();
   // this sample's derived constants: wave-uniform addresses -> scalar loads
   const float* __restrict__ gder = a.derived + (size_t)b * a.D;
-  const float* __restrict__ dH = gder;
-  const float* __restrict__ dS = gder + NFWP * n_h;
+  LENS lens;
+  lens.init(a, s_lens, tid, wave, b, n_lens, gder);
+  for (int i = tid; i < a.A; i += WG) s_row[i] = 0.f;
+  __syncthreads();
   // A slot beyond the model's counts points at a neutral block (zero amplitude; behind the NFW table): it adds exact zeros to
   // the deflection, the image and the cotangent of beta, and its own sums are never written -- the pixel loop carries no count
   // guards.  The pointers are laundered per step: left alone the compiler hoists all 48 constants out of the loop and spills
@@ -150,17 +210,17 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
   // buffers in turn, the load of source j + 1 in flight under source j's arithmetic (0.959 ms: the scalar round trips were not
   // what the waves wait for); the next step's grid / observation lines pulled into L1 a phase ahead (0.986 ms); wave-uniform
   // count guards instead of neutral blocks (1.05 ms).
-  const float* neutral = a.nfw_tab + CW_NEUTRAL_OFF;  // [NFW block (4) | Sersic block (16)]
-  cw_gptr pH[HPW], pS[SPW];
+  const float* neutral = a.neutral;  // [NFW block (4) | Sersic block (16)]
+  cw_gptr pS[SPW];
+  int aS[SPW];  // accumulator slot of source wave + 4 j inside the row (-1: no such source)
 #pragma unroll
-  for (int i = 0; i < HPW; ++i) pH[i] = (cw_gptr)(wave + 4 * i < n_h ? dH + NFWP * (wave + 4 * i) : neutral);
-#pragma unroll
-  for (int j = 0; j < SPW; ++j) pS[j] = (cw_gptr)(wave + 4 * j < n_s ? dS + SERP * (wave + 4 * j) : neutral + NFWP);
-  V accH[HPW][NFW_NACC], accS[SPW][NSA];
-#pragma unroll
-  for (int i = 0; i < HPW; ++i)
-#pragma unroll
-    for (int k = 0; k < NFW_NACC; ++k) accH[i][k] = V(0.f);
+  for (int j = 0; j < SPW; ++j) {
+    const bool on = wave + 4 * j < n_s;
+    const CompDesc cd = a.comps[n_lens + (on ? wave + 4 * j : 0)];
+    pS[j] = (cw_gptr)(on ? gder + cd.d_off : neutral + NFWP);
+    aS[j] = on ? cd.a_off : -1;
+  }
+  V accS[SPW][NSA];
 #pragma unroll
   for (int j = 0; j < SPW; ++j)
 #pragma unroll
@@ -187,21 +247,13 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
     const V x = V{ldf(a.gx, jo0), ldf(a.gx, jo1)}, y = V{ldf(a.gy, jo0), ldf(a.gy, jo1)};
     V vmask = V(1.f);
     if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
-    using PH = cw_gptr;
     using PS = cw_gptr;
-    cw_gptr cH[HPW], cS[SPW];
-#pragma unroll
-    for (int i = 0; i < HPW; ++i) cH[i] = cw_launder(pH[i]);
+    cw_gptr cS[SPW];
 #pragma unroll
     for (int j = 0; j < SPW; ++j) cS[j] = cw_launder(pS[j]);
-    // ---- ray-shoot: this wave's halos (tf/simulator.py:72-78) ----
-    NfwStateC<V> hst[HPW];
+    // ---- ray-shoot: this wave's lenses (tf/simulator.py:72-78) ----
     V pax = V(0.f), pay = V(0.f);  // -(sum of this wave's alpha)
-#pragma unroll
-    for (int i = 0; i < HPW; ++i) {
-      nfw_fwd_s<PH>(cH[i], s_tab, x, y, pax, pay, hst[i]);
-      CW_FENCE();
-    }
+    lens.fwd(x, y, pax, pay);
     s_xa[my] = float4{pax.x, pax.y, pay.x, pay.y};
     __syncthreads();
     V bx = x, by = y;
@@ -292,19 +344,12 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
       tgx += V{t.x, t.y};
       tgy += V{t.z, t.w};
     }
-    // ---- halo VJPs with the cotangent -g_beta (beta = x - sum alpha) ----
+    // ---- lens VJPs with the cotangent -g_beta (beta = x - sum alpha) ----
     tgx = -tgx;
     tgy = -tgy;
     // the grid coordinates are read again (L1 hits) instead of holding four registers through the source phases
     const V xh = V{ldf(a.gx, jo0), ldf(a.gx, jo1)}, yh = V{ldf(a.gy, jo0), ldf(a.gy, jo1)};
-#pragma unroll
-    for (int i = 0; i < HPW; ++i) {
-      V va[NFW_NACC];
-      nfw_vjp_c<V, PH>(cH[i], xh, yh, tgx, tgy, hst[i], va);
-#pragma unroll
-      for (int k = 0; k < NFW_NACC; ++k) accH[i][k] += va[k];
-      CW_FENCE();
-    }
+    lens.vjp(xh, yh, tgx, tgy);
   };
   {
     const bool plain = !has_mask && !has_pix;
@@ -315,19 +360,9 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
   }
   // ---- epilogue: one wave reduction per sum; lane 63 parks it in the workgroup's row (every slot has one owner) ----
   const bool last = lane == 63;
-#pragma unroll
-  for (int i = 0; i < HPW; ++i) {
-    const int h = wave + 4 * i;
-#pragma unroll
-    for (int k = 0; k < NFW_NACC; ++k) {
-      const float v = wave_sum63(accH[i][k].x + accH[i][k].y);
-      if (last && h < n_h) s_row[NSTAT + NFW_NACC * h + k] = v;
-    }
-  }
-  const int aS = NSTAT + NFW_NACC * n_h;
+  lens.finish(a, s_row, s_aux, wave, last, n_lens);
 #pragma unroll
   for (int j = 0; j < SPW; ++j) {
-    const int s = wave + 4 * j;
 #pragma unroll
     for (int k = 0; k < NSA; ++k) {
       float v = wave_sum63(accS[j][k].x + accS[j][k].y);
@@ -338,7 +373,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
         constexpr int map[S5_N] = {SERA_CX, SERA_CY, SERA_L, SERA_INVN, SERA_IE};  // where the raw sums (Sx, Sy, A, D, B) are parked
         slot = map[k];
       }
-      if (last && s < n_s) s_row[aS + SER_NACC * s + slot] = v;
+      if (last && aS[j] >= 0) s_row[aS[j] + slot] = v;
     }
   }
   if (MODE == LL_GRAD && wave == 0) {
@@ -346,15 +381,21 @@ __global__ void __launch_bounds__(WG, WAVES) gl_clusterw_kernel(MainArgs a, int 
     if (last) { s_row[0] = c2; s_row[1] = nm; }
   }
   __syncthreads();
-  float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
-  for (int k = tid; k < a.A; k += WG) {
-    if (ELL || k < aS) { out[k] = s_row[k]; continue; }
-    // spherical sources: the row holds RAW sums (sersic_vjp5_c); each source's five sums -> its accumulator slots
-    const int sidx = (k - aS) / SER_NACC, kk = (k - aS) % SER_NACC;
-    const float* r = s_row + aS + SER_NACC * sidx;
-    const float raw[S5_N] = {r[SERA_CX], r[SERA_CY], r[SERA_L], r[SERA_INVN], r[SERA_IE]};
-    out[k] = cluster_sersic5_finish(dS + SERP * sidx, raw, kk);
+  lens.finish2(s_row, s_aux, tid);
+  if constexpr (!ELL) {
+    // spherical sources: the row holds RAW sums (sersic_vjp5_c); each source's five sums -> its accumulator slots, in place
+    // (one thread per source: reads its five raw sums, writes its eight slots)
+    for (int s = tid; s < n_s; s += WG) {
+      const CompDesc cd = a.comps[n_lens + s];
+      float* r = s_row + cd.a_off;
+      const float raw[S5_N] = {r[SERA_CX], r[SERA_CY], r[SERA_L], r[SERA_INVN], r[SERA_IE]};
+#pragma unroll
+      for (int kk = 0; kk < SER_NACC; ++kk) r[kk] = cluster_sersic5_finish(gder + cd.d_off, raw, kk);
+    }
   }
+  __syncthreads();
+  float* out = a.partial + ((size_t)b * gridDim.x + chunk) * a.A;
+  for (int k = tid; k < a.A; k += WG) out[k] = s_row[k];
 }
 
 }  // namespace glk

@@ -104,6 +104,7 @@ struct MainArgs {
   int n_lin;         // IMG_BASIS: channels of the stack  img[B][n_lin][img_stride]
   const SeriesDev* series;
   const float* nfw_tab;  // models with NFW lenses: the shared h(X) table (gl_host_tables.h), [kNfwNodes][2]; else null
+  const float* neutral;  // gl_clusterw_kernel: constant blocks of an unused component slot, [NFW (4) | Sersic (16)]; else null
   int dbg;  // -DGL_EXPERIMENTS builds only (GIGALENS_HIP_DBGFLAGS): 1 skip the pixel tiles, 2 skip the epilogue reductions, 4 skip the constant staging
 };
 

@@ -41,19 +41,19 @@ int launch_generic(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     done = true;
   }
   if constexpr (MODE == IMG_BWD || MODE == LL_GRAD) {
-    if (!done && m->cluster && m->cluster_w && a.parts == 7u) {  // ... with the components dealt over the four waves (gl_clusterw.hip.h)
-      const size_t sh = sizeof(float) * (CW_XCHG_FLOATS + 4 * NFWS_N + m->A);
-#define GL_CLUSTERW(HPW_, SPW_, E_, W_)                                                                  \
+#define GL_CLUSTERW(LENS_, SPW_, E_, W_)                                                                 \
   do {                                                                                                 \
-    m->last_main_fn = (const void*)&gl_clusterw_kernel<MODE, HPW_, SPW_, E_, W_>;                        \
-    hipExtLaunchKernelGGL((gl_clusterw_kernel<MODE, HPW_, SPW_, E_, W_>), grid, block, (std::uint32_t)(sh), stream, ev0, ev1, 0, a, m->n_lens, m->n_src); \
+    const size_t sh = sizeof(float) * (CW_XCHG_FLOATS + LENS_::kLdsFloats + 16 + m->A);                \
+    m->last_main_fn = (const void*)&gl_clusterw_kernel<MODE, LENS_, SPW_, E_, W_>;                       \
+    hipExtLaunchKernelGGL((gl_clusterw_kernel<MODE, LENS_, SPW_, E_, W_>), grid, block, (std::uint32_t)(sh), stream, ev0, ev1, 0, a, m->n_lens, m->n_src); \
   } while (0)
+    if (!done && m->cluster && m->cluster_w && a.parts == 7u) {  // ... with the components dealt over the four waves (gl_clusterw.hip.h)
       const int size = (m->n_lens <= 4 && m->n_src <= 8) ? 0 : (m->n_src <= 12 ? 1 : 2);
-      if (m->cluster == 2) { if (size == 0) GL_CLUSTERW(1, 2, true, 4); else if (size == 1) GL_CLUSTERW(2, 3, true, 3); else GL_CLUSTERW(2, 5, true, 2); }
-      else { if (size == 0) GL_CLUSTERW(1, 2, false, 4); else if (size == 1) GL_CLUSTERW(2, 3, false, 4); else GL_CLUSTERW(2, 5, false, 3); }
-#undef GL_CLUSTERW
+      if (m->cluster == 2) { if (size == 0) GL_CLUSTERW(CwLensNfw<1>, 2, true, 4); else if (size == 1) GL_CLUSTERW(CwLensNfw<2>, 3, true, 3); else GL_CLUSTERW(CwLensNfw<2>, 5, true, 2); }
+      else { if (size == 0) GL_CLUSTERW(CwLensNfw<1>, 2, false, 4); else if (size == 1) GL_CLUSTERW(CwLensNfw<2>, 3, false, 4); else GL_CLUSTERW(CwLensNfw<2>, 5, false, 3); }
       done = true;
     }
+#undef GL_CLUSTERW
     if (!done && m->cluster && a.parts == 7u) {  // N x same-kind cluster model: forward state of every component kept in registers
       const size_t sh = (size_t)64 * m->Apad * sizeof(float) + sizeof(float) * 2 * NFW_TAB_NODES;  // gradient columns + the h(X) table
 #define GL_CLUSTER(NH_, NS_, E_, W_)                                                                     \

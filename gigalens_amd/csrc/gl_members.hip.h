@@ -80,8 +80,10 @@ template <class V> __device__ __forceinline__ V vatan2(V y, V x) {
 template <class V> struct ScaleTan { V tx, ty, cx, cy, ux, uy; };
 
 // ---- dPIE member (piemd.py:201-255; same maths as piemd_fwd / piemd_vjp in gl_dpie.h) -----------------------------
-template <class V, bool GRAD>
-__device__ __forceinline__ void piemd_member_v(const float* __restrict__ gs, const float* __restrict__ gm, V x, V y,
+// (P: the pointer type of the two constant blocks -- plain, or address space 4 where the caller's kernel holds an opaque asm, next
+// to which only constant-address-space loads stay scalar: gl_clusterw.hip.h)
+template <class V, bool GRAD, class P = const float*>
+__device__ __forceinline__ void piemd_member_v(P gs, P gm, V x, V y,
                                                V& bx, V& by, ScaleTan<V>& tn) {
   const float c = gs[DPS_CPHI], s = gs[DPS_SPHI], s2 = gs[DPS_S2];
   const V dx = x - gs[DPS_CX], dy = y - gs[DPS_CY];
@@ -133,8 +135,8 @@ __device__ __forceinline__ void piemd_member_v(const float* __restrict__ gs, con
 }
 
 // ---- dPIS / dPIEP member (piemd.py:33-49, piep.py:31-43): alpha' = S h (x' m1, y' p1), h = 1/(Wc+rc) - 1/(Wt+rt) ----
-template <class V, bool GRAD>
-__device__ __forceinline__ void piep_member_v(const float* __restrict__ gs, const float* __restrict__ gm, V x, V y,
+template <class V, bool GRAD, class P = const float*>
+__device__ __forceinline__ void piep_member_v(P gs, P gm, V x, V y,
                                               V& bx, V& by, ScaleTan<V>& tn) {
   const float c = gs[DPS_CPHI], s = gs[DPS_SPHI];
   const V dx = x - gs[DPS_CX], dy = y - gs[DPS_CY];

@@ -20,8 +20,8 @@ DISPATCHED = {
     "C1 SIE | Sersic": [f"gl_pair_kernel<{m}, {V2}, {w}, {SIE}, {NONE}, {SERSIC} >" for m, w in ((0, 4), (1, 3), (2, 4), (3, 3))],
     "C2 EPL+Shear | Sersic": [f"gl_pair_kernel<{m}, {V2}, {w}, {EPLSHEAR}, {NONE}, {SERSIC} >" for m, w in ((0, 4), (1, 3), (2, 4), (3, 3))],
     "C3 EPL+Shear | Shapelets": [f"gl_shp_kernel<{m}, 2, {EPLSHEAR}, {NONE}, 6, true, false>" for m in (0, 1, 2, 3)],  # table mode (the default), whole tiles
-    "C4 / C5 8 NFW | 20 Sersic": ["gl_main_kernel<0, 4, false, 0, false>", "gl_clusterw_kernel<1, 2, 5, false, 3>",
-                                  "gl_main_kernel<2, 4, false, 0, false>", "gl_clusterw_kernel<3, 2, 5, false, 3>"],
+    "C4 / C5 8 NFW | 20 Sersic": ["gl_main_kernel<0, 4, false, 0, false>", "gl_clusterw_kernel<1, glk::CwLensNfw<2>, 5, false, 3>",
+                                  "gl_main_kernel<2, 4, false, 0, false>", "gl_clusterw_kernel<3, glk::CwLensNfw<2>, 5, false, 3>"],
 }
 
 

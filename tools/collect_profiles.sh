@@ -40,6 +40,7 @@ for G in "sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_C3_$N -- python3 $R/tools/prof_kernel.py --workload C3 --iters 6 > $OUT/pmc_C3_$N.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_C3direct -- python3 $R/tools/prof_kernel.py --workload C3 --direct --iters 6 > $OUT/pmc_C3direct.log 2>&1
+python3 $R/tools/dev/grad_error_distribution.py --n 256 > $OUT/grad_error_distribution.jsonl 2> $OUT/grad_error_distribution.err
 python3 $R/tools/dev/grad_accuracy_scan.py --n 8 > $OUT/grad_accuracy.jsonl 2> $OUT/grad_accuracy.err
 python3 $R/tools/dev/grad_accuracy_scan.py --configs cases > $OUT/grad_accuracy_cases.jsonl 2>> $OUT/grad_accuracy.err
 python3 -m pytest $R/tests/test_gpu_dist.py -m gpu -q > $OUT/two_rank_test.log 2>&1
@@ -50,4 +51,8 @@ python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 $R/bench.py --no-cpu-baseline --mode svi > $OUT/bench_svi.json 2> $OUT/bench_svi.err
 python3 $R/bench.py --no-cpu-baseline --workload C5 --steps 200 --warmup 20 > $OUT/bench_C5.json 2> $OUT/bench_C5.err
 python3 $R/bench.py --no-cpu-baseline --workload C5 --mode svi --steps 200 --warmup 20 > $OUT/bench_C5_svi.json 2> $OUT/bench_C5_svi.err
+# round 4: the N > 1 line (C2 value, svi_step, BASELINE configs[4] in `configs`) rehearsed with two gloo ranks sharing this GPU
+GIGALENS_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err
+# the cluster kernel's issue / wait / LDS counters (tools/pmc_kernel.sh: four passes)
+bash $R/tools/pmc_kernel.sh ${TAG}_C4 C4 > $OUT/pmc_kernel_C4.log 2>&1
 tail -1 $OUT/bench.json

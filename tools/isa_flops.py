@@ -419,6 +419,25 @@ def execution_model(co, name, md, series, p_live=None):
         if per_pixel["mfma"]:  # exact-fp32 16x16x4 MFMA: 2 * 16 * 16 * 4 flops per wave-instruction = 32 per lane
             out["mfma_flops_per_pixel"] = round(per_pixel["mfma"] * 32, 2)
         return out
+    mi = re.search(r"gl_main_kernel<([13]), 2, (true|false), 1, false>", name)
+    if mi and (series or {}).get("n_members"):
+        # The interpreter on a model with a galaxy catalogue: the catalogue's member loop -- the innermost
+        # single-block loop that loads a member's two constant blocks through scalar loads and carries the tangents (the largest
+        # such loop of the gradient kernel: piemd_member_v<v2f, true>, csrc/gl_members.hip.h) -- runs n_members times per pixel
+        # pair.  Only that loop is modelled: its share of the launch is what SQ_INSTS_VALU says the rest is (profiles/
+        # r4_summary.json::pmc_C6: 16 100 instructions per pixel counted, 14 300 of them this loop at 200 members).
+        cfg = CFG(disassemble(md["co"], md["symbol"]))
+        loops = [l for l in cfg.loops if not l.children and len(l.blocks) == 1 and cfg.tally(l.blocks)["smem"] >= 4]
+        if not loops:
+            return None
+        body = max((cfg.tally(l.blocks) for l in loops), key=lambda t: t["valu"])
+        n = float(series["n_members"])
+        return dict(flops_per_pixel=round(body["flops"] * n / 2, 1), valu_insts_per_pixel=round(body["valu"] * n / 2, 1),
+                    trans_per_pixel=round(body["trans"] * n / 2, 1), packed_insts_per_pixel=round(body["packed"] * n / 2, 1),
+                    flop_weights=weights,
+                    model=dict(what="catalogue member loop only (the other components are not modelled)", members=n,
+                               member_loop_valu_per_member_and_pixel_pair=body["valu"],
+                               member_loop_trans_per_member_and_pixel_pair=body["trans"]))
     m = re.search(r"gl_pair_kernel<(\d+), (float __vector\(2\)|float),", name)
     W = None
     if m:
