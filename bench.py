@@ -299,11 +299,15 @@ def roofline_of(model, wl, sim, x, kernel_ms, ms_per_step, err, stride):
         symbol = model.last_main_kernel()
     except Exception:  # evidence only: a model whose kernel has no name to report still gets its line
         symbol = ""
-    if "gl_shp_kernel" in symbol:  # the share of wave-tiles that ran the shapelet chains, counted by the kernel itself
+    if "gl_shp_kernel" in symbol:
+        # rounds of the shapelet chains per wave-tile, counted by the kernel itself (table mode compacts a wave-tile's live pixels
+        # and runs ceil(live / 64) rounds of one chain per lane: 0, 1 or 2; direct mode always 2) -- as a share of the two chains
+        # per lane a tile without compaction runs, which is how the ISA model weights the chain blocks
         rows = model.partial_rows(B)
         seen = float(rows[:, :, 3].sum())
-        p_live = float(rows[:, :, 2].sum()) / seen if seen > 0 else 1.0
+        p_live = 0.5 * float(rows[:, :, 2].sum()) / seen if seen > 0 else 1.0
         roof["shapelet_live_wave_tile_share"] = round(p_live, 4)
+        roof["shapelet_chain_rounds_per_wave_tile"] = round(2.0 * p_live, 4)
     n_members = sum(int(getattr(l, "n_galaxy", 0)) for l in wl.phys_model.lenses)  # galaxy catalogues (ScalingRelation / DPIESubhalo)
     try:
         # (the steady-state tile of the likelihood kernels is compiled once per variance model: tell the ISA model which ran)

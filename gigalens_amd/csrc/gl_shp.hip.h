@@ -29,7 +29,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // dwords per order-pair plane of a wave's exchange buffer: 128 pixels (two per lane) x 2 + 4 pad: stride = 4 (mod 32 banks)
 constexpr int SHX_PLANE = 128 * 2 + 4;
-__host__ __device__ constexpr int shp_exchange_floats(int np) { return 2 /*X, Y*/ * np * SHX_PLANE + 128 /*gS*/; }  // per wave
+// per wave: the order planes, gS of the 128 slots, and the compaction buffers of table mode -- (u, v) of the live pixels in rank
+// order [128][2] and their (S, dS/du, dS/dv, -) on the way back [128][4]
+constexpr int SHX_GS = 128, SHX_CIN = 256, SHX_COUT = 512;
+__host__ __device__ constexpr int shp_exchange_floats(int np) { return 2 /*X, Y*/ * np * SHX_PLANE + SHX_GS + SHX_CIN + SHX_COUT; }
 __host__ __device__ constexpr size_t shp_exchange_bytes(int np) { return (size_t)4 /*waves*/ * shp_exchange_floats(np) * sizeof(float); }
 
 template <int NP> struct ShpPix { float S, Su, Sv, u, v, dx, dy, fac; };  // what a pixel's VJP needs of its forward pass
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
   const int mm = min(lane & 15, 2 * NP - 1);
   const float* rd_gx = xw + mm * SHX_PLANE + 2 * (lane >> 4);
   const float* rd_y = rd_gx + 1;
-  float* wr_gs = xw + 2 * NP * SHX_PLANE + lane;            // gS of pixel slot w at 64 w + lane
+  float* wr_gs0 = xw + 2 * NP * SHX_PLANE;                  // gS of the pixel with rank k at slot k (direct mode: 64 w + lane)
   const float* rd_gs = xw + 2 * NP * SHX_PLANE + (lane >> 4);  // pixel 4 kb + k of the operand lane (m, k)
 
   const int p0 = chunk * a.chunk;
@@ -269,16 +272,59 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     shp_pixel_coords<NP>(dS, bx.x, by.x, ps0);
     shp_pixel_coords<NP>(dS, bx.y, by.y, ps1);
     // Table mode: a pixel whose u OR v lies outside the table's support renders exactly zero with zero slopes (fill 0 / 0,
-    // shapelets.py:58-60), so a wave none of whose 128 pixels is inside skips the gathers, both chains, the LDS traffic and
-    // the MFMAs -- on a lensed field that is every tile away from the arcs (wave-uniform branch; the values are the same zeros).
+    // shapelets.py:58-60).  Round 3 skipped the wave-tiles none of whose 128 pixels is inside (54 % on the C3 prior) and ran both
+    // chains of every lane on the others -- but on a lensed field the support is a band along the arcs, and a live wave-tile
+    // typically holds 30-60 live pixels of 128.  Round 4 COMPACTS them: every live pixel takes its rank in the wave (ballot +
+    // mbcnt), its (u, v) goes to the rank's slot of a wave-private LDS list, and the chains run on the list -- lane i of round r
+    // takes entry 64 r + i -- in ceil(count / 64) rounds (0, 1 or 2, wave-uniform) instead of always two; the order planes are
+    // parked by RANK, so the matrix-pipe pass walks 16 pixel groups per round instead of 32 per tile; (S, dS/du, dS/dv) travel
+    // back to the owning lane through the list.  Entries beyond the count run the chain outside the table (all zeros).
     bool shp_live = true;
+    int rounds = 2, r0 = lane, r1 = 64 + lane;  // direct mode: every pixel is live, slot w of lane l has rank 64 w + l
+    bool in0 = true, in1 = true;
     ++n_tiles;
     if constexpr (INTERP) {
-      const bool inr = (shp_in_table(ps0.u) && shp_in_table(ps0.v)) || (shp_in_table(ps1.u) && shp_in_table(ps1.v));
-      shp_live = __builtin_amdgcn_ballot_w64(inr) != 0;
-    }
-    if (shp_live) {
-      ++n_live;
+      in0 = shp_in_table(ps0.u) && shp_in_table(ps0.v);
+      in1 = shp_in_table(ps1.u) && shp_in_table(ps1.v);
+      const unsigned long long m0 = __builtin_amdgcn_ballot_w64(in0), m1 = __builtin_amdgcn_ballot_w64(in1);
+      const int c0 = __builtin_popcountll(m0), count = c0 + __builtin_popcountll(m1);
+      r0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+      r1 = c0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+      rounds = (count + 63) >> 6;
+      shp_live = count != 0;
+      ps0.S = ps0.Su = ps0.Sv = 0.f; ps0.fac = 1.f;
+      ps1.S = ps1.Su = ps1.Sv = 0.f; ps1.fac = 1.f;
+      if (shp_live) {
+        float2* cin = reinterpret_cast<float2*>(xw + 2 * NP * SHX_PLANE + SHX_GS);
+        float4* cout = reinterpret_cast<float4*>(xw + 2 * NP * SHX_PLANE + SHX_GS + SHX_CIN);
+        float* gs_all = xw + 2 * NP * SHX_PLANE;
+        if (in0) cin[r0] = float2{ps0.u, ps0.v};
+        if (in1) cin[r1] = float2{ps1.u, ps1.v};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+          const int idx = 64 * r + lane;
+          const float2 uv = cin[idx];
+          ShpPix<NP> pc;
+          pc.u = idx < count ? uv.x : 100.f;  // (beyond the count: stale list entries -- outside the table instead)
+          pc.v = idx < count ? uv.y : 100.f;
+          pc.Su = pc.Sv = 0.f;
+          (void)shp_pixel_fwd<NP, true, GRAD>(dS, gA, xw + 2 * idx, pc);
+          cout[idx] = float4{pc.S, pc.Su, pc.Sv, 0.f};
+          if constexpr (GRAD) gs_all[idx] = 0.f;  // a slot without an owner multiplies its planes by zero in the matrix-pipe pass
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (in0) { const float4 q = cout[r0]; ps0.S = q.x; ps0.Su = q.y; ps0.Sv = q.z; }
+        if (in1) { const float4 q = cout[r1]; ps1.S = q.x; ps1.Su = q.y; ps1.Sv = q.z; }
+        m += V{ps0.S, ps1.S};
+      }
+      n_live += rounds;
+    } else {
+      n_live += 2;
       const float l0 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, wr_xy, ps0);
       const float l1 = shp_pixel_fwd<NP, INTERP, GRAD>(dS, gA, wr_xy + 128, ps1);
       m += V{l0, l1};
@@ -338,8 +384,9 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
         const V pdx = bx - dS[SHP_CX], pdy = by - dS[SHP_CY];
         const V fac = INTERP ? V(1.f) : V{ps0.fac, ps1.fac};
         const V gS = INTERP ? gm : gm * fac;
-        wr_gs[0] = gS.x;   // the pixel's cotangent of S: applied to the Y operand after the transposed read
-        wr_gs[64] = gS.y;
+        // the pixel's cotangent of S, at its RANK's slot: applied to the Y operand after the transposed read
+        if (in0) wr_gs0[r0] = gS.x;
+        if (in1) wr_gs0[r1] = gS.y;
         const float ds = INTERP ? (float)(SH_NODES - 1) / 10.f : 1.f;  // table mode: the differences are per node spacing
         V gu = gS * (V{ps0.Su, ps1.Su} * ds), gv = gS * (V{ps0.Sv, ps1.Sv} * ds);
         if constexpr (!INTERP) {  // d fac / du = -u fac
@@ -379,23 +426,33 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       // batch's reads are issued ahead of this batch's MFMAs), two accumulator tiles in turn: the chain of dependent MFMAs
       // (40 cycles each) is half as long and no MFMA waits for its own LDS read
       constexpr int MB = 4;  // pixel groups per batch (a batch's 2 MB operand registers are double-buffered)
-      float opa[2][MB], opb[2][MB];
+      auto mfma_groups = [&](const float* gx, const float* gy, const float* gg, auto n_batches) {
+        constexpr int NB = decltype(n_batches)::value;
+        float opa[2][MB], opb[2][MB];
 #pragma unroll
-      for (int i = 0; i < MB; ++i) { opa[0][i] = rd_gx[8 * i]; opb[0][i] = rd_y[8 * i] * rd_gs[4 * i]; }
+        for (int i = 0; i < MB; ++i) { opa[0][i] = gx[8 * i]; opb[0][i] = gy[8 * i] * gg[4 * i]; }
 #pragma unroll
-      for (int bt = 0; bt < 32 / MB; ++bt) {
-        if (bt + 1 < 32 / MB) {
+        for (int bt = 0; bt < NB; ++bt) {
+          if (bt + 1 < NB) {
 #pragma unroll
-          for (int i = 0; i < MB; ++i) {
-            opa[(bt + 1) & 1][i] = rd_gx[8 * (MB * (bt + 1) + i)];
-            opb[(bt + 1) & 1][i] = rd_y[8 * (MB * (bt + 1) + i)] * rd_gs[4 * (MB * (bt + 1) + i)];
+            for (int i = 0; i < MB; ++i) {
+              opa[(bt + 1) & 1][i] = gx[8 * (MB * (bt + 1) + i)];
+              opb[(bt + 1) & 1][i] = gy[8 * (MB * (bt + 1) + i)] * gg[4 * (MB * (bt + 1) + i)];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < MB; i += 2) {
+            G = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[bt & 1][i], opb[bt & 1][i], G, 0, 0, 0);
+            G2 = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[bt & 1][i + 1], opb[bt & 1][i + 1], G2, 0, 0, 0);
           }
         }
-#pragma unroll
-        for (int i = 0; i < MB; i += 2) {
-          G = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[bt & 1][i], opb[bt & 1][i], G, 0, 0, 0);
-          G2 = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[bt & 1][i + 1], opb[bt & 1][i + 1], G2, 0, 0, 0);
-        }
+      };
+      if constexpr (INTERP) {
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r)  // 16 pixel groups (64 ranked slots) per round of the chains
+          mfma_groups(rd_gx + 128 * r, rd_y + 128 * r, rd_gs + 64 * r, std::integral_constant<int, 16 / MB>{});
+      } else {
+        mfma_groups(rd_gx, rd_y, rd_gs, std::integral_constant<int, 32 / MB>{});  // all 128 slots, one unrolled stream
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's stores stay behind these loads
       __builtin_amdgcn_wave_barrier();
@@ -435,8 +492,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     for (int k = 0; k < NVP; ++k) vals[k] = 0.f;
     vals[0] = (MODE == LL_GRAD) ? hsum(st0) : 0.f;
     vals[1] = (MODE == LL_GRAD) ? hsum(st1) : 0.f;
-    vals[2] = lane == 0 ? (float)n_live : 0.f;   // pad slots of the row (finalize does not read them): how many of the
-    vals[3] = lane == 0 ? (float)n_tiles : 0.f;  // workgroup's wave-tiles ran the shapelet chains -- bench.py's work model
+    vals[2] = lane == 0 ? (float)n_live : 0.f;   // pad slots of the row (finalize does not read them): rounds of the shapelet
+    vals[3] = lane == 0 ? (float)n_tiles : 0.f;  // chains this wave ran (0-2 per tile) and its tiles -- bench.py's work model
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int kind = LK::kinds[i];

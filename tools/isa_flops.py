@@ -329,9 +329,14 @@ def shp_model(cfg, mean_series_pairs, p_live, W=2):
                   conditional=[], p_live=p_live)
     for c in inner:
         t = cfg.tally(c.blocks)
+        # round 4, table mode: the shapelet chains and the matrix-pipe pass run in ROUNDS over the wave-tile's compacted live
+        # pixels (0, 1 or 2 per tile): loops with a large packed body or MFMAs; mean trips = 2 p_live (p_live is handed over as
+        # the share of the two chains per lane a tile would run without compaction).  The other inner loop is the EPL series.
+        rounds_loop = t["mfma"] > 0 or t["packed"] >= 60
+        trips = 2.0 * p_live if rounds_loop else mean_series_pairs
         for k in out:
-            out[k] += t[k] * mean_series_pairs
-        detail["inner"].append(dict(header=hex(c.header), per_trip=t, trips=mean_series_pairs))
+            out[k] += t[k] * trips
+        detail["inner"].append(dict(header=hex(c.header), per_trip=t, trips=trips, what="chain / MFMA rounds" if rounds_loop else "EPL series"))
     for b in sorted(own - mandatory):
         t = cfg.tally([b])
         live = t["packed"] >= 8 or t["mfma"] > 0
