@@ -1176,8 +1176,10 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
     const dim3 grid(lw.n_chunks, B), block(WG);
 #define GL_SHPN(NT_, I_)                                                                                        \
   do {                                                                                                          \
-    m->last_main_fn = (const void*)&gl_shp_normal_kernel<NT_, (I_ ? 4 : 3), L_EplShear, NPS, I_>;                          \
-    hipLaunchKernelGGL((gl_shp_normal_kernel<NT_, (I_ ? 4 : 3), L_EplShear, NPS, I_>), grid, block, sh, stream, fa, sn);  \
+    /* (table mode, five tile rows: 17 spilled VGPRs under the 128-register budget of four waves per SIMD since the live-pixel \
+       list of round 4 -- three waves there) */                                                                  \
+    m->last_main_fn = (const void*)&gl_shp_normal_kernel<NT_, ((I_ && NT_ < 5) ? 4 : 3), L_EplShear, NPS, I_>;              \
+    hipLaunchKernelGGL((gl_shp_normal_kernel<NT_, ((I_ && NT_ < 5) ? 4 : 3), L_EplShear, NPS, I_>), grid, block, sh, stream, fa, sn);  \
   } while (0)
     if (nt == 1) { if (interp) GL_SHPN(1, true); else GL_SHPN(1, false); }
     else if (nt == 2) { if (interp) GL_SHPN(2, true); else GL_SHPN(2, false); }

@@ -571,7 +571,8 @@ struct ShpNormalArgs {
 };
 
 constexpr int SHN_PLANE = 132;  // floats per plane of the normal kernel: 64 pixels x 2 orders, + 4 (plane stride = 4 mod 32 banks)
-__host__ __device__ constexpr int shn_wave_floats(int np) { return (2 * np + 1) * SHN_PLANE; }  // X', Y planes + the (obs w, 1) plane
+constexpr int SHN_LIST = 512;   // table mode: the wave-tile's live pixels in rank order, [128] x (u, v, w, obs w)
+__host__ __device__ constexpr int shn_wave_floats(int np) { return (2 * np + 1) * SHN_PLANE + SHN_LIST; }  // X', Y planes + the (obs w, 1) plane + the list
 
 template <int NT, int WAVES, class LK, int NP, bool INTERP>
 __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, ShpNormalArgs na) {
@@ -655,24 +656,14 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
       else if constexpr (kind == K_SHEAR) shear_fwd_v<V>(dL[i], x, y, bx, by);
       else sis_fwd_v<V>(dL[i], x, y, bx, by);
     }, std::make_integer_sequence<int, NL>{});
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float w1 = h ? wgt.y : wgt.x, ow1 = h ? ow.y : ow.x;
-      ShpPix<NP> ps;
-      shp_pixel_coords<NP>(dS, h ? bx.y : bx.x, h ? by.y : by.x, ps);
-      if constexpr (INTERP) {
-        const bool inr = shp_in_table(ps.u) && shp_in_table(ps.v);
-        if (__builtin_amdgcn_ballot_w64(inr) == 0) {  // every basis image vanishes on these 64 pixels: only Y^T Y grows
-          yy = __builtin_fmaf(ow1, ow1, yy);
-          continue;
-        }
-      }
+    // the bases of 64 pixels -> planes, then the MFMA pass over them: one ROUND
+    auto round_ = [&](float u, float v, float w1, float ow1) {
       {
         constexpr int NO = 2 * NP;
-        const float fac = INTERP ? 1.f : exp_(-(ps.u * ps.u + ps.v * ps.v) * 0.5f);
+        const float fac = INTERP ? 1.f : exp_(-(u * u + v * v) * 0.5f);
         const v2f xs = v2f{w1 * fac, 1.f};  // weight (and the Gaussian of direct mode) folded into the X factor
         ShpGen<INTERP> gen;
-        gen.init(ps.u, ps.v);
+        gen.init(u, v);
 #pragma unroll
         for (int n = 0; n < NO - 1; ++n) {
           v2f xy = gen.value() * (xs * SH_K[n]);  // phi_n = SH_K[n] P_n: the channels of the normal matrix are the normalised bases
@@ -688,17 +679,51 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb) {  // fully unrolled: every LDS offset is an immediate, no address arithmetic beside the MFMAs
-        float v[NT];
+        float v_[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) v[t] = rd_a[t][8 * kb] * rd_b[t][8 * kb];
+        for (int t = 0; t < NT; ++t) v_[t] = rd_a[t][8 * kb] * rd_b[t][8 * kb];
         int q = 0;
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-          for (int tj = 0; tj <= ti; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[ti], v[tj], acc[q], 0, 0, 0);
+          for (int tj = 0; tj <= ti; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(v_[ti], v_[tj], acc[q], 0, 0, 0);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+    };
+    ShpPix<NP> ps0, ps1;
+    shp_pixel_coords<NP>(dS, bx.x, by.x, ps0);
+    shp_pixel_coords<NP>(dS, bx.y, by.y, ps1);
+    if constexpr (INTERP) {
+      // Table mode: a pixel outside the table has every basis image zero -- only Y^T Y grows by its (obs w)^2.  Round 3 decided
+      // that per 64-pixel run; round 4 compacts the wave-tile's LIVE pixels by rank (as gl_shp_kernel does) and runs
+      // ceil(live / 64) rounds of bases + MFMA pass over the list: on a lensed field a live wave-tile holds 30-60 live pixels.
+      const bool in0 = shp_in_table(ps0.u) && shp_in_table(ps0.v), in1 = shp_in_table(ps1.u) && shp_in_table(ps1.v);
+      const unsigned long long m0 = __builtin_amdgcn_ballot_w64(in0), m1 = __builtin_amdgcn_ballot_w64(in1);
+      const int c0 = __builtin_popcountll(m0), count = c0 + __builtin_popcountll(m1);
+      if (!in0) yy = __builtin_fmaf(ow.x, ow.x, yy);
+      if (!in1) yy = __builtin_fmaf(ow.y, ow.y, yy);
+      if (count != 0) {
+        float4* list = reinterpret_cast<float4*>(xw + (2 * NP + 1) * SHN_PLANE);
+        const int r0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+        const int r1 = c0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+        if (in0) list[r0] = float4{ps0.u, ps0.v, wgt.x, ow.x};
+        if (in1) list[r1] = float4{ps1.u, ps1.v, wgt.y, ow.y};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int rounds = (count + 63) >> 6;
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+          const int idx = 64 * r + lane;
+          const float4 e = list[idx];
+          const bool ok = idx < count;  // beyond the count: a stale entry -- outside the table, weight 0
+          round_(ok ? e.x : 100.f, ok ? e.y : 100.f, ok ? e.z : 0.f, ok ? e.w : 0.f);
+        }
+      }
+    } else {
+      round_(ps0.u, ps0.v, wgt.x, ow.x);
+      round_(ps1.u, ps1.v, wgt.y, ow.y);
     }
   }
   // ---- the four waves' tiles summed in fixed order through LDS (aliases the planes), then the lower tiles written ----

@@ -54,15 +54,6 @@ ALLOWED_SPILLS = [
     (r"gl_main_kernel<[13], 2, true, [01], false>", "shapelets through the interpreter, gradient modes (models outside the specialised compositions)"),
     (r"gl_static_kernel<[13], [24], ", "pre-pair tile variants of the specialised kernels in gradient modes: reached only with GIGALENS_HIP_PAIR=0 / GIGALENS_HIP_TILE*"),
     (r"gl_series_hessian_precompute_kernel<", "one-off float64 jet precompute of the Hessian series (not on the per-step path)"),
-    (r"gl_shp_kernel<[13], 2, glk::KindList<1, 4>, glk::KindList<(17)?>, \d, true, true>",
-     "shapelet kernel, table mode, gradient modes, RAGGED instantiation (masks, pixel lists, pixel counts that are not whole "
-     "512-pixel tiles -- no BASELINE config): the ragged-end tile code beside the steady-state body does not fit 256 registers"),
-    (r"gl_shp_kernel<[13], 2, glk::KindList<1, 4>, glk::KindList<17>, \d, true, false>",
-     "shapelet kernel WITH a lens-light component, table mode, gradient modes (the shapelets-demo model, not a BASELINE config): "
-     "16 VGPRs past the 256 of two waves per SIMD; measured 0.286 ms per 1024 at C3D (round-2 kernel: 0.383)"),
-    (r"gl_shp_normal_kernel<5, 4, glk::KindList<1, 4>, 6, true>",
-     "stack-free normal matrix, five tile rows, table mode: held to 128 VGPRs for four workgroups per CU at the price of two "
-     "spilled registers outside the MFMA loop; measured 0.644 ms per 1024 C3L solves against 0.662 at 129 VGPRs / three per CU"),
 ]
 
 
