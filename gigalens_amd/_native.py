@@ -168,7 +168,10 @@ def component_of(profile, bodies=None):
             raise NativeLibraryError(f"profile {profile.name!r}: a user-written profile inside a model takes at most 16 parameters, got {n}")
         if profile.hip_body not in bodies:
             bodies.append(profile.hip_body)
-        return gl_component(20 if isinstance(profile, LightProfile) else 13, n, bodies.index(profile.hip_body), 0)
+        # reserved = 1: the LAST parameter of a user-written light is its linear amplitude (LightProfile._amp, profile.py:24-60) --
+        # the column the linear-amplitude solve sets to 1 for the basis image and writes the solved coefficient into
+        is_light = isinstance(profile, LightProfile)
+        return gl_component(20 if is_light else 13, n, bodies.index(profile.hip_body), 1 if (is_light and getattr(profile, "_amp", "")) else 0)
     if not kind:
         raise NativeLibraryError(
             f"profile {getattr(profile, 'name', type(profile).__name__)!r} has no gl_kind: user-defined deriv / light bodies "

@@ -616,6 +616,8 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
     }
     cd.lin_off = (int)m->lin_cols.size();
     for (int k = 0; k < kind_num_linear(c.kind, iparam); ++k) m->lin_cols.push_back(p_off + kind_linear_col(c.kind, iparam) + k);
+    // a user-written light whose last parameter is declared the linear amplitude (gl_component::reserved): one basis image
+    if (c.kind == GL_USER_LIGHT && c.reserved == 1 && iparam >= 1) m->lin_cols.push_back(p_off + iparam - 1);
     p_off += cd.n_par;
     d_off += (kind_num_derived(c.kind, iparam) + 3) & ~3;
     a_off += cd.n_acc;
@@ -948,9 +950,13 @@ int gl_model_timing_drain(gl_model* m, float* ms, int cap, int* n_out) {
 
 int gl_model_last_main_kernel(const gl_model* m, char* buf, size_t cap) {
   if (!m || !buf || cap == 0) return fail(GL_EINVAL, "bad argument");
-  if (m->last_main_user >= 0) {  // a model with user-written profiles: the run-time compiled interpreter (gl_user.hip)
-    snprintf(buf, cap, "gl_main_kernel<%d, 2, %s, %d> [run-time compiled with the model's user-written profile bodies]", m->last_main_user.load(),
-             m->has_shapelets ? "true" : "false", m->fam);
+  if (m->last_main_user >= 0) {  // a model with user-written profiles: a run-time compiled kernel (gl_user.hip)
+    const int u = m->last_main_user.load();
+    if (u >= 16)
+      snprintf(buf, cap, "gl_pair_kernel<%d, v2f, 2, KindList<the model's own component list>...> [run-time compiled with the model's user-written profile bodies]", u - 16);
+    else
+      snprintf(buf, cap, "gl_main_kernel<%d, 2, %s, %d> [run-time compiled with the model's user-written profile bodies]", u,
+               m->has_shapelets ? "true" : "false", m->fam);
     return GL_OK;
   }
   if (!m->last_main_fn) return fail(GL_EINVAL, "no main kernel has been launched on this model yet");
@@ -1127,7 +1133,7 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
                  float* coeffs_or_null, float* stacked_or_null, float* image_or_null, void* workspace,
                  size_t workspace_bytes, void* hip_stream) {
   if (!m) return fail(GL_EINVAL, "model is null");
-  if (m->has_user) return fail(GL_EUNSUPPORTED, "the linear-amplitude solve is not built for models with user-written profiles");
+  if (m->has_user && !m->user_fn[IMG_BASIS]) return fail(GL_EUNSUPPORTED, "the basis-stack kernel of this model with user-written profiles was not built");
   const int D = (int)m->lin_cols.size();
   if (D == 0) return fail(GL_EINVAL, "the model has no linear (light amplitude) coefficients");
   if (!params || !workspace) return fail(GL_EINVAL, "params / workspace is null");

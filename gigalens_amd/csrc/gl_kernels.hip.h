@@ -946,6 +946,9 @@ __global__ void __launch_bounds__(WG, (SHP || FAM) ? 2 : 4) gl_main_kernel(MainA
             const float px_ = src ? bx[t] : x[t], py_ = src ? by[t] : y[t];
             float v;
             if (XF && cd.kind == K_CORE_SERSIC) v = core_sersic_fwd<float>(d, px_, py_);
+#ifdef GL_HAVE_USER
+            else if (cd.kind == K_USER_LIGHT) v = glu::light_fwd(cd.flags, d, px_, py_);  // (its amplitude column holds 1, like a Sersic's)
+#endif
             else v = sersic_fwd(d, px_, py_);
             if (valid[t]) row[pidx[t]] = isnan_(v) ? 0.f : v;
           }

@@ -31,8 +31,12 @@ int launch_generic(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     MainArgs args = a;
     void* kargs[] = {(void*)&args};
     m->last_main_fn = nullptr;
-    m->last_main_user = MODE;  // gl_model_last_main_kernel names it "gl_main_kernel<MODE, 2, ..., user>" (no host function to look up)
-    GL_HIP(hipExtModuleLaunchKernel(m->user_fn[MODE], grid.x * block.x, grid.y, 1, block.x, 1, 1, (unsigned)shmem, stream, kargs, nullptr, ev0, ev1, 0));
+    // the specialised pair kernel of the model's own composition when gl_user.hip could build it (whole renders only: partial
+    // renders -- `parts` -- are the interpreter's), else the interpreter with the bodies behind its component switch
+    const bool pair = MODE < 4 && m->user_pair_fn[MODE < 4 ? MODE : 0] && a.parts == 7u;
+    m->last_main_user = MODE + (pair ? 16 : 0);  // gl_model_last_main_kernel names it (no host function to look up)
+    GL_HIP(hipExtModuleLaunchKernel(pair ? m->user_pair_fn[MODE < 4 ? MODE : 0] : m->user_fn[MODE], grid.x * block.x, grid.y, 1, block.x, 1, 1,
+                                    (unsigned)shmem, stream, kargs, nullptr, ev0, ev1, 0));
     done = true;
   }
   if (!done && m->shp_big) {  // shapelets above n_max = 10: the runtime-order interpreter variant (basic profile families, T = 2)

@@ -56,6 +56,9 @@ struct gl_model {
   bool has_user = false;
   hipModule_t user_module = nullptr;
   hipFunction_t user_fn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // per Mode (IMG_BASIS: none)
+  // ... and, for the compositions the pair kernel serves (EPL / SIE / Shear / SIS / user lenses | Sersic / user lights), that kernel
+  // specialised on the model's component list with the user bodies inside (gl_pair_kernel<MODE, v2f, 2, KindList<...>, ...>)
+  hipFunction_t user_pair_fn[4] = {nullptr, nullptr, nullptr, nullptr};
   int height = 0, width = 0, supersample = 1, N = 0;
   float conversion_factor = 1.f;
   // device-resident, immutable

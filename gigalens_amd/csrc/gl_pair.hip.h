@@ -16,6 +16,71 @@
 
 namespace glk {
 
+#ifdef GL_HAVE_USER
+// ---- user-written profiles in the pair kernel (run-time compiled: gl_user.hip) --------------------------------------------------
+// The model's bodies sit behind glu::mass_fwd / mass_vjp / light_fwd / light_vjp (a switch on the body index, which is a
+// compile-time constant here: it folds).  A body is scalar code over a number type, so the two pixels of a pair are evaluated one
+// after the other; the VJP comes from the body's forward-mode duals.
+template <class V, int CODE> __device__ __forceinline__ void user_mass_fwd_v(const float* d, V x, V y, V& bx, V& by) {
+  constexpr unsigned body = (unsigned)user_code_body(CODE);
+  if constexpr (sizeof(V) == sizeof(float)) {
+    float ax, ay;
+    glu::mass_fwd(body, d, x, y, ax, ay);
+    bx -= ax; by -= ay;
+  } else {
+    float ax0, ay0, ax1, ay1;
+    glu::mass_fwd(body, d, x.x, y.x, ax0, ay0);
+    glu::mass_fwd(body, d, x.y, y.y, ax1, ay1);
+    bx -= V{ax0, ax1};
+    by -= V{ay0, ay1};
+  }
+}
+template <class V, int CODE> __device__ __forceinline__ void user_mass_vjp_v(const float* d, V x, V y, V gx, V gy, V* acc) {
+  constexpr unsigned body = (unsigned)user_code_body(CODE);
+  constexpr int NPAR = user_code_npar(CODE);
+  float t0[NPAR > 0 ? NPAR : 1], t1[NPAR > 0 ? NPAR : 1];
+#pragma unroll
+  for (int k = 0; k < NPAR; ++k) { t0[k] = 0.f; t1[k] = 0.f; }
+  if constexpr (sizeof(V) == sizeof(float)) {
+    glu::mass_vjp(body, d, x, y, gx, gy, t0);
+#pragma unroll
+    for (int k = 0; k < NPAR; ++k) acc[k] += t0[k];
+  } else {
+    glu::mass_vjp(body, d, x.x, y.x, gx.x, gy.x, t0);
+    glu::mass_vjp(body, d, x.y, y.y, gx.y, gy.y, t1);
+#pragma unroll
+    for (int k = 0; k < NPAR; ++k) acc[k] += V{t0[k], t1[k]};
+  }
+}
+template <class V, int CODE> __device__ __forceinline__ V user_light_fwd_v(const float* d, V x, V y) {
+  constexpr unsigned body = (unsigned)user_code_body(CODE);
+  if constexpr (sizeof(V) == sizeof(float)) return glu::light_fwd(body, d, x, y);
+  else return V{glu::light_fwd(body, d, x.x, y.x), glu::light_fwd(body, d, x.y, y.y)};
+}
+template <class V, int CODE, bool SRC>
+__device__ __forceinline__ void user_light_vjp_v(const float* d, V x, V y, V g, V* acc, V& gpx, V& gpy) {
+  constexpr unsigned body = (unsigned)user_code_body(CODE);
+  constexpr int NPAR = user_code_npar(CODE);
+  float t0[NPAR > 0 ? NPAR : 1], t1[NPAR > 0 ? NPAR : 1];
+#pragma unroll
+  for (int k = 0; k < NPAR; ++k) { t0[k] = 0.f; t1[k] = 0.f; }
+  if constexpr (sizeof(V) == sizeof(float)) {
+    float dgx = 0.f, dgy = 0.f;
+    glu::light_vjp(body, d, x, y, g, t0, dgx, dgy);
+#pragma unroll
+    for (int k = 0; k < NPAR; ++k) acc[k] += t0[k];
+    if (SRC) { gpx += dgx; gpy += dgy; }
+  } else {
+    float dgx0 = 0.f, dgy0 = 0.f, dgx1 = 0.f, dgy1 = 0.f;
+    glu::light_vjp(body, d, x.x, y.x, g.x, t0, dgx0, dgy0);
+    glu::light_vjp(body, d, x.y, y.y, g.y, t1, dgx1, dgy1);
+#pragma unroll
+    for (int k = 0; k < NPAR; ++k) acc[k] += V{t0[k], t1[k]};
+    if (SRC) { gpx += V{dgx0, dgx1}; gpy += V{dgy0, dgy1}; }
+  }
+}
+#endif
+
 // ---- the pair kernel ----------------------------------------------------------------------------------------
 // V = v2f: each thread owns pixels (j, j + 256) of every 512-pixel tile; V = float: one pixel per thread.
 template <int MODE, class V, int WAVES, class LK, class LLK, class SK>
@@ -120,12 +185,20 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
       if constexpr (kind == K_EPL) epl_fwd_v<V, GRAD>(dL[i], gder + comps[i].d_off, x, y, bx, by, est[i]);
       else if constexpr (kind == K_SIE) sie_fwd_v<V>(dL[i], x, y, bx, by);
       else if constexpr (kind == K_SHEAR) shear_fwd_v<V>(dL[i], x, y, bx, by);
+#ifdef GL_HAVE_USER
+      else if constexpr (is_user_code(kind)) user_mass_fwd_v<V, kind>(dL[i], x, y, bx, by);
+#endif
       else sis_fwd_v<V>(dL[i], x, y, bx, by);
     }, std::make_integer_sequence<int, NL>{});
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr bool src = i >= NLL;
-      constexpr bool ell = (src ? SK::kinds[src ? i - NLL : 0] : LLK::kinds[src ? 0 : i]) != K_SERSIC;  // K_SERSIC in the list = all spherical
+      constexpr int lkind = src ? SK::kinds[src ? i - NLL : 0] : LLK::kinds[src ? 0 : i];
+      constexpr bool ell = lkind != K_SERSIC;  // K_SERSIC in the list = all spherical
+#ifdef GL_HAVE_USER
+      if constexpr (is_user_code(lkind)) m += user_light_fwd_v<V, lkind>(dC[i], src ? bx : x, src ? by : y);
+      else
+#endif
       m += sersic_fwd_v<V, ell>(dC[i], src ? bx : x, src ? by : y, sst[i]);
     }, std::make_integer_sequence<int, NLIGHT>{});
     auto nanp = m != m;
@@ -189,7 +262,12 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
           for (int j = 0; j < i; ++j) n += static_nacc(j < NLL ? LLK::kinds[j < NLL ? j : 0] : SK::kinds[j >= NLL ? j - NLL : 0]);
           return n;
         }();
-        constexpr bool ell = (src ? SK::kinds[src ? i - NLL : 0] : LLK::kinds[src ? 0 : i]) != K_SERSIC;
+        constexpr int lkind = src ? SK::kinds[src ? i - NLL : 0] : LLK::kinds[src ? 0 : i];
+        constexpr bool ell = lkind != K_SERSIC;
+#ifdef GL_HAVE_USER
+        if constexpr (is_user_code(lkind)) user_light_vjp_v<V, lkind, src>(dC[i], src ? bx : x, src ? by : y, gm, accC + off, gbx, gby);
+        else
+#endif
         sersic_vjp_v<V, src, ell>(dC[i], sst[i], gm, accC + off, gbx, gby);
       }, std::make_integer_sequence<int, NLIGHT>{});
       gbx = -gbx;
@@ -201,6 +279,9 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
         if constexpr (kind == K_EPL) epl_vjp_v<V>(dL[i], gbx, gby, est[i], accL + off);
         else if constexpr (kind == K_SIE) sie_vjp_v<V>(dL[i], x, y, gbx, gby, accL + off);
         else if constexpr (kind == K_SHEAR) shear_vjp_v<V>(x, y, gbx, gby, accL + off);
+#ifdef GL_HAVE_USER
+        else if constexpr (is_user_code(kind)) user_mass_vjp_v<V, kind>(dL[i], x, y, gbx, gby, accL + off);
+#endif
         else sis_vjp_v<V>(dL[i], x, y, gbx, gby, accL + off);
       }, std::make_integer_sequence<int, NL>{});
     }
@@ -268,8 +349,14 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
         for (int j = 0; j < i; ++j) n += static_nacc(j < NLL ? LLK::kinds[j < NLL ? j : 0] : SK::kinds[j >= NLL ? j - NLL : 0]);
         return n;
       }();
+      constexpr int lkind = i < NLL ? LLK::kinds[i < NLL ? i : 0] : SK::kinds[i >= NLL ? i - NLL : 0];
+      if constexpr (is_user_code(lkind)) {  // a user-written light: one sum per parameter, as it stands
 #pragma unroll
-      for (int k = 0; k < SER_NACC; ++k) vals[NSTAT + NACC_L + off + k] = hsum(accC[off + k]) * (k == SERA_INVN ? (float)kLn2 : 1.f);
+        for (int k = 0; k < static_nacc(lkind); ++k) vals[NSTAT + NACC_L + off + k] = hsum(accC[off + k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < SER_NACC; ++k) vals[NSTAT + NACC_L + off + k] = hsum(accC[off + k]) * (k == SERA_INVN ? (float)kLn2 : 1.f);
+      }
     }, std::make_integer_sequence<int, NLIGHT>{});
     const bool odd = tid & 1, hi = tid & 2;
     float* s_row16 = s_acc + (tid >> 4) * a.Apad;  // [16 rows of the workgroup][Apad]

@@ -11,7 +11,27 @@
 // Same per-profile maths (gl_profiles.h), same launch geometry, same partial/finalize protocol as the
 // generic kernel; the two are cross-checked against each other and against the oracle in tests/.
 #pragma once
+#if defined(__HIPCC_RTC__) && !__has_include(<utility>)
+// the run-time compiler of models with user-written profiles (gl_user.hip) has no host library: what the kernels use of
+// <utility> / <type_traits>
+namespace std {
+template <class T, T v> struct integral_constant {
+  static constexpr T value = v;
+  typedef T value_type;
+  typedef integral_constant type;
+  constexpr operator T() const { return v; }
+};
+typedef integral_constant<bool, true> true_type;
+typedef integral_constant<bool, false> false_type;
+template <class T, T... Is> struct integer_sequence {};
+template <class T, T N> using make_integer_sequence = __make_integer_seq<integer_sequence, T, N>;
+template <bool B, class T, class F> struct conditional { typedef T type; };
+template <class T, class F> struct conditional<false, T, F> { typedef F type; };
+template <bool B, class T, class F> using conditional_t = typename conditional<B, T, F>::type;
+}  // namespace std
+#else
 #include <utility>
+#endif
 
 #include "gl_kernels.hip.h"
 #include "gl_shapelets.hip.h"
@@ -23,7 +43,18 @@ template <int... Ks> struct KindList {
   static constexpr int kinds[sizeof...(Ks) + 1] = {Ks..., 0};
 };
 
+// A user-written profile inside a kind list of the run-time compiled specialised kernels (gl_user.hip): the code carries which of
+// the model's bodies it is and its parameter count, so that the kernel is specialised on both --
+//   USER_CODE + 2048 light + 32 body + n_params          (n_params <= 16, body < 64)
+constexpr int USER_CODE = 0x1000;
+__host__ __device__ constexpr bool is_user_code(int kind) { return kind >= USER_CODE; }
+__host__ __device__ constexpr bool user_code_light(int kind) { return ((kind - USER_CODE) >> 11) & 1; }
+__host__ __device__ constexpr int user_code_body(int kind) { return ((kind - USER_CODE) >> 5) & 63; }
+__host__ __device__ constexpr int user_code_npar(int kind) { return (kind - USER_CODE) & 31; }
+__host__ __device__ constexpr int user_code(bool light, int body, int npar) { return USER_CODE + (light ? 2048 : 0) + 32 * body + npar; }
+
 __host__ __device__ constexpr int static_nacc(int kind) {
+  if (is_user_code(kind)) return user_code_npar(kind);  // one gradient sum per parameter, straight from the body's duals
   return kind == K_EPL ? EPL_NACC : kind == K_SIE ? SIE_NACC : kind == K_NFW ? NFW_NACC : kind == K_SHEAR ? SHR_NACC
          : kind == K_SIS ? SIS_NACC : (kind == K_SERSIC || kind == K_SERSIC_ELLIPSE) ? SER_NACC
          : kind == K_SHAPELETS ? (SHPA_AMP + SH_MAXL) : 0;

@@ -193,6 +193,7 @@ int compile_user_profile(const char* body, int is_light, int n_params, std::vect
 
 // ---- user bodies inside a model: the interpreter kernel compiled with them ----------------------------------------------------
 #include "gl_kernels.hip.h"  // MainArgs, Mode, kinds (host view; the device code of this translation unit is unused)
+#include "gl_static.hip.h"   // KindList codes of user-written profiles, static_nacc
 
 namespace glk {
 
@@ -207,7 +208,8 @@ namespace glk {
 // the same bodies -- the seconds of hiprtc are paid once per process, a model only loads the code object
 struct UserCode {
   std::vector<char> code;
-  std::string lowered[4];
+  std::string lowered[5];       // [4] = the basis-stack kernel (models with linear columns), else empty
+  std::string lowered_pair[4];  // empty: the composition is not one the pair kernel serves
 };
 static std::mutex g_user_mu;
 static std::map<std::string, std::shared_ptr<const UserCode>>& user_cache() {
@@ -264,10 +266,47 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
                   "      for (int k = 0; k < @N; ++k) acc[k] += g * f.d[2 + k]; } break;\n");
   src += "  }\n}\n}  // namespace glu\n#include \"gl_kernels.hip.h\"\n";
   // the instantiations launch_main would pick for an interpreter model: T = 2, the model's shapelet / family switches
-  std::string names[4];
-  for (int mode = 0; mode < 4; ++mode) {
+  // (mode 4 = IMG_BASIS, the basis stack of the linear-amplitude solve: only for models with linear columns)
+  const int n_modes = m->lin_cols.empty() ? 4 : 5;
+  std::string names[5];
+  for (int mode = 0; mode < n_modes; ++mode) {
     names[mode] = "glk::gl_main_kernel<" + std::to_string(mode) + ", 2, " + (m->has_shapelets ? "true" : "false") + ", " + std::to_string(m->fam) + ", false>";
     src += "template __global__ void " + names[mode] + "(glk::MainArgs);\n";
+  }
+  // Round 4: the SPECIALISED pixel-pair kernel for the model's own component list (the same gl_pair_kernel the built-in
+  // compositions run: component loops unrolled at compile time, accumulators in registers, forward state kept for the VJPs,
+  // packed fp32 for the built-in members) with the user bodies as members of the kind lists -- when every lens is EPL / SIE /
+  // Shear / SIS or user-written, every light Sersic / SersicEllipse or user-written, the counts are small and the accumulator
+  // row is the plain [stats | lenses | lights] sequence the kernel addresses in closed form.
+  std::string pair_names[4];
+  bool pair_ok = getenv("GIGALENS_HIP_USER_PAIR") == nullptr || atoi(getenv("GIGALENS_HIP_USER_PAIR")) != 0;
+  {
+    const int n_lens = m->n_lens, n_ll = m->n_ll, n_src = m->n_src;
+    pair_ok = pair_ok && !m->has_shapelets && m->fam == 0 && n_lens >= 1 && n_lens <= 4 && n_ll <= 2 && n_src >= 1 && n_src <= 3;
+    int off = NSTAT;
+    std::string lists[3];
+    for (int i = 0; i < (int)m->comps.size() && pair_ok; ++i) {
+      const CompDesc& cd = m->comps[i];
+      const bool lens = i < n_lens;
+      int code = -1;
+      if (lens && (cd.kind == K_EPL || cd.kind == K_SIE || cd.kind == K_SHEAR || cd.kind == K_SIS)) code = cd.kind;
+      if (!lens && (cd.kind == K_SERSIC || cd.kind == K_SERSIC_ELLIPSE)) code = cd.kind;
+      if (lens && cd.kind == K_USER_MASS && cd.iparam <= 16) code = user_code(false, (int)cd.flags, cd.iparam);
+      if (!lens && cd.kind == K_USER_LIGHT && cd.iparam <= 16) code = user_code(true, (int)cd.flags, cd.iparam);
+      pair_ok = code >= 0 && cd.a_off == off && cd.n_acc == static_nacc(code);
+      off += cd.n_acc;
+      std::string& l = lists[lens ? 0 : (i < n_lens + n_ll ? 1 : 2)];
+      l += (l.empty() ? "" : ", ") + std::to_string(code);
+    }
+    pair_ok = pair_ok && off == m->A;
+    if (pair_ok) {
+      src += "#include \"gl_pair.hip.h\"\n";
+      for (int mode = 0; mode < 4; ++mode) {
+        pair_names[mode] = "glk::gl_pair_kernel<" + std::to_string(mode) + ", glk::v2f, 2, glk::KindList<" + lists[0] + ">, glk::KindList<" +
+                           lists[1] + ">, glk::KindList<" + lists[2] + "> >";
+        src += "template __global__ void " + pair_names[mode] + "(glk::MainArgs);\n";
+      }
+    }
   }
   const char* dev_dir = getenv("GIGALENS_HIP_CSRC");
   std::shared_ptr<const UserCode> uc;
@@ -282,11 +321,16 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
       const hiprtcResult rcc = dev_dir ? hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", 0, nullptr, nullptr)
                                        : hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", kEmbeddedCount, kEmbeddedSources, kEmbeddedNames);
       if (rcc != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcCreateProgram failed");
-      for (int mode = 0; mode < 4; ++mode) (void)hiprtcAddNameExpression(prog, names[mode].c_str());
+      for (int mode = 0; mode < n_modes; ++mode) (void)hiprtcAddNameExpression(prog, names[mode].c_str());
+      if (pair_ok)
+        for (int mode = 0; mode < 4; ++mode) (void)hiprtcAddNameExpression(prog, pair_names[mode].c_str());
       const std::string inc = std::string("-I") + (dev_dir ? dev_dir : ".");
       // (-fno-slp-vectorize: as for the interpreter of the library itself, gl_launch_generic.hip.h)
-      const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", inc.c_str()};
-      const hiprtcResult rc = hiprtcCompileProgram(prog, dev_dir ? 5 : 4, opts);
+      // (-fno-hip-fp32-correctly-rounded-divide-sqrt: a user body's `/` and sqrt as the hardware reciprocal / square root with
+      // one Newton step -- 2.5 ulp, what the built-in kinds' v_rcp / v_sqrt wrappers deliver -- instead of the correctly rounded
+      // sequences: a body is evaluated on n_params + 2 tangents, every division of which was ~10 instructions)
+      const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", inc.c_str()};
+      const hiprtcResult rc = hiprtcCompileProgram(prog, dev_dir ? 6 : 5, opts);
       if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
         (void)hiprtcGetProgramLogSize(prog, &n);
@@ -299,13 +343,20 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
                     dev_dir ? dev_dir : "embedded in the library", log.c_str() + from);
       }
       auto fresh = std::make_shared<UserCode>();
-      for (int mode = 0; mode < 4; ++mode) {
+      for (int mode = 0; mode < n_modes; ++mode) {
         const char* ln = nullptr;
         if (hiprtcGetLoweredName(prog, names[mode].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
           (void)hiprtcDestroyProgram(&prog);
           return fail(GL_ELAUNCH, "hiprtcGetLoweredName failed for %s", names[mode].c_str());
         }
         fresh->lowered[mode] = ln;
+        if (pair_ok && mode < 4) {
+          if (hiprtcGetLoweredName(prog, pair_names[mode].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+            (void)hiprtcDestroyProgram(&prog);
+            return fail(GL_ELAUNCH, "hiprtcGetLoweredName failed for %s", pair_names[mode].c_str());
+          }
+          fresh->lowered_pair[mode] = ln;
+        }
       }
       size_t code_size = 0;
       if (hiprtcGetCodeSize(prog, &code_size) != HIPRTC_SUCCESS || !code_size) {
@@ -322,7 +373,10 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
     }
   }
   hipError_t e = hipModuleLoadData(&m->user_module, uc->code.data());
-  for (int mode = 0; mode < 4 && e == hipSuccess; ++mode) e = hipModuleGetFunction(&m->user_fn[mode], m->user_module, uc->lowered[mode].c_str());
+  for (int mode = 0; mode < 5 && e == hipSuccess; ++mode)
+    if (!uc->lowered[mode].empty()) e = hipModuleGetFunction(&m->user_fn[mode], m->user_module, uc->lowered[mode].c_str());
+  for (int mode = 0; mode < 4 && e == hipSuccess; ++mode)
+    if (!uc->lowered_pair[mode].empty()) e = hipModuleGetFunction(&m->user_pair_fn[mode], m->user_module, uc->lowered_pair[mode].c_str());
   if (e != hipSuccess) return fail(GL_ELAUNCH, "loading the compiled user model failed: %s", hipGetErrorString(e));
   return GL_OK;
 }

@@ -77,7 +77,7 @@ typedef struct gl_component {
   int32_t kind;   /* gl_kind */
   int32_t iparam; /* EPL: niter cap (epl.py:15, default 50); SHAPELETS: n_max; SCALED: number of scales; else 0 */
   uint32_t flags; /* GL_FLAG_* */
-  int32_t reserved;
+  int32_t reserved; /* GL_USER_LIGHT: 1 = the last parameter is the profile's linear amplitude (lstsq_simulate solves for it); else 0 */
 } gl_component;
 
 /* Pixel grid and camera set-up == what LensSimulator.__init__ precomputes
@@ -356,7 +356,9 @@ int gl_model_launch_shape(const gl_model* m, int B, int* chunk_px, int* n_chunks
 /* ... and inside a model: components of kind GL_USER_MASS / GL_USER_LIGHT (iparam = parameter count <= 16, flags = index into
  * `bodies`) make gl_model_create_user compile the interpreter kernel of the likelihood path at run time with those bodies in it:
  * simulate / log-likelihood / fused log-prob and their gradients (forward-mode duals of the body) work as for built-in kinds.
- * Not served for such models: the linear-amplitude solve, the image-position likelihood, lens maps (typed refusals). */
+ * The linear-amplitude solve serves them too (round 4: a user-written light with `reserved = 1` contributes one basis image).
+ * Not served for such models: the image-position likelihood, lens maps (typed refusals; LensSimulator forms the maps lens by lens
+ * through the plugin-level kernels instead). */
 int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light, int n_src, const gl_grid* grid,
                          const char* const* bodies, int n_bodies, gl_model** out);
 /* The compiled interpreter is cached per process, keyed on the program text (bodies, parameter counts, shapelet / family

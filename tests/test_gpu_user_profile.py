@@ -342,3 +342,46 @@ def test_models_with_the_same_bodies_share_one_compile_and_need_no_source_tree(g
         imgs.append(s.simulate(params))
     assert torch.isfinite(imgs[0]).all() and torch.equal(imgs[0], imgs[1])
     assert "run-time compiled" in sims[0]._model.last_main_kernel()
+
+
+def test_linear_amplitude_solve_with_a_user_written_light(gl):
+    """lstsq_simulate / BackwardProbModel (tf/simulator.py:158-240, tf/model.py:197-273) on a model whose source is a USER-written
+    light with ``use_lstsq=True``: its unit-amplitude basis image comes from the run-time compiled basis-stack kernel
+    (gl_main_kernel<IMG_BASIS> with the body inside; the amplitude column is the body's last parameter, gl_component::reserved),
+    the normal matrix / solve / envelope gradient are the built-in ones.  Must equal the same model of built-in kinds."""
+    from gigalens_amd.model import BackwardProbModel, PhysicalModel
+    from gigalens_amd.profile import LightProfile
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.profiles.mass.sis import SIS
+    from gigalens_amd.simulator import LensSimulator, SimulatorConfig
+    UserSIS, _ = _profiles()
+
+    class UserSersic(LightProfile):
+        _name, _params, _amp = "USER_SERSIC", ["R_sersic", "n_sersic", "center_x", "center_y"], "Ie"
+        hip_body = SERSIC_BODY
+
+    cfg = SimulatorConfig(delta_pix=0.08, num_pix=40)
+    B = 5
+    sim_u = LensSimulator(PhysicalModel([UserSIS(), Shear()], [], [UserSersic(use_lstsq=True)]), cfg, bs=B)
+    sim_b = LensSimulator(PhysicalModel([SIS(), Shear()], [], [Sersic(use_lstsq=True)]), cfg, bs=B)
+    r = np.random.default_rng(7)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    params = {"lens_mass": [dict(theta_E=t(r.uniform(0.8, 1.2, B)), center_x=t(r.normal(0, 0.05, B)), center_y=t(r.normal(0, 0.05, B))),
+                            dict(gamma1=t(r.normal(0, 0.03, B)), gamma2=t(r.normal(0, 0.03, B)))],
+              "source_light": [dict(R_sersic=t(r.uniform(0.2, 0.4, B)), n_sersic=t(r.uniform(1.0, 3.0, B)),
+                                    center_x=t(r.normal(0.05, 0.1, B)), center_y=t(r.normal(0, 0.1, B)))]}
+    truth = {"lens_mass": params["lens_mass"], "source_light": [dict(params["source_light"][0], Ie=t(np.full(B, 40.0)))]}
+    full = LensSimulator(PhysicalModel([SIS(), Shear()], [], [Sersic()]), cfg, bs=B)
+    obs = (full.simulate(truth)[0] + 0.3 * t(r.normal(size=(40, 40)))).contiguous()
+    err = torch.full_like(obs, 0.3)
+    st_u, st_b = sim_u.lstsq_simulate(params, obs, err, return_stacked=True), sim_b.lstsq_simulate(params, obs, err, return_stacked=True)
+    assert st_u.shape == st_b.shape
+    assert torch.allclose(st_u, st_b, rtol=1e-4, atol=2e-5 * float(st_b.abs().max()))
+    c_u, c_b = sim_u.lstsq_simulate(params, obs, err, return_coeffs=True), sim_b.lstsq_simulate(params, obs, err, return_coeffs=True)
+    assert c_u.shape == c_b.shape == (B, 1) and torch.allclose(c_u, c_b, rtol=2e-4)
+    # sample 0 holds the truth's nonlinear parameters: the solve recovers its amplitude (the coefficient multiplies the rendered
+    # basis image, which carries det(T) = delta_pix^2: tf/simulator.py:156)
+    assert abs(float(c_b[0, 0]) / (40.0 * 0.08 ** 2) - 1.0) < 0.1
+    im_u, im_b = sim_u.lstsq_simulate(params, obs, err), sim_b.lstsq_simulate(params, obs, err)
+    assert torch.allclose(im_u, im_b, rtol=2e-4, atol=2e-5 * float(im_b.abs().max()))
