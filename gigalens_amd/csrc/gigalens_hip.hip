@@ -363,47 +363,61 @@ PostArgs post_args(const gl_model* m, float scale) {
 // supersampled pre-PSF image S [B,Hs,Ws] -> final image [B,H,W] (x conversion factor)
 // the register-blocked pair kernel on one plan (gl_post.hip.h); false: no instantiation for this kernel width / stride
 bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* out, float scale, hipStream_t stream, int dbg = 0,
-                 int max_pairs_env = 0) {
+                 int max_pairs_env = 0, int corr_wide = 1) {
   if (!pl.ok) return false;
   CorrArgs a = pl.args;
   a.B = B;
   a.scale = scale;
   a.dbg = dbg;
-  const int TR = (CORR_TR - 1) * pl.ST + pl.max_KH, TC = ((CORR_TCG * CORR_OX - 1) * pl.ST + pl.KWP) | 1;
-  const int ks = pl.ST == 2 ? 4 : 2;
-  const size_t sh = std::max((size_t)TR * TC * sizeof(float2), (size_t)(ks - 1) * a.ncj * CORR_OX * CORR_GT * sizeof(float2) +
-                                                                   (size_t)2 * CORR_TR * CORR_TCG * CORR_OX * a.ncj * sizeof(float));
-  if (sh > 64 * 1024) return false;
+  a.vec = (a.Wi % 4 == 0 && a.Wout % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) ? 1 : 0;
+  // forward at supersample 2 with kernels up to 28 taps wide: 16 outputs per thread and 8 wavefronts per tile (two 75 KB tiles per
+  // CU); everything else 8 outputs per thread
+  const bool wide = pl.ST == 2 && a.ncj == 1 && pl.KWP <= 28 && pl.max_KH <= 28 && corr_wide;
+  const int ox = wide ? 16 : CORR_OX, ks = wide ? 8 : pl.ST == 2 ? 4 : 2;
+  const int TR = (CORR_TR - 1) * pl.ST + pl.max_KH, TC = corr_tile_width((CORR_TCG * ox - 1) * pl.ST + pl.KWP) | 1;
+  const size_t sh = std::max((size_t)TR * TC * sizeof(float2), (size_t)(ks - 1) * a.ncj * ox * CORR_GT * sizeof(float2) +
+                                                                   (size_t)2 * CORR_TR * CORR_TCG * ox * a.ncj * sizeof(float));
+  if (sh > (wide ? 80 : 64) * 1024) return false;
   // grid.z carries (row class, sample pair): at most 65535 per launch -- larger batches (the basis stack of lstsq_simulate is
   // B x D images) go out in slices
   const int max_pairs = max_pairs_env > 0 ? max_pairs_env : 65535 / a.n_class;
   if ((B + 1) / 2 > max_pairs) {
     for (int b_lo = 0; b_lo < B; b_lo += 2 * max_pairs) {
       const int nb = std::min(B - b_lo, 2 * max_pairs);
-      if (!launch_corr(pl, nb, in + (size_t)b_lo * a.Hi * a.Wi, out + (size_t)b_lo * a.Hout * a.Wout, scale, stream, dbg, max_pairs_env)) return false;
+      if (!launch_corr(pl, nb, in + (size_t)b_lo * a.Hi * a.Wi, out + (size_t)b_lo * a.Hout * a.Wout, scale, stream, dbg, max_pairs_env, corr_wide)) return false;
     }
     return true;
   }
-  const dim3 grid((pl.max_Wo + CORR_TCG * CORR_OX - 1) / (CORR_TCG * CORR_OX), (pl.max_Ho + CORR_TR - 1) / CORR_TR,
+  const dim3 grid((pl.max_Wo + CORR_TCG * ox - 1) / (CORR_TCG * ox), (pl.max_Ho + CORR_TR - 1) / CORR_TR,
                   (unsigned)(a.n_class * ((B + 1) / 2)));
-#define GL_CORR(KWP_, ST_, KS_, NCJ_) hipLaunchKernelGGL((gl_corr_pair_kernel<KWP_, ST_, KS_, NCJ_>), grid, dim3(CORR_GT * KS_), sh, stream, in, out, a); return true
-#define GL_CORR_W(ST_, KS_, NCJ_)                                                                                     \
-  switch (pl.KWP) {                                                                                                   \
-    case 4: GL_CORR(4, ST_, KS_, NCJ_); case 8: GL_CORR(8, ST_, KS_, NCJ_); case 12: GL_CORR(12, ST_, KS_, NCJ_);       \
-    case 16: GL_CORR(16, ST_, KS_, NCJ_); case 20: GL_CORR(20, ST_, KS_, NCJ_); case 24: GL_CORR(24, ST_, KS_, NCJ_);   \
-    case 28: GL_CORR(28, ST_, KS_, NCJ_); case 32: GL_CORR(32, ST_, KS_, NCJ_);                                        \
-    default: return false;                                                                                            \
+#define GL_CORR(KWP_, ST_, KS_, NCJ_, OX_)                                                                             \
+  {                                                                                                                    \
+    auto* fn = gl_corr_pair_kernel<KWP_, ST_, KS_, NCJ_, OX_>;                                                          \
+    if (sh > 64 * 1024) {                                                                                              \
+      static const hipError_t big = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+      if (big != hipSuccess) return false;                                                                             \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(fn, grid, dim3(CORR_GT * KS_), sh, stream, in, out, a);                                         \
+    return true;                                                                                                       \
   }
-  if (pl.ST == 2 && a.ncj == 1) { GL_CORR_W(2, 4, 1) }  // forward at supersample 2
-  if (pl.ST == 1 && a.ncj == 1) { GL_CORR_W(1, 2, 1) }  // forward / transpose at supersample 1
-  if (pl.ST == 1 && a.ncj == 2) { GL_CORR_W(1, 2, 2) }  // transpose at supersample 2
+#define GL_CORR_W(ST_, KS_, NCJ_, OX_)                                                                                          \
+  switch (pl.KWP) {                                                                                                             \
+    case 4: GL_CORR(4, ST_, KS_, NCJ_, OX_) case 8: GL_CORR(8, ST_, KS_, NCJ_, OX_) case 12: GL_CORR(12, ST_, KS_, NCJ_, OX_)     \
+    case 16: GL_CORR(16, ST_, KS_, NCJ_, OX_) case 20: GL_CORR(20, ST_, KS_, NCJ_, OX_) case 24: GL_CORR(24, ST_, KS_, NCJ_, OX_) \
+    case 28: GL_CORR(28, ST_, KS_, NCJ_, OX_) case 32: GL_CORR(32, ST_, KS_, NCJ_, OX_)                                          \
+    default: return false;                                                                                                      \
+  }
+  if (wide) { GL_CORR_W(2, 8, 1, 16) }
+  if (pl.ST == 2 && a.ncj == 1) { GL_CORR_W(2, 4, 1, CORR_OX) }  // forward at supersample 2
+  if (pl.ST == 1 && a.ncj == 1) { GL_CORR_W(1, 2, 1, CORR_OX) }  // forward / transpose at supersample 1
+  if (pl.ST == 1 && a.ncj == 2) { GL_CORR_W(1, 2, 2, CORR_OX) }  // transpose at supersample 2
 #undef GL_CORR_W
 #undef GL_CORR
   return false;
 }
 
 int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t stream, float scale = -1.f) {
-  if (launch_corr(m->corr_fwd, B, S, out, scale < 0.f ? m->conversion_factor : scale, stream, m->dbg_flags, m->corr_max_pairs)) {
+  if (launch_corr(m->corr_fwd, B, S, out, scale < 0.f ? m->conversion_factor : scale, stream, m->dbg_flags, m->corr_max_pairs, m->corr_wide)) {
     GL_HIP(hipGetLastError());
     return GL_OK;
   }
@@ -418,7 +432,7 @@ int post_fwd(const gl_model* m, int B, const float* S, float* out, hipStream_t s
 }
 // cotangent of the final image [B,H,W] -> cotangent of S [B,Hs,Ws]
 int post_bwd(const gl_model* m, int B, const float* gP, float* gS, hipStream_t stream) {
-  if (launch_corr(m->corr_bwd, B, gP, gS, m->conversion_factor, stream, m->dbg_flags, m->corr_max_pairs)) {
+  if (launch_corr(m->corr_bwd, B, gP, gS, m->conversion_factor, stream, m->dbg_flags, m->corr_max_pairs, m->corr_wide)) {
     GL_HIP(hipGetLastError());
     return GL_OK;
   }
@@ -741,6 +755,7 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
   }
 #endif
   m->corr_max_pairs = env_int("GIGALENS_HIP_CORR_MAXPAIRS", 0);  // tests: force the slicing of the PSF launches (read once)
+  m->corr_wide = env_int("GIGALENS_HIP_CORR_WIDE", 1);           // 0: 8 outputs per thread in the stride-2 forward correlation as well
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
   m->lstsq_wgs = std::max(1, env_int("GIGALENS_HIP_LSTSQ_WGS", 2048));
   m->lstsq_chol = env_int("GIGALENS_HIP_LSTSQ_CHOL", 1) != 0;    // tests: 0 = every system through the eigenvalue solve

@@ -41,7 +41,8 @@ struct CorrArgs {
   int Hi, Wi;          // input image
   int Hout, Wout, os;  // output image and the placement stride of a class's outputs
   float scale;
-  int dbg;  // -DGL_EXPERIMENTS builds only (GIGALENS_HIP_DBGFLAGS): 16 skip the tile fill, 32 skip the multiply-add loop
+  int vec;  // image widths multiples of four and 16-byte aligned buffers: float4 tile fill and output stores
+  int dbg;  // -DGL_EXPERIMENTS builds only (GIGALENS_HIP_DBGFLAGS): 16 skip the tile fill, 32 skip the multiply-add loop, 64 skip the output stores
   CorrClass cls[16];
 };
 }  // namespace glk
@@ -71,6 +72,7 @@ struct gl_model {
   int chunk_px_override = 0;  // -DGL_EXPERIMENTS builds only
   int dbg_flags = 0;          // -DGL_EXPERIMENTS builds only
   int corr_max_pairs = 0;     // GIGALENS_HIP_CORR_MAXPAIRS, read once at gl_model_create
+  int corr_wide = 1;          // GIGALENS_HIP_CORR_WIDE, read once at gl_model_create
   bool has_nfw = false;
   size_t nfw_lds = 0;          // bytes of that table in a main kernel's LDS
   int shp_stride = 0;

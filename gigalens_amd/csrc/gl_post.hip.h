@@ -106,30 +106,93 @@ __global__ void __launch_bounds__(256) gl_psf_pool_bwd_kernel(const float* __res
 // (CorrClass / CorrArgs: gl_model.h, the model keeps one plan per direction)
 constexpr int CORR_TR = 16, CORR_TCG = 4, CORR_OX = 8;  // output tile: 16 rows x (4 threads x 8 outputs) columns
 constexpr int CORR_GT = CORR_TR * CORR_TCG;             // threads of one group (one wavefront)
+// columns of the LDS tile for a window of TC input columns: up to three more on the left (the tile starts at a 16-byte boundary
+// of the image row), rounded up to whole groups of four
+__host__ __device__ constexpr int corr_tile_width(int TC) { return ((TC + 3 + 3) / 4) * 4; }
 
 // KS: the kernel's rows are dealt to KS wavefronts (u = g, g + KS, ..) that share the LDS tile and add their sums at the end --
 // the stride-2 tile is 41 KB, so one wavefront per tile would leave a CU with three.
 // NCJ: column classes per thread (transpose: ss -- a thread then writes ss * 8 CONSECUTIVE floats of a row; one class per
 // launch unit wrote every ss-th float of a 29 MB buffer from different workgroups, and the partial-line writes bound the kernel)
-template <int KWP, int ST, int KS, int NCJ>
+// OX: consecutive outputs of a thread (8; 16 for the wide stride-2 kernels, whose main loop is otherwise bound by the LDS pipe:
+// 42 window reads per 224 multiply-adds at 8, 58 per 448 at 16)
+template <int KWP, int ST, int KS, int NCJ, int OX>
 __global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float* __restrict__ in, float* __restrict__ out, CorrArgs p) {
   typedef float v2 __attribute__((ext_vector_type(2)));
   extern __shared__ float2 ctile[];
   constexpr int NT = CORR_GT * KS;
-  const int ci = blockIdx.z % p.n_class, bp = blockIdx.z / p.n_class;
+  // workgroup -> (tile, class, sample pair).  Consecutive workgroups go to consecutive XCDs, each with an L2 of its own: in launch
+  // order the tiles of ONE sample pair -- which share their halos, 2.9 x the image in all on the demo set-up -- would land on eight
+  // different L2s and every halo would come from memory again.  Instead the k-th workgroup of XCD x walks the tiles and classes of
+  // pair 8 j + x before moving to pair 8 (j + 1) + x (the pairs beyond a multiple of eight are dealt the same way among themselves).
+  int ci, bp, bx, by;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, per_pair = gx * gy * p.n_class, n_pairs = (p.B + 1) / 2;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int full = (n_pairs / 8) * 8, lin_full = full * per_pair;
+    int t;
+    if (lin < lin_full) {
+      const int q = lin >> 3;
+      t = q % per_pair;
+      bp = (q / per_pair) * 8 + (lin & 7);
+    } else {
+      const int rest = n_pairs - full, l2 = lin - lin_full;
+      t = l2 / rest;
+      bp = full + l2 % rest;
+    }
+    bx = t % gx;
+    by = (t / gx) % gy;
+    ci = t / (gx * gy);
+  }
   const CorrClass c = p.cls[ci];
-  const int I0 = blockIdx.y * CORR_TR, J0 = blockIdx.x * (CORR_TCG * CORR_OX);
+  const int I0 = by * CORR_TR, J0 = bx * (CORR_TCG * OX);
   if (I0 >= c.Ho || J0 >= c.Wo[0]) return;  // classes differ in size: whole workgroups leave together (Wo[0] is the largest)
   const int TR = (CORR_TR - 1) * ST + c.KH;
-  constexpr int TC = (CORR_TCG * CORR_OX - 1) * ST + KWP, TCp = TC | 1;
+  constexpr int TC = (CORR_TCG * OX - 1) * ST + KWP, TCW = corr_tile_width(TC), TCp = TCW | 1;
   const int b0 = 2 * bp, b1 = min(b0 + 1, p.B - 1);
   const bool has1 = b0 + 1 < p.B;
   const float* in0 = in + (size_t)b0 * p.Hi * p.Wi;
   const float* in1 = in + (size_t)b1 * p.Hi * p.Wi;
-  const int r0 = I0 * ST - c.pt, c0 = J0 * ST - c.pl;
+  // the tile starts at the 16-byte boundary at or before its first column (sh columns earlier): rows are then filled by float4 loads
+  const int r0 = I0 * ST - c.pt, c_first = J0 * ST - c.pl, sh = p.vec ? (c_first & 3) : 0, c0 = c_first - sh;
   // fill: one wavefront per tile row, lanes along the row (no index division, row-contiguous global reads); all of a wavefront's
   // loads (up to 16 per lane) are issued before the first LDS write: one global round trip per wavefront instead of one per row
-  constexpr int NW = NT / 64, CPASS = (TC + 63) / 64, FR = 16 / CPASS;  // 16 float2 of loads in flight per lane
+  // (round 4: the fill was 11 of the forward kernel's 51 us on the demo set-up and neither latency -- 32 loads in flight, a
+  // staggered first round and a register-prefetching resident-workgroup form measured no faster or slower -- nor memory: it
+  // is INSTRUCTIONS, ~20 per float2 with its two dword loads against 5 multiply-adds per LDS read in the main loop.  With the image
+  // width a multiple of four a lane now moves four columns of both samples per step: two 16-byte loads, four 8-byte LDS writes.)
+  constexpr int NW = NT / 64;
+  if (p.vec) {
+    constexpr int NG = TCW / 4, LPR = NG <= 8 ? 8 : NG <= 16 ? 16 : NG <= 32 ? 32 : 64, RPI = 64 / LPR, RSTEP = NW * RPI, FB = 4;
+    static_assert(NG <= 64, "a tile row is at most 64 column groups");
+    const int lane = threadIdx.x & 63, gl = lane % LPR, rl = lane / LPR + RPI * (int)(threadIdx.x >> 6);
+    const int gc = c0 + 4 * gl;
+    const bool col_in = gl < NG && gc >= 0 && gc < p.Wi;  // c0 and Wi are multiples of four: a group is inside or outside as a whole
+    for (int rb = GL_DBG(p.dbg, 16) ? TR : 0; rb < TR; rb += RSTEP * FB) {
+      float4 a0[FB], a1[FB];
+#pragma unroll
+      for (int f = 0; f < FB; ++f) {
+        const int r = rb + rl + f * RSTEP, gr = r0 + r;
+        const bool inside = col_in && r < TR && gr >= 0 && gr < p.Hi;
+        const unsigned off = inside ? (unsigned)(gr * p.Wi + gc) : 0u;
+        a0[f] = *reinterpret_cast<const float4*>(in0 + off);
+        a1[f] = *reinterpret_cast<const float4*>(in1 + off);
+      }
+#pragma unroll
+      for (int f = 0; f < FB; ++f) {
+        const int r = rb + rl + f * RSTEP, gr = r0 + r;
+        const bool inside = col_in && gr >= 0 && gr < p.Hi;
+        if (r < TR && gl < NG) {
+          float2* d = ctile + r * TCp + 4 * gl;
+          d[0] = inside ? float2{a0[f].x, a1[f].x} : float2{0.f, 0.f};
+          d[1] = inside ? float2{a0[f].y, a1[f].y} : float2{0.f, 0.f};
+          d[2] = inside ? float2{a0[f].z, a1[f].z} : float2{0.f, 0.f};
+          d[3] = inside ? float2{a0[f].w, a1[f].w} : float2{0.f, 0.f};
+        }
+      }
+    }
+  } else {
+  constexpr int CPASS = (TC + 63) / 64, FR = 16 / CPASS;  // 16 float2 of loads in flight per lane
   for (int rb = GL_DBG(p.dbg, 16) ? TR : (int)(threadIdx.x >> 6); rb < TR; rb += NW * FR) {
     float2 v[FR][CPASS];
 #pragma unroll
@@ -156,19 +219,20 @@ __global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float*
       }
     }
   }
+  }
   __syncthreads();
   // lane -> (row ti fastest, column group tg): the 16 lanes of an LDS pass read 16 different rows, ST * TCp float2 apart with
   // TCp odd -> distinct banks (column groups are 16 banks apart: four of them would collide)
   static_assert(CORR_GT == 64, "one group = one wavefront: its kernel row is wave-uniform");
   const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / CORR_GT)), t128 = threadIdx.x % CORR_GT;  // scalar: taps come through s_load
   const int ti = t128 % CORR_TR, tg = t128 / CORR_TR;
-  constexpr int WIN = (CORR_OX - 1) * ST + KWP;
-  v2 acc[NCJ][CORR_OX];
+  constexpr int WIN = (OX - 1) * ST + KWP;
+  v2 acc[NCJ][OX];
 #pragma unroll
   for (int j = 0; j < NCJ; ++j)
 #pragma unroll
-    for (int o = 0; o < CORR_OX; ++o) acc[j][o] = v2{0.f, 0.f};
-  const float2* base = ctile + (ti * ST) * TCp + tg * CORR_OX * ST;
+    for (int o = 0; o < OX; ++o) acc[j][o] = v2{0.f, 0.f};
+  const float2* base = ctile + (ti * ST) * TCp + tg * OX * ST + sh;
   const float* __restrict__ kc = p.k + c.koff;
   for (int u = GL_DBG(p.dbg, 32) ? c.KH : g; u < c.KH; u += KS) {
     const float2* row = base + u * TCp;
@@ -182,44 +246,64 @@ __global__ void __launch_bounds__(CORR_GT * KS) gl_corr_pair_kernel(const float*
       for (int v = 0; v < KWP; ++v) {
         const float kv = kr[j * KWP + v];
 #pragma unroll
-        for (int o = 0; o < CORR_OX; ++o) acc[j][o] = __builtin_elementwise_fma(w[o * ST + v], v2{kv, kv}, acc[j][o]);
+        for (int o = 0; o < OX; ++o) acc[j][o] = __builtin_elementwise_fma(w[o * ST + v], v2{kv, kv}, acc[j][o]);
       }
   }
   // ---- epilogue: sums of the row groups, then the tile leaves through LDS so that the global writes are row-contiguous (a lane
   // owns eight outputs of ONE row and neighbouring lanes different rows: written from registers every store instruction touched
   // 64 cache lines -- 42 of the transpose's 64 us were those stores)
   float2* sred = ctile;
-  float* otile = reinterpret_cast<float*>(ctile + (KS - 1) * NCJ * CORR_OX * CORR_GT);  // [2 samples][16 rows][32 NCJ columns]
-  constexpr int WT = CORR_TCG * CORR_OX * NCJ;
+  float* otile = reinterpret_cast<float*>(ctile + (KS - 1) * NCJ * OX * CORR_GT);  // [2 samples][16 rows][32 NCJ columns]
+  constexpr int WT = CORR_TCG * OX * NCJ;
+  // every wavefront OWNS NA / KS of the thread's NA sums: it receives the other row groups' partial sums of those and sends its
+  // partial sums of theirs (one wavefront adding up everything left the others waiting at the barrier).  Added in row-group
+  // order, whoever owns the sum.
+  constexpr int NA = NCJ * OX, OWN = NA / KS;
+  static_assert(KS > 1 && NA % KS == 0, "the sums are dealt evenly to the row groups");
   __syncthreads();  // every wavefront is done with the input tile
-  if constexpr (KS > 1) {
-    if (g > 0) {
 #pragma unroll
-      for (int j = 0; j < NCJ; ++j)
+  for (int gg = 0; gg < KS; ++gg)
+    if (g == gg) {
 #pragma unroll
-        for (int o = 0; o < CORR_OX; ++o)
-          sred[(((g - 1) * NCJ + j) * CORR_OX + o) * CORR_GT + t128] = float2{acc[j][o].x, acc[j][o].y};
-    }
-    __syncthreads();
-  }
-  if (g == 0) {
-#pragma unroll
-    for (int j = 0; j < NCJ; ++j)
-#pragma unroll
-      for (int o = 0; o < CORR_OX; ++o) {
-        v2 a = acc[j][o];
-#pragma unroll
-        for (int gg = 1; gg < KS; ++gg) {
-          const float2 t = sred[(((gg - 1) * NCJ + j) * CORR_OX + o) * CORR_GT + t128];
-          a += v2{t.x, t.y};
-        }
-        const int col = (tg * CORR_OX + o) * NCJ + c.oo_c[j];  // NCJ == the placement stride of the plan
-        otile[ti * WT + col] = a.x * p.scale;
-        otile[(CORR_TR + ti) * WT + col] = a.y * p.scale;
+      for (int ia = 0; ia < NA; ++ia) {
+        const int owner = ia / OWN;
+        if (owner != gg) sred[(((gg < owner ? gg : gg - 1) * NA + ia)) * CORR_GT + t128] = float2{acc[ia / OX][ia % OX].x, acc[ia / OX][ia % OX].y};
       }
-  }
+    }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * CORR_TR * WT; idx += NT) {
+#pragma unroll
+  for (int gg = 0; gg < KS; ++gg)
+    if (g == gg) {
+#pragma unroll
+      for (int ia = gg * OWN; ia < (gg + 1) * OWN; ++ia) {
+        const int j = ia / OX, o = ia % OX;
+        v2 sum = v2{0.f, 0.f};
+#pragma unroll
+        for (int src = 0; src < KS; ++src) {
+          v2 part = acc[j][o];
+          if (src != gg) {
+            const float2 t = sred[(((src < gg ? src : src - 1) * NA + ia)) * CORR_GT + t128];
+            part = v2{t.x, t.y};
+          }
+          sum = src == 0 ? part : sum + part;
+        }
+        const int col = (tg * OX + o) * NCJ + c.oo_c[j];  // NCJ == the placement stride of the plan
+        otile[ti * WT + col] = sum.x * p.scale;
+        otile[(CORR_TR + ti) * WT + col] = sum.y * p.scale;
+      }
+    }
+  __syncthreads();
+  if (p.vec) {  // four consecutive outputs per lane (the output width is a multiple of four: a group is inside or outside as a whole)
+    for (int e = GL_DBG(p.dbg, 64) ? 2 * CORR_TR * WT : 4 * (int)threadIdx.x; e < 2 * CORR_TR * WT; e += 4 * NT) {
+      const int sidx = e / (CORR_TR * WT), rem = e - sidx * (CORR_TR * WT);
+      const int row = rem / WT, col = rem - row * WT;
+      const int gi = (I0 + row) * p.os + c.oo_r, gj = J0 * p.os + col;
+      if (gi < p.Hout && I0 + row < c.Ho && gj < p.Wout && (sidx == 0 || has1))
+        *reinterpret_cast<float4*>(out + ((size_t)(sidx ? b1 : b0) * p.Hout + gi) * p.Wout + gj) = *reinterpret_cast<const float4*>(otile + e);
+    }
+    return;
+  }
+  for (int idx = GL_DBG(p.dbg, 64) ? 2 * CORR_TR * WT : (int)threadIdx.x; idx < 2 * CORR_TR * WT; idx += NT) {
     const int sidx = idx / (CORR_TR * WT), rem = idx - sidx * (CORR_TR * WT);
     const int row = rem / WT, col = rem - row * WT;
     const int gi = (I0 + row) * p.os + c.oo_r, gj = J0 * p.os + col;
