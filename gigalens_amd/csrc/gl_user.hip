@@ -99,6 +99,7 @@ template <int N> __device__ inline Dual<N> fmax(const Dual<N>& a, const Dual<N>&
 __device__ inline float value(float a) { return a; }
 template <int N> __device__ inline float value(const Dual<N>& a) { return a.v; }
 }  // namespace gl
+using gl::value;  // value(float) has no namespace to be found through
 )GLSRC";
 
 const char* kKernel = R"GLSRC(

@@ -8,6 +8,47 @@ from gigalens_amd.profile import MassProfile
 
 _BASE_KINDS = (6, 7, 8)  # dPIS, dPIE, dPIEP
 
+# Member bodies of built-in kinds, in the form of a user-written `hip_body` (profile.py): what a population of such members is
+# compiled from when it sits inside a PhysicalModel (`_member_loop_body` below).  Restated from the reference's formulas:
+# tf/profiles/mass/sis.py:13-18, nfw.py:15-51 (acosh(1/x) = log((1 + sqrt(1 - x^2)) / x), acos(1/x) = atan(sqrt(x^2 - 1))).
+_MEMBER_BODIES = {
+    "SIS": """
+template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) {
+  const R dx = x - p[1], dy = y - p[2];
+  const R r = sqrt(dx * dx + dy * dy);
+  if (value(r) == 0.f) { fx = R(0.f); fy = R(0.f); return; }
+  const R a = p[0] / r;
+  fx = a * dx;  fy = a * dy;
+}
+""",
+    "NFW": """
+template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) {
+  const R rho0 = p[1] / (4.f * p[0] * p[0] * (1.f - 0.693147180559945f));
+  const R dx = x - p[2], dy = y - p[3];
+  R r = sqrt(dx * dx + dy * dy);
+  if (value(r) < 1e-7f) r = R(1e-7f);
+  R rs = p[0];
+  if (value(rs) < 1e-7f) rs = R(1e-7f);
+  const R X = r / rs;
+  R xg = X;
+  if (value(xg) < 1e-6f) xg = R(1e-6f);
+  R g = R(1.f);
+  if (value(xg) < 1.f) { const R s = sqrt(1.f - xg * xg); g = log(xg * 0.5f) + log((1.f + s) / xg) / s; }
+  else if (value(xg) > 1.f) { const R s = sqrt(xg * xg - 1.f); g = log(xg * 0.5f) + atan(s) / s; }
+  const R a = 4.f * rho0 * rs * g / (X * X);
+  fx = a * dx;  fy = a * dy;
+}
+""",
+}
+
+
+def _float_literal(v) -> str:
+    """A float32 as a C++ literal that reads back to the same bits."""
+    if not np.isfinite(v):
+        raise ValueError(f"galaxy catalogue holds a non-finite value ({v})")
+    txt = "%.9g" % float(v)
+    return txt + ("f" if ("." in txt or "e" in txt) else ".f")
+
 
 class ScalingRelation(MassProfile):
     """Population of galaxies following luminosity scaling relations
@@ -20,10 +61,12 @@ class ScalingRelation(MassProfile):
     memory bound, :33-36,46) is accepted and unused.
 
     The fused kernels are built for the dPIE family (``DPIS``, ``DPIE``, ``DPIEP``) with scaling parameters among the
-    amplitude and the two radii -- what ``DPIESubhalo`` (dpie_subhalo.py) uses; only those can be part of a
-    ``PhysicalModel``.  Any other base profile -- another built-in kind, other scaling parameters, a user-written
-    ``hip_body`` -- is served at the plugin level the way the reference does it (:61-83): ``deriv`` / ``hessian`` evaluate the
-    base profile on ``chunk_size`` galaxies at a time and sum.
+    amplitude and the two radii -- what ``DPIESubhalo`` (dpie_subhalo.py) uses.  Any other base profile -- another built-in
+    kind, other scaling parameters, a user-written ``hip_body`` -- is served at the plugin level the way the reference does it
+    (:61-83): ``deriv`` / ``hessian`` evaluate the base profile on ``chunk_size`` galaxies at a time and sum.  Inside a
+    ``PhysicalModel`` such a population becomes ONE run-time compiled lens (csrc/gl_user.hip): the member loop around the base
+    profile's body -- its own ``hip_body``, or the restated body of a built-in kind (``_MEMBER_BODIES``: SIS, NFW) -- with the
+    catalogue as constants of the program and the gradient with respect to the scales from forward-mode duals.
     """
 
     _kind = 9
@@ -56,14 +99,45 @@ class ScalingRelation(MassProfile):
             raise KeyError(f"galaxy catalogue lacks the columns {missing}")
         self._slots = slots
         self._dev_table = None
+        if self._generic:
+            # inside a PhysicalModel such a population is ONE run-time compiled lens: the member loop around the base profile's
+            # body (its own `hip_body`, or the restated body of a built-in kind), catalogue and (L/L*)^power factors as constants
+            # of the program.  No body: the population stays a plugin-level object (deriv / hessian on points).
+            member = getattr(profile, "hip_body", "") or _MEMBER_BODIES.get(profile.name, "")
+            self._kind = 0
+            self.hip_body = self._member_loop_body(member) if member else ""
+
+    def _member_loop_body(self, member: str) -> str:
+        """`hip_body` of the population (scaling_relation.py:61-70 as one device function): for every galaxy the base profile's
+        body on parameters ``scale * (L/L*)^power`` (float32 product, :52-55) or the catalogue column, summed."""
+        import re
+        names = list(self.profile.params)
+        unscaled = self._unscaled()
+        rows = []
+        for g in range(self.n_galaxy):
+            vals = [unscaled[n][g] if n in self.scaling_params else np.float32(np.asarray(self.galaxy_cat[n], dtype=np.float32)[g])
+                    for n in names]
+            rows.append("{" + ", ".join(_float_literal(v) for v in vals) + "}")
+        q = "\n".join(
+            f"    q[{k}] = p[{self.scaling_params.index(n)}] * sr_cat[g][{k}];" if n in self.scaling_params
+            else f"    q[{k}] = R(sr_cat[g][{k}]);" for k, n in enumerate(names))
+        return (re.sub(r"\bderiv\b", "sr_member_deriv", member)
+                + f"\n__device__ const float sr_cat[{self.n_galaxy}][{len(names)}] = {{\n  " + ",\n  ".join(rows) + "\n};\n"
+                + "template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) {\n"
+                + "  fx = R(0.f);  fy = R(0.f);\n#pragma unroll 1\n"
+                + f"  for (int g = 0; g < {self.n_galaxy}; ++g) {{\n    R q[{len(names)}], ax, ay;\n" + q
+                + "\n    sr_member_deriv<R>(x, y, q, ax, ay);\n    fx += ax;  fy += ay;\n  }\n}\n")
 
     # -- what the native library consumes (include/gigalens_hip.h: gl_model_set_catalogue) --------------------------
     def _component(self):
-        if self._generic:
+        if self._generic and not self.hip_body:
             raise _native.NativeLibraryError(
-                f"ScalingRelation over {self.profile.name} with scales {self.scaling_params}: the pixel kernels sum populations of "
-                "dPIS, dPIE, dPIEP members scaled in amplitude and radii only; other populations are served at the plugin level "
-                "(deriv / hessian on points), not inside a PhysicalModel")
+                f"ScalingRelation over {self.profile.name} with scales {self.scaling_params}: inside a PhysicalModel the fused kernels "
+                "sum populations of dPIS, dPIE, dPIEP members scaled in amplitude and radii, and the run-time compiled member loop "
+                f"serves bases that carry a `hip_body` (user-written) or one of {sorted(_MEMBER_BODIES)}; this population is served at "
+                "the plugin level only (deriv / hessian on points)")
+        if self._generic:
+            return (0, 0, 0)  # -> _native.component_of: a GL_USER_MASS component compiled from self.hip_body
         return (self._kind, len(self.scaling_params), 0)
 
     def _unscaled(self):

@@ -164,7 +164,7 @@ class LensSimulator(LensSimulatorInterface):
                     lens.set_grid(self.img_X, self.img_Y)
                     lens.set_deriv()
                 self._model.set_series(i, lens.series_var_0, lens._coefs)
-            elif hasattr(lens, "_catalogue"):  # galaxy catalogues of ScalingRelation lenses
+            elif getattr(lens, "_kind", 0) == 9:  # galaxy catalogues of ScalingRelation lenses (fused dPIE-family kernels)
                 self._model.set_catalogue(i, *lens._catalogue())
         self._layout = phys_model._packing()
         assert self._layout.P == self._model.P

@@ -79,8 +79,10 @@ def test_scaling_relation_outside_the_dpie_family_is_refused():
     from gigalens_amd.profiles.light.sersic import Sersic
     from gigalens_amd.simulator import LensSimulator, SimulatorConfig
     cat = dict(lum=np.ones(3, np.float32), center_x=np.zeros(3, np.float32), center_y=np.zeros(3, np.float32))
-    # a population of NFW halos is served at the plugin level (tests/test_gpu_user_profile.py) but not inside a model
-    pop = ScalingRelation(NFW(), ["Rs"], 1.0, {"Rs": 0.5}, dict(cat, alpha_Rs=np.ones(3, np.float32)))
+    # populations of NFW / SIS / user-written members are compiled at run time (tests/test_gpu_user_profile.py); a base kind with
+    # neither a fused kernel nor a member body is served at the plugin level only
+    from gigalens_amd.profiles.mass.tnfw import TNFW
+    pop = ScalingRelation(TNFW(), ["Rs"], 1.0, {"Rs": 0.5}, dict(cat, alpha_Rs=np.ones(3, np.float32), r_trunc=np.ones(3, np.float32)))
     with pytest.raises(_native.NativeLibraryError, match="dPIS, dPIE, dPIEP"):
         LensSimulator(PhysicalModel([pop], [], [Sersic()]), SimulatorConfig(delta_pix=0.1, num_pix=8), bs=1)
     L = _native.lib()

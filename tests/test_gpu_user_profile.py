@@ -385,3 +385,73 @@ def test_linear_amplitude_solve_with_a_user_written_light(gl):
     assert abs(float(c_b[0, 0]) / (40.0 * 0.08 ** 2) - 1.0) < 0.1
     im_u, im_b = sim_u.lstsq_simulate(params, obs, err), sim_b.lstsq_simulate(params, obs, err)
     assert torch.allclose(im_u, im_b, rtol=2e-4, atol=2e-5 * float(im_b.abs().max()))
+
+
+@pytest.mark.parametrize("base", ["NFW", "SIS", "USER_SIS"])
+def test_population_over_any_base_profile_inside_a_model(gl, base):
+    """scaling_relation.py:8-19 wraps ANY MassProfile, and a PhysicalModel may hold the population.  Outside the dPIE family the
+    population becomes one run-time compiled lens: the member loop around the base profile's body (its own `hip_body`, or the
+    restated body of a built-in kind), catalogue as constants, gradient with respect to the scales from duals.  Against the
+    oracle's sum over members in float64 (oracle/ref_torch.py scaled_deriv): image, image VJP, log-likelihood and gradient; a
+    population of user-written members must equal the population of the built-in kind."""
+    from oracle import ref_torch as ref
+    from tests import helpers as H
+    from gigalens_amd.model import PhysicalModel
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.profiles.mass.epl import EPL
+    from gigalens_amd.profiles.mass.nfw import NFW
+    from gigalens_amd.profiles.mass.sis import SIS
+    from gigalens_amd.profiles.mass.scaling_relation import ScalingRelation
+    from gigalens_amd.simulator import LensSimulator, SimulatorConfig
+    UserSIS, _ = _profiles()
+    r = np.random.default_rng(11)
+    G, B, n = 9, 4, 36
+    cat = dict(lum=r.uniform(0.3, 2.0, G).astype(np.float32), center_x=r.uniform(-1.3, 1.3, G).astype(np.float32),
+               center_y=r.uniform(-1.3, 1.3, G).astype(np.float32))
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    if base == "NFW":
+        pop = ScalingRelation(NFW(), ["Rs", "alpha_Rs"], 1.2, {"Rs": 0.4, "alpha_Rs": 0.6}, cat)
+        scales = dict(Rs=t(r.uniform(0.3, 0.6, B)), alpha_Rs=t(r.uniform(0.05, 0.12, B)))
+        twin = None
+    else:
+        pop = ScalingRelation(UserSIS() if base == "USER_SIS" else SIS(), ["theta_E"], 1.2, {"theta_E": 0.5}, cat)
+        scales = dict(theta_E=t(r.uniform(0.04, 0.08, B)))
+        twin = ScalingRelation(SIS(), ["theta_E"], 1.2, {"theta_E": 0.5}, cat)
+    assert pop._generic and pop.hip_body
+    cfg = SimulatorConfig(delta_pix=0.08, num_pix=n)
+    phys = PhysicalModel([EPL(), pop], [], [Sersic()])
+    sim = LensSimulator(phys, cfg, bs=B)
+    params = {"lens_mass": [dict(theta_E=t(r.uniform(0.9, 1.1, B)), gamma=t(r.uniform(1.9, 2.1, B)), e1=t(r.normal(0.05, 0.03, B)),
+                                 e2=t(r.normal(-0.03, 0.03, B)), center_x=t(r.normal(0, 0.03, B)), center_y=t(r.normal(0, 0.03, B))), scales],
+              "source_light": [dict(R_sersic=t(r.uniform(0.2, 0.3, B)), n_sersic=t(r.uniform(1.5, 2.5, B)), center_x=t(r.normal(0.05, 0.05, B)),
+                                    center_y=t(r.normal(0, 0.05, B)), Ie=t(r.uniform(20, 40, B)))]}
+    packed = sim.pack(params)
+    # the oracle knows the population by the reference's name of its base profile
+    phys_o = phys if twin is None else PhysicalModel([EPL(), twin], [], [Sersic()])
+    rs = ref.RefSimulator(phys_o, cfg, B, dtype=torch.float64)
+    p64 = packed.cpu().double().requires_grad_(True)
+    img_o = rs.simulate(H.struct_from_packed(phys_o, p64))
+    img = sim.simulate(packed)
+    top = float(img_o.detach().abs().max())
+    assert np.allclose(img.cpu().numpy(), img_o.detach().numpy(), rtol=1e-4, atol=3e-5 * top), float((img.cpu() - img_o.detach()).abs().max()) / top
+    # image VJP
+    w = torch.tensor(r.normal(size=(B, n, n)), dtype=torch.float32)
+    (g_o,) = torch.autograd.grad((img_o * w.double()).sum(), p64, retain_graph=True)
+    v = sim._model.simulate_bwd(packed, w.cuda())
+    S = g_o.abs().amax(dim=0, keepdim=True).numpy()
+    assert np.all(np.abs(v.cpu().numpy() - g_o.numpy()) <= 2e-3 * S + 1e-6), (np.abs(v.cpu().numpy() - g_o.numpy()) / S).max()
+    # fused log-likelihood and gradient
+    obs = (img_o[0].detach() + 0.5 * torch.tensor(r.normal(size=(n, n)))).float()
+    ll, chi, g = sim._model.loglike(packed, obs.cuda(), None, None, 0.5, 100.0, True)
+    ll_o, _ = ref.stats_pixels(rs, H.struct_from_packed(phys_o, p64), obs.numpy(), 0.5, 100.0)
+    (gl_o,) = torch.autograd.grad(ll_o.sum(), p64)
+    assert np.allclose(ll.cpu().numpy(), ll_o.detach().numpy(), rtol=2e-5)
+    S = gl_o.abs().amax(dim=0, keepdim=True).numpy()
+    assert np.all(np.abs(g.cpu().numpy() - gl_o.numpy()) <= 2e-3 * S + 1e-6), (np.abs(g.cpu().numpy() - gl_o.numpy()) / S).max()
+    # the scales' columns carry a real gradient
+    lo = len(EPL().params)
+    assert np.all(np.abs(gl_o.numpy()[:, lo:lo + len(scales)]).max(axis=0) > 0)
+    # lens maps of the population through the plugin-level sum (tf/simulator.py:72-107)
+    xs, ys = sim.img_X[:50, None], sim.img_Y[:50, None]
+    kap = sim.convergence(xs, ys, params["lens_mass"])
+    assert kap.shape == (50, B) and bool(torch.isfinite(kap).all())

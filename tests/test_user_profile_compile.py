@@ -30,3 +30,33 @@ def test_compile_errors_come_back_verbatim():
         _native.user_profile_check(SIS_BODY, False, 100)
     with pytest.raises(_native.NativeLibraryError):  # a mass body offered as a light profile: no `light` to instantiate
         _native.user_profile_check(SIS_BODY, True, 3)
+
+
+def test_member_loop_bodies_of_populations_compile_without_a_gpu():
+    """ScalingRelation outside the dPIE family inside a model: the generated member loop around the base profile's body
+    (profiles/mass/scaling_relation.py `_member_loop_body`) is a valid user body for every base it is offered for."""
+    import numpy as np
+    from gigalens_amd.profile import MassProfile
+    from gigalens_amd.profiles.mass.nfw import NFW
+    from gigalens_amd.profiles.mass.sis import SIS
+    from gigalens_amd.profiles.mass.tnfw import TNFW
+    from gigalens_amd.profiles.mass.scaling_relation import ScalingRelation
+
+    class UserSIS(MassProfile):
+        _name, _params = "USER_SIS", ["theta_E", "center_x", "center_y"]
+        hip_body = SIS_BODY
+
+    cat = dict(lum=np.array([0.5, 1.0, 2.0], np.float32), center_x=np.array([0.1, -0.4, 0.9], np.float32),
+               center_y=np.array([0.3, 0.2, -0.7], np.float32), alpha_Rs=np.array([0.5, 0.6, 0.7], np.float32),
+               r_trunc=np.ones(3, np.float32))
+    for pop in (ScalingRelation(NFW(), ["Rs", "alpha_Rs"], 1.0, {"Rs": 0.4, "alpha_Rs": 0.5}, cat),
+                ScalingRelation(SIS(), ["theta_E"], 1.0, {"theta_E": 0.5}, cat),
+                ScalingRelation(UserSIS(), ["theta_E"], 1.0, {"theta_E": 0.5}, cat)):
+        assert pop._generic and "sr_member_deriv" in pop.hip_body and "sr_cat[3]" in pop.hip_body
+        assert pop._component() == (0, 0, 0) and pop._native_params() == pop.scaling_params
+        _native.user_profile_check(pop.hip_body, False, len(pop.scaling_params))
+    # a base with neither a fused kernel nor a member body: plugin level only, and the message says what is served
+    pop = ScalingRelation(TNFW(), ["Rs"], 1.0, {"Rs": 0.5}, cat)
+    assert pop._generic and not pop.hip_body
+    with pytest.raises(_native.NativeLibraryError, match="NFW.*SIS"):
+        pop._component()
