@@ -97,6 +97,7 @@ SYMBOLS = {
                                 c_void_p, c_void_p, c_void_p]),
     "gl_user_model_compile_count": (ctypes.c_longlong, []),
     "gl_user_profile_check": (c_int, [ctypes.c_char_p, c_int, c_int]),
+    "gl_user_points_check": (c_int, [ctypes.c_char_p, c_int]),
     "gl_user_profile_create": (c_int, [ctypes.c_char_p, c_int, c_int, POINTER(c_void_p)]),
     "gl_user_profile_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
@@ -212,6 +213,11 @@ def user_profile_of(profile):
     if key not in _USER_PROFILES:
         _USER_PROFILES[key] = _UserProfile(body, is_light, len(profile.params))
     return _USER_PROFILES[key]
+
+
+def user_points_check(body, n_params):
+    """Compile a mass body into the point kernels (image-position likelihood, lens maps: nested duals) without a GPU."""
+    _check(lib().gl_user_points_check(body.encode(), int(n_params)))
 
 
 def user_profile_check(body, is_light, n_params):

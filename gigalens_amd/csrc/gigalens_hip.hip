@@ -315,7 +315,8 @@ int run_order(const gl_model* m, int B, const Workspace& w, MainArgs* a, hipStre
 // image-position likelihood on the packed parameter rows `params` [B,P] (already on the device)
 int run_positions(const gl_model* m, const float* params, int B, const Workspace& w, bool want_grad, hipStream_t stream) {
   if (m->n_series) return fail(GL_EUNSUPPORTED, "a series-expansion lens lives on the pixel grid only (series_profile.py:76-81): no image-position likelihood");
-  if (m->has_user) return fail(GL_EUNSUPPORTED, "the image-position likelihood is not built for models with user-written profiles");
+  if (m->has_user)  // the four kernels below, compiled at run time with the user's bodies on the nested duals (once per model text)
+    if (int rc = compile_user_points(m)) return rc;
   PosArgs a{};
   a.comps = m->d_comps;
   a.n_lens = m->n_lens;
@@ -340,6 +341,19 @@ int run_positions(const gl_model* m, const float* params, int B, const Workspace
   a.gal_table = m->d_gal_table;
   a.gal_static = m->d_gal_static;
   auto blocks = [](long long n) { return dim3((unsigned)((n + 63) / 64)); };
+  if (m->has_user) {
+    int lens_params = m->lens_params;
+    void* args1[] = {&a};
+    void* args2[] = {&a, &lens_params};
+    auto go = [&](int k, long long n, void** args) {
+      return hipModuleLaunchKernel(m->user_point_fn[k], blocks(n).x, 1, 1, 64, 1, 1, 0, stream, args, nullptr);
+    };
+    GL_HIP(go(0, (long long)B * a.J, args1));
+    GL_HIP(go(1, (long long)B * a.F, args1));
+    if (want_grad && m->lens_params) GL_HIP(go(2, (long long)B * a.J * m->lens_params, args2));
+    GL_HIP(go(3, (long long)B * (a.P + 1), args2));
+    return GL_OK;
+  }
   hipLaunchKernelGGL(gl_pos_p1_kernel, blocks((long long)B * a.J), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(gl_pos_p2_kernel, blocks((long long)B * a.F), dim3(64), 0, stream, a);
   if (want_grad && m->lens_params)
@@ -998,6 +1012,7 @@ int gl_model_launch_shape(const gl_model* m, int B, int* chunk_px, int* n_chunks
 void gl_model_destroy(gl_model* m) {
   if (!m) return;
   if (m->user_module) (void)hipModuleUnload(m->user_module);
+  if (m->user_point_module) (void)hipModuleUnload(m->user_point_module);
   for (hipEvent_t e : m->evs) (void)hipEventDestroy(e);
   if (m->d_comps) (void)hipFree(m->d_comps);
   if (m->d_gx) (void)hipFree(m->d_gx);
@@ -1593,7 +1608,8 @@ int gl_profile_hessian(const gl_component* comp, const float* x, const float* y,
 int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, const float* y, int64_t n_pts,
                  int xy_batched, float* out, void* hip_stream) {
   if (!m || !params || !out) return fail(GL_EINVAL, "null argument");
-  if (m->has_user) return fail(GL_EUNSUPPORTED, "lens maps are not built for models with user-written profiles");
+  if (m->has_user)  // the kernel below compiled at run time with the user's bodies (Hessians from the duals)
+    if (int rc = compile_user_points(m)) return rc;
   if ((x == nullptr) != (y == nullptr)) return fail(GL_EINVAL, "x and y must both be given or both be null");
   if (B <= 0 || n_pts <= 0) return fail(GL_EINVAL, "B and n_pts must be positive");
   if ((int)m->cats.size() != m->n_scaled) return fail(GL_EINVAL, "GL_SCALED component without a catalogue");
@@ -1618,6 +1634,12 @@ int gl_lens_maps(const gl_model* m, const float* params, int B, const float* x, 
   a.gal_static = m->d_gal_static;
   a.series = m->d_series;
   const long long total = (long long)n_pts * B;
+  if (m->has_user) {
+    long long n_pts_ll = (long long)n_pts;
+    void* args[] = {&a, &x, &y, &n_pts_ll, &xy_batched, &out};
+    GL_HIP(hipModuleLaunchKernel(m->user_point_fn[4], (unsigned)((total + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)hip_stream, args, nullptr));
+    return GL_OK;
+  }
   hipLaunchKernelGGL(gl_lens_maps_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, a,
                      x, y, (long long)n_pts, xy_batched, out);
   GL_HIP(hipGetLastError());

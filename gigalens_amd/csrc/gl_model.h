@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
 #include <vector>
 
 #include <atomic>
@@ -60,6 +61,11 @@ struct gl_model {
   // ... and, for the compositions the pair kernel serves (EPL / SIE / Shear / SIS / user lenses | Sersic / user lights), that kernel
   // specialised on the model's component list with the user bodies inside (gl_pair_kernel<MODE, v2f, 2, KindList<...>, ...>)
   hipFunction_t user_pair_fn[4] = {nullptr, nullptr, nullptr, nullptr};
+  // ... and the point kernels (gl_positions.hip.h: image-position likelihood P1-P4, lens maps) with the bodies on nested duals,
+  // compiled from user_point_src when first asked for (gl_user.hip compile_user_points)
+  std::string user_point_src;
+  hipModule_t user_point_module = nullptr;
+  hipFunction_t user_point_fn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int height = 0, width = 0, supersample = 1, N = 0;
   float conversion_factor = 1.f;
   // device-resident, immutable
@@ -147,6 +153,7 @@ template <int MODE>
 int launch_main(const gl_model* m, const MainArgs& a, int B, int n_chunks, hipStream_t stream);
 // gl_user.hip: compile gl_main_kernel with the model's user bodies (n_bodies HIP C++ sources), fill user_module / user_fn
 __attribute__((visibility("hidden"))) int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies);
+__attribute__((visibility("hidden"))) int compile_user_points(const gl_model* m);
 int match_static(const gl_model* m);
 extern template int launch_main<IMG_FWD>(const gl_model*, const MainArgs&, int, int, hipStream_t);
 extern template int launch_main<IMG_BWD>(const gl_model*, const MainArgs&, int, int, hipStream_t);

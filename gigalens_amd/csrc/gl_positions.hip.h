@@ -42,10 +42,21 @@ struct PosArgs {
   const SeriesDev* series;
 };
 
+// parameters of one lens as the point kernels hold them: 7 for the built-in kinds; a user-written body (the run-time compiled
+// build of this header, gl_user.hip compile_user_points: GL_HAVE_USER_POINT) takes up to 16
+#ifdef GL_HAVE_USER_POINT
+constexpr int POS_MAXP = 16;
+#else
+constexpr int POS_MAXP = 7;
+#endif
+
 // deflection of one lens at (x, y) with raw parameters p, generic in the real type (catalogues are summed)
 template <class R> __device__ void lens_point(const PosArgs& a, const CompDesc& cd, const R* p, R x, R y, R& ax, R& ay) {
   using namespace glp;
   switch (cd.kind) {
+#ifdef GL_HAVE_USER_POINT
+    case K_USER_MASS: glu::mass_point<R>((int)cd.flags, p, x, y, ax, ay); break;  // the body on this number type (Hessian and mixed derivatives from the nested duals)
+#endif
     case K_EPL: epl_point<R>(p, cd.iparam, x, y, ax, ay); break;
     case K_SIE: { R d[SIE_ND + 1]; sie_prep<R>(p, d); sie_fwd<R>(d, x, y, ax, ay); } break;
     case K_NFW: { R d[NFW_ND]; nfw_prep<R>(p, d); nfw_fwd<R>(d, x, y, ax, ay); } break;
@@ -111,8 +122,8 @@ __global__ void __launch_bounds__(64) gl_pos_p1_kernel(PosArgs a) {
   float bx = a.px[j], by = a.py[j], fxx = 0.f, fxy = 0.f, fyx = 0.f, fyy = 0.f;
   for (int l = 0; l < a.n_lens; ++l) {
     CompDesc cd = a.comps[l];
-    R p[7];
-    float pf[7];
+    R p[POS_MAXP];
+    float pf[POS_MAXP];
     for (int k = 0; k < cd.n_par; ++k) { pf[k] = a.params[(size_t)b * a.P + cd.p_off + k]; p[k] = R(pf[k]); }
     R ax, ay;
     lens_point<R>(a, cd, p, x, y, ax, ay);
@@ -142,8 +153,8 @@ __global__ void __launch_bounds__(64) gl_lens_maps_kernel(PosArgs a, const float
   float bx = px, by = py, fxx = 0.f, fxy = 0.f, fyx = 0.f, fyy = 0.f;
   for (int l = 0; l < a.n_lens; ++l) {
     CompDesc cd = a.comps[l];
-    R p[7];
-    float pf[7];
+    R p[POS_MAXP];
+    float pf[POS_MAXP];
     for (int k = 0; k < cd.n_par; ++k) { pf[k] = a.params[(size_t)b * a.P + cd.p_off + k]; p[k] = R(pf[k]); }
     if (cd.kind == glp::K_SERIES) {  // host guarantees: points = the model grid, both fields attached
       const SeriesDev sv = a.series[cd.flags];
@@ -293,9 +304,9 @@ __global__ void __launch_bounds__(64) gl_pos_p3_kernel(PosArgs a, int lens_param
   R x(R1(a.px[j])), y(R1(a.py[j]));
   x.d[0] = R1(1.f);
   y.d[1] = R1(1.f);
-  R p[7];
-  R1 p1[7];
-  for (int m = 0; m < 7; ++m) {
+  R p[POS_MAXP];
+  R1 p1[POS_MAXP];
+  for (int m = 0; m < POS_MAXP; ++m) {
     R1 v(m < cd.n_par ? a.params[(size_t)b * a.P + cd.p_off + m] : 0.f);
     if (m == k) v.d[0] = 1.f;
     p1[m] = v;

@@ -209,8 +209,7 @@ namespace glk {
 // the same bodies -- the seconds of hiprtc are paid once per process, a model only loads the code object
 struct UserCode {
   std::vector<char> code;
-  std::string lowered[5];       // [4] = the basis-stack kernel (models with linear columns), else empty
-  std::string lowered_pair[4];  // empty: the composition is not one the pair kernel serves
+  std::vector<std::string> lowered;  // of the name expressions, in the caller's order
 };
 static std::mutex g_user_mu;
 static std::map<std::string, std::shared_ptr<const UserCode>>& user_cache() {
@@ -218,6 +217,129 @@ static std::map<std::string, std::shared_ptr<const UserCode>>& user_cache() {
   return c;
 }
 static std::atomic<long long> g_user_compiles{0};
+
+// program text + name expressions -> code object and lowered names, compiled once per distinct text and process
+static int rtc_compile_cached(const std::string& src, const std::vector<std::string>& names, std::shared_ptr<const UserCode>& out) {
+  const char* dev_dir = getenv("GIGALENS_HIP_CSRC");
+  std::lock_guard<std::mutex> lock(g_user_mu);  // (also serialises concurrent compiles of the same text: the second finds the first's)
+  const std::string key = src + (dev_dir ? std::string("\n//csrc=") + dev_dir : std::string());
+  auto it = user_cache().find(key);
+  if (it != user_cache().end()) {
+    out = it->second;
+    return GL_OK;
+  }
+  hiprtcProgram prog = nullptr;
+  const hiprtcResult rcc = dev_dir ? hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", 0, nullptr, nullptr)
+                                   : hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", kEmbeddedCount, kEmbeddedSources, kEmbeddedNames);
+  if (rcc != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcCreateProgram failed");
+  for (const std::string& n : names) (void)hiprtcAddNameExpression(prog, n.c_str());
+  const std::string inc = std::string("-I") + (dev_dir ? dev_dir : ".");
+  // (-fno-slp-vectorize: as for the interpreter of the library itself, gl_launch_generic.hip.h)
+  // (-fno-hip-fp32-correctly-rounded-divide-sqrt: a user body's `/` and sqrt as the hardware reciprocal / square root with
+  // one Newton step -- 2.5 ulp, what the built-in kinds' v_rcp / v_sqrt wrappers deliver -- instead of the correctly rounded
+  // sequences: a body is evaluated on n_params + 2 tangents, every division of which was ~10 instructions)
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", inc.c_str()};
+  const hiprtcResult rc = hiprtcCompileProgram(prog, dev_dir ? 6 : 5, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    (void)hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n ? n : 1, '\0');
+    if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+    (void)hiprtcDestroyProgram(&prog);
+    const size_t at = log.find("error");
+    const size_t from = at == std::string::npos ? 0 : log.rfind('\n', at) == std::string::npos ? 0 : log.rfind('\n', at) + 1;
+    return fail(GL_EINVAL, "user profile does not compile (%s; kernel headers %s):\n%.330s", hiprtcGetErrorString(rc),
+                dev_dir ? dev_dir : "embedded in the library", log.c_str() + from);
+  }
+  auto fresh = std::make_shared<UserCode>();
+  for (const std::string& n : names) {
+    const char* ln = nullptr;
+    if (hiprtcGetLoweredName(prog, n.c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+      (void)hiprtcDestroyProgram(&prog);
+      return fail(GL_ELAUNCH, "hiprtcGetLoweredName failed for %s", n.c_str());
+    }
+    fresh->lowered.push_back(ln);
+  }
+  size_t code_size = 0;
+  if (hiprtcGetCodeSize(prog, &code_size) != HIPRTC_SUCCESS || !code_size) {
+    (void)hiprtcDestroyProgram(&prog);
+    return fail(GL_ELAUNCH, "hiprtcGetCodeSize failed");
+  }
+  fresh->code.resize(code_size);
+  const hiprtcResult rc2 = hiprtcGetCode(prog, fresh->code.data());
+  (void)hiprtcDestroyProgram(&prog);
+  if (rc2 != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcGetCode failed");
+  g_user_compiles.fetch_add(1);
+  user_cache()[key] = fresh;
+  out = fresh;
+  return GL_OK;
+}
+
+// What a user body needs from the nested duals of the point kernels (gl_dual.h: gld::Dual<T, N>, T = float or a dual again): the
+// vocabulary of the prelude above under the same names -- found by argument-dependent lookup when the body is instantiated on
+// gld::Dual<float, 2> (Hessians) and gld::Dual<gld::Dual<float, 1>, 2> (their parameter derivatives).
+static const char* kGldVocabulary = R"GLSRC(
+#include "gl_dual.h"
+namespace gld {
+#define GLD_U template <class T, int N> __device__ inline
+GLD_U Dual<T, N> sqrt(const Dual<T, N>& a) { return l_sqrt(a); }
+GLD_U Dual<T, N> exp(const Dual<T, N>& a) { return l_exp(a); }
+GLD_U Dual<T, N> log(const Dual<T, N>& a) { return l_log(a); }
+GLD_U Dual<T, N> sin(const Dual<T, N>& a) { return l_sin(a); }
+GLD_U Dual<T, N> cos(const Dual<T, N>& a) { return l_cos(a); }
+GLD_U Dual<T, N> tan(const Dual<T, N>& a) { return l_sin(a) / l_cos(a); }
+GLD_U Dual<T, N> atan(const Dual<T, N>& a) { return l_atan(a); }
+GLD_U Dual<T, N> atanh(const Dual<T, N>& a) { return l_atanh(a); }
+GLD_U Dual<T, N> atan2(const Dual<T, N>& y, const Dual<T, N>& x) { return l_atan2(y, x); }
+GLD_U Dual<T, N> sinh(const Dual<T, N>& a) { const Dual<T, N> e = l_exp(a); return (e - Dual<T, N>(T(1)) / e) * Dual<T, N>(T(0.5f)); }
+GLD_U Dual<T, N> cosh(const Dual<T, N>& a) { const Dual<T, N> e = l_exp(a); return (e + Dual<T, N>(T(1)) / e) * Dual<T, N>(T(0.5f)); }
+GLD_U Dual<T, N> tanh(const Dual<T, N>& a) { const Dual<T, N> e = l_exp(a + a); return (e - Dual<T, N>(T(1))) / (e + Dual<T, N>(T(1))); }
+GLD_U Dual<T, N> abs(const Dual<T, N>& a) { return fabs_(a); }
+GLD_U Dual<T, N> fabs(const Dual<T, N>& a) { return fabs_(a); }
+GLD_U Dual<T, N> fmin(const Dual<T, N>& a, const Dual<T, N>& b) { return fmin_(a, b); }
+GLD_U Dual<T, N> fmax(const Dual<T, N>& a, const Dual<T, N>& b) { return fmax_(a, b); }
+GLD_U Dual<T, N> pow(const Dual<T, N>& a, const Dual<T, N>& b) { return l_pow(a, b); }
+template <class T, int N, class S> __device__ inline auto pow(const Dual<T, N>& a, S b) -> decltype(Dual<T, N>((float)b)) { return l_pow(a, Dual<T, N>((float)b)); }
+template <class T, int N, class S> __device__ inline auto pow(S a, const Dual<T, N>& b) -> decltype(Dual<T, N>((float)a)) { return l_exp(b * Dual<T, N>(::logf((float)a))); }
+GLD_U float value(const Dual<T, N>& a) { return (float)val(a); }
+#define GLD_MIXED(OP) \
+  template <class T, int N, class S> __device__ inline auto operator OP(const Dual<T, N>& a, S b) -> decltype(a OP Dual<T, N>((float)b)) { return a OP Dual<T, N>((float)b); } \
+  template <class T, int N, class S> __device__ inline auto operator OP(S a, const Dual<T, N>& b) -> decltype(Dual<T, N>((float)a) OP b) { return Dual<T, N>((float)a) OP b; }
+GLD_MIXED(+) GLD_MIXED(-) GLD_MIXED(*) GLD_MIXED(/)
+GLD_MIXED(<) GLD_MIXED(>) GLD_MIXED(<=) GLD_MIXED(>=) GLD_MIXED(==)
+#undef GLD_MIXED
+GLD_U bool operator!=(const Dual<T, N>& a, const Dual<T, N>& b) { return val(a) != val(b); }
+GLD_U Dual<T, N>& operator/=(Dual<T, N>& a, const Dual<T, N>& b) { a = a / b; return a; }
+GLD_U Dual<T, N> operator+(const Dual<T, N>& a) { return a; }
+template <class T, int N, class S> __device__ inline auto operator+=(Dual<T, N>& a, S b) -> decltype(a = a + Dual<T, N>((float)b)) { a = a + Dual<T, N>((float)b); return a; }
+template <class T, int N, class S> __device__ inline auto operator-=(Dual<T, N>& a, S b) -> decltype(a = a - Dual<T, N>((float)b)) { a = a - Dual<T, N>((float)b); return a; }
+template <class T, int N, class S> __device__ inline auto operator*=(Dual<T, N>& a, S b) -> decltype(a = a * Dual<T, N>((float)b)) { a = a * Dual<T, N>((float)b); return a; }
+template <class T, int N, class S> __device__ inline auto operator/=(Dual<T, N>& a, S b) -> decltype(a = a / Dual<T, N>((float)b)) { a = a / Dual<T, N>((float)b); return a; }
+#undef GLD_U
+}  // namespace gld
+)GLSRC";
+
+// program text of the point kernels for a set of bodies (npar[w] < 0: body w unused; light[w]: it is a light profile)
+static std::string point_program(const std::string& body_text, const std::vector<int>& npar, const std::vector<int>& light) {
+  std::string ps = std::string("#define GL_HAVE_USER_POINT 1\n") + kGldVocabulary + kPrelude + body_text +
+                   "#line 1 \"gl_user_point_glue\"\nnamespace glu {\n"
+                   "template <class R> __device__ inline void mass_point(int which, const R* p, R x, R y, R& ax, R& ay) {\n  ax = R(0.f);  ay = R(0.f);\n  switch (which) {\n";
+  for (size_t w = 0; w < npar.size(); ++w)
+    if (npar[w] >= 0 && light[w] == 0) ps += "    case " + std::to_string(w) + ": glu_body" + std::to_string(w) + "::deriv<R>(x, y, p, ax, ay); break;\n";
+  ps += "  }\n}\n}  // namespace glu\n#include \"gl_positions.hip.h\"\n";
+  return ps;
+}
+static const char* const kPointKernels[5] = {"glk::gl_pos_p1_kernel", "glk::gl_pos_p2_kernel", "glk::gl_pos_p3_kernel", "glk::gl_pos_p4_kernel",
+                                             "glk::gl_lens_maps_kernel"};
+
+// a mass body through the point kernels' compile, no device needed (gl_user_points_check)
+int check_user_points(const char* body, int n_params) {
+  if (!body) return fail(GL_EINVAL, "body is null");
+  if (n_params < 0 || n_params > 16) return fail(GL_EINVAL, "n_params %d outside [0, 16]", n_params);
+  const std::string text = std::string("namespace glu_body0 {\n#line 1 \"user_profile_0\"\n") + body + "\n}\n";
+  std::shared_ptr<const UserCode> uc;
+  return rtc_compile_cached(point_program(text, {n_params}, {0}), std::vector<std::string>(kPointKernels, kPointKernels + 5), uc);
+}
 
 int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
   // which body serves which kind, with how many parameters (a body used by several components must agree with itself)
@@ -232,10 +354,14 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
   }
   std::string src = "#define GL_HAVE_USER 1\n";
   src += kPrelude;
+  std::string body_text;
   for (int w = 0; w < n_bodies; ++w) {
     if (npar[w] < 0) continue;
-    src += "namespace glu_body" + std::to_string(w) + " {\n#line 1 \"user_profile_" + std::to_string(w) + "\"\n" + bodies[w] + "\n}\n";
+    body_text += "namespace glu_body" + std::to_string(w) + " {\n#line 1 \"user_profile_" + std::to_string(w) + "\"\n" + bodies[w] + "\n}\n";
   }
+  src += body_text;
+  // the program of the point kernels (image-position likelihood, lens maps; compiled when first asked for: compile_user_points)
+  m->user_point_src = point_program(body_text, npar, light);
   auto cases = [&](int want_light, const char* fmt_body) {
     std::string out;
     for (int w = 0; w < n_bodies; ++w) {
@@ -309,76 +435,34 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
       }
     }
   }
-  const char* dev_dir = getenv("GIGALENS_HIP_CSRC");
+  std::vector<std::string> all_names(names, names + n_modes);
+  if (pair_ok) all_names.insert(all_names.end(), pair_names, pair_names + 4);
   std::shared_ptr<const UserCode> uc;
-  {
-    std::lock_guard<std::mutex> lock(g_user_mu);  // (also serialises concurrent compiles of the same text: the second finds the first's)
-    const std::string key = src + (dev_dir ? std::string("\n//csrc=") + dev_dir : std::string());
-    auto it = user_cache().find(key);
-    if (it != user_cache().end()) {
-      uc = it->second;
-    } else {
-      hiprtcProgram prog = nullptr;
-      const hiprtcResult rcc = dev_dir ? hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", 0, nullptr, nullptr)
-                                       : hiprtcCreateProgram(&prog, src.c_str(), "gl_user_model.hip", kEmbeddedCount, kEmbeddedSources, kEmbeddedNames);
-      if (rcc != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcCreateProgram failed");
-      for (int mode = 0; mode < n_modes; ++mode) (void)hiprtcAddNameExpression(prog, names[mode].c_str());
-      if (pair_ok)
-        for (int mode = 0; mode < 4; ++mode) (void)hiprtcAddNameExpression(prog, pair_names[mode].c_str());
-      const std::string inc = std::string("-I") + (dev_dir ? dev_dir : ".");
-      // (-fno-slp-vectorize: as for the interpreter of the library itself, gl_launch_generic.hip.h)
-      // (-fno-hip-fp32-correctly-rounded-divide-sqrt: a user body's `/` and sqrt as the hardware reciprocal / square root with
-      // one Newton step -- 2.5 ulp, what the built-in kinds' v_rcp / v_sqrt wrappers deliver -- instead of the correctly rounded
-      // sequences: a body is evaluated on n_params + 2 tangents, every division of which was ~10 instructions)
-      const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", inc.c_str()};
-      const hiprtcResult rc = hiprtcCompileProgram(prog, dev_dir ? 6 : 5, opts);
-      if (rc != HIPRTC_SUCCESS) {
-        size_t n = 0;
-        (void)hiprtcGetProgramLogSize(prog, &n);
-        std::string log(n ? n : 1, '\0');
-        if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
-        (void)hiprtcDestroyProgram(&prog);
-        const size_t at = log.find("error");
-        const size_t from = at == std::string::npos ? 0 : log.rfind('\n', at) == std::string::npos ? 0 : log.rfind('\n', at) + 1;
-        return fail(GL_EINVAL, "user profile does not compile (%s; kernel headers %s):\n%.330s", hiprtcGetErrorString(rc),
-                    dev_dir ? dev_dir : "embedded in the library", log.c_str() + from);
-      }
-      auto fresh = std::make_shared<UserCode>();
-      for (int mode = 0; mode < n_modes; ++mode) {
-        const char* ln = nullptr;
-        if (hiprtcGetLoweredName(prog, names[mode].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
-          (void)hiprtcDestroyProgram(&prog);
-          return fail(GL_ELAUNCH, "hiprtcGetLoweredName failed for %s", names[mode].c_str());
-        }
-        fresh->lowered[mode] = ln;
-        if (pair_ok && mode < 4) {
-          if (hiprtcGetLoweredName(prog, pair_names[mode].c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
-            (void)hiprtcDestroyProgram(&prog);
-            return fail(GL_ELAUNCH, "hiprtcGetLoweredName failed for %s", pair_names[mode].c_str());
-          }
-          fresh->lowered_pair[mode] = ln;
-        }
-      }
-      size_t code_size = 0;
-      if (hiprtcGetCodeSize(prog, &code_size) != HIPRTC_SUCCESS || !code_size) {
-        (void)hiprtcDestroyProgram(&prog);
-        return fail(GL_ELAUNCH, "hiprtcGetCodeSize failed");
-      }
-      fresh->code.resize(code_size);
-      const hiprtcResult rc2 = hiprtcGetCode(prog, fresh->code.data());
-      (void)hiprtcDestroyProgram(&prog);
-      if (rc2 != HIPRTC_SUCCESS) return fail(GL_ELAUNCH, "hiprtcGetCode failed");
-      g_user_compiles.fetch_add(1);
-      user_cache()[key] = fresh;
-      uc = fresh;
-    }
-  }
+  if (int rc = rtc_compile_cached(src, all_names, uc)) return rc;
   hipError_t e = hipModuleLoadData(&m->user_module, uc->code.data());
-  for (int mode = 0; mode < 5 && e == hipSuccess; ++mode)
-    if (!uc->lowered[mode].empty()) e = hipModuleGetFunction(&m->user_fn[mode], m->user_module, uc->lowered[mode].c_str());
-  for (int mode = 0; mode < 4 && e == hipSuccess; ++mode)
-    if (!uc->lowered_pair[mode].empty()) e = hipModuleGetFunction(&m->user_pair_fn[mode], m->user_module, uc->lowered_pair[mode].c_str());
+  for (int mode = 0; mode < n_modes && e == hipSuccess; ++mode)
+    e = hipModuleGetFunction(&m->user_fn[mode], m->user_module, uc->lowered[mode].c_str());
+  for (int mode = 0; mode < 4 && pair_ok && e == hipSuccess; ++mode)
+    e = hipModuleGetFunction(&m->user_pair_fn[mode], m->user_module, uc->lowered[n_modes + mode].c_str());
   if (e != hipSuccess) return fail(GL_ELAUNCH, "loading the compiled user model failed: %s", hipGetErrorString(e));
+  return GL_OK;
+}
+
+// The point kernels of a model with user-written lenses (gl_positions.hip.h: the four kernels of the image-position likelihood
+// and the lens-maps kernel), compiled with the bodies on the nested duals when first asked for -- most models never are.
+int compile_user_points(const gl_model* cm) {
+  gl_model* m = const_cast<gl_model*>(cm);
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (m->user_point_fn[0]) return GL_OK;
+  if (m->user_point_src.empty()) return fail(GL_EINVAL, "model without user-written profiles");
+  std::shared_ptr<const UserCode> uc;
+  if (int rc = rtc_compile_cached(m->user_point_src, std::vector<std::string>(kPointKernels, kPointKernels + 5), uc)) return rc;
+  hipFunction_t fn[5] = {};
+  hipError_t e = hipModuleLoadData(&m->user_point_module, uc->code.data());
+  for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipModuleGetFunction(&fn[k], m->user_point_module, uc->lowered[k].c_str());
+  if (e != hipSuccess) return fail(GL_ELAUNCH, "loading the compiled point kernels failed: %s", hipGetErrorString(e));
+  for (int k = 4; k >= 0; --k) m->user_point_fn[k] = fn[k];  // [0] last: it is the "compiled" flag
   return GL_OK;
 }
 
@@ -387,6 +471,8 @@ int compile_user_model(gl_model* m, const char* const* bodies, int n_bodies) {
 extern "C" {
 
 long long gl_user_model_compile_count(void) { return glk::g_user_compiles.load(); }
+
+int gl_user_points_check(const char* body, int n_params) { return glk::check_user_points(body, n_params); }
 
 int gl_user_profile_check(const char* body, int is_light, int n_params) {
   std::vector<char> code;

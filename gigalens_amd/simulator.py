@@ -182,16 +182,6 @@ class LensSimulator(LensSimulatorInterface):
         return beta_x, beta_y
 
     def _lens_maps(self, x, y, lens_params):
-        if any(getattr(l, "hip_body", "") and not getattr(l, "_kind", 0) for l in self.phys_model.lenses):
-            # user-written lenses: the maps as the reference forms them (tf/simulator.py:72-107), lens by lens through the
-            # plugin-level kernels (a user body's Hessian comes from its forward-mode duals)
-            if torch.is_tensor(lens_params):
-                raise NotImplementedError("lens maps of a model with user-written lenses take the parameter dictionaries")
-            bx, by = self.beta(x, y, lens_params)
-            h = [0.0, 0.0, 0.0, 0.0]
-            for lens, p, c in zip(self.phys_model.lenses, lens_params, self.phys_model.lenses_constants):
-                h = [a + b for a, b in zip(h, lens.hessian(x, y, **p, **c))]
-            return (bx, by, *h)
         packed = self._pack_partial({"lens_mass": lens_params}) if not torch.is_tensor(lens_params) else lens_params
         series = [(i, l) for i, l in enumerate(self.phys_model.lenses) if getattr(l, "_kind", 0) == 10]
         if not series:

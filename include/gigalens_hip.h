@@ -357,8 +357,10 @@ int gl_model_launch_shape(const gl_model* m, int B, int* chunk_px, int* n_chunks
  * `bodies`) make gl_model_create_user compile the interpreter kernel of the likelihood path at run time with those bodies in it:
  * simulate / log-likelihood / fused log-prob and their gradients (forward-mode duals of the body) work as for built-in kinds.
  * The linear-amplitude solve serves them too (round 4: a user-written light with `reserved = 1` contributes one basis image).
- * Not served for such models: the image-position likelihood, lens maps (typed refusals; LensSimulator forms the maps lens by lens
- * through the plugin-level kernels instead). */
+ * The image-position likelihood and gl_lens_maps serve them as well (round 4): their kernels are compiled -- when first asked for
+ * -- with the mass bodies on the nested duals of the point kernels (Hessians and their parameter derivatives by differentiating
+ * `deriv`, as the reference does for every profile, tf/profile.py:9-43).  gl_user_points_check: that compile alone, for one mass
+ * body, no device needed. */
 int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light, int n_src, const gl_grid* grid,
                          const char* const* bodies, int n_bodies, gl_model** out);
 /* The compiled interpreter is cached per process, keyed on the program text (bodies, parameter counts, shapelet / family
@@ -366,6 +368,7 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
  * one hiprtc compile.  The kernel headers the compile includes are embedded in the library (no source checkout needed).
  * gl_user_model_compile_count: hiprtc compiles of model kernels this process has paid for so far (diagnostics, tests). */
 long long gl_user_model_compile_count(void);
+int gl_user_points_check(const char* body, int n_params);
 typedef struct gl_user_profile gl_user_profile;
 int gl_user_profile_check(const char* body, int is_light, int n_params);
 int gl_user_profile_create(const char* body, int is_light, int n_params, gl_user_profile** out);

@@ -210,10 +210,10 @@ def test_user_written_profiles_inside_a_model_equal_the_built_in_kinds(gl):
     v_u, v_b = mu.simulate_bwd(pu, w), mb.simulate_bwd(pb, w)
     vs = v_b.abs().amax(dim=0, keepdim=True)
     assert torch.all((v_u - v_b).abs() <= 2e-3 * vs + 1e-6)
-    from gigalens_amd import _native
-    with pytest.raises(_native.NativeLibraryError, match="not built for models with user-written"):
-        mu.lens_maps(pu, None, None)
-    # ... the simulator forms the maps lens by lens instead (tf/simulator.py:72-107)
+    # lens maps (tf/simulator.py:72-107): the fused kernel compiled with the bodies on the nested duals of the point kernels
+    maps_u, maps_b = mu.lens_maps(pu, None, None), mb.lens_maps(pb, None, None)
+    for a, b2 in zip(maps_u, maps_b):
+        assert torch.allclose(a, b2, rtol=2e-4, atol=2e-5)
     xs, ys = sim_b.img_X[:200, None], sim_b.img_Y[:200, None]
     for fn in ("magnification", "convergence"):
         a, b2 = getattr(sim_u, fn)(xs, ys, params["lens_mass"]), getattr(sim_b, fn)(xs, ys, params["lens_mass"])
@@ -455,3 +455,73 @@ def test_population_over_any_base_profile_inside_a_model(gl, base):
     xs, ys = sim.img_X[:50, None], sim.img_Y[:50, None]
     kap = sim.convergence(xs, ys, params["lens_mass"])
     assert kap.shape == (50, B) and bool(torch.isfinite(kap).all())
+
+
+def test_image_position_likelihood_with_user_written_lenses(gl):
+    """tf/model.py:103-124 on a model whose lens is user-written: beta and the magnification at the image positions need the body's
+    Hessian and, for the gradient, its mixed second derivatives -- the four position kernels are compiled at run time with the body
+    on the nested duals (Dual<float, 2>, Dual<Dual<float, 1>, 2>).  Same numbers as the built-in twin; a population of user-written
+    members (the generated member loop) against the oracle."""
+    import math
+    from oracle import ref_torch as ref
+    from tests import helpers as H
+    from gigalens_amd import prior as tfd
+    from gigalens_amd.model import ForwardProbModel, PhysicalModel
+    from gigalens_amd.profiles.light.sersic import Sersic
+    from gigalens_amd.profiles.mass.scaling_relation import ScalingRelation
+    from gigalens_amd.profiles.mass.shear import Shear
+    from gigalens_amd.profiles.mass.sis import SIS
+    from gigalens_amd.simulator import LensSimulator, SimulatorConfig
+    UserSIS, _ = _profiles()
+    J, S = tfd.JointDistributionNamed, tfd.JointDistributionSequential
+    r = np.random.default_rng(21)
+    cat = dict(lum=r.uniform(0.5, 1.5, 5).astype(np.float32), center_x=r.uniform(-1.5, 1.5, 5).astype(np.float32),
+               center_y=r.uniform(-1.5, 1.5, 5).astype(np.float32))
+    pop_u = ScalingRelation(UserSIS(), ["theta_E"], 1.0, {"theta_E": 0.5}, cat)
+    pop_b = ScalingRelation(SIS(), ["theta_E"], 1.0, {"theta_E": 0.5}, cat)
+    prior = J(dict(lens_mass=S([J(dict(theta_E=tfd.LogNormal(math.log(1.2), 0.1), center_x=tfd.Normal(0, 0.05), center_y=tfd.Normal(0, 0.05))),
+                                J(dict(gamma1=tfd.Normal(0, 0.05), gamma2=tfd.Normal(0, 0.05))),
+                                J(dict(theta_E=tfd.LogNormal(math.log(0.05), 0.2)))]),
+                   source_light=S([J(dict(R_sersic=tfd.LogNormal(math.log(0.3), 0.1), n_sersic=tfd.Uniform(1, 3), center_x=tfd.Normal(0, 0.1),
+                                          center_y=tfd.Normal(0, 0.1), Ie=tfd.LogNormal(math.log(40.0), 0.2)))])))
+    cfg = SimulatorConfig(delta_pix=0.08, num_pix=16)
+    B = 5
+    phys_u = PhysicalModel([UserSIS(), Shear(), pop_u], [], [Sersic()])
+    phys_b = PhysicalModel([SIS(), Shear(), pop_b], [], [Sersic()])
+    sim_u, sim_b = LensSimulator(phys_u, cfg, bs=B), LensSimulator(phys_b, cfg, bs=B)
+    cx = [np.array([1.25, -1.15, 0.2, -0.3], np.float32), np.array([0.9, -0.95], np.float32)]
+    cy = [np.array([0.3, -0.25, 1.2, -1.22], np.float32), np.array([-0.9, 0.95], np.float32)]
+    ex = [np.full(4, 0.01, np.float32), np.full(2, 0.02, np.float32)]
+    pm = ForwardProbModel(prior, centroids_x=cx, centroids_y=cy, centroids_errors_x=ex, centroids_errors_y=ex,
+                          include_pixels=False, include_positions=True)
+    packed = sim_u.pack(prior.sample(B, seed=2))
+    pu, pb = packed.clone().requires_grad_(True), packed.clone().requires_grad_(True)
+    ll_u, red_u = pm.stats_positions(sim_u, pu)
+    ll_b, red_b = pm.stats_positions(sim_b, pb)
+    ll_u.sum().backward()
+    ll_b.sum().backward()
+    assert torch.allclose(ll_u, ll_b, rtol=1e-4) and torch.allclose(red_u, red_b, rtol=1e-4)
+    sc = pb.grad.abs().amax(dim=1, keepdim=True)
+    assert torch.all((pu.grad - pb.grad).abs() <= 2e-3 * torch.maximum(pb.grad.abs(), 1e-2 * sc) + 1e-6)
+    # ... and both against the oracle (float64, autograd through the member sum)
+    rs = ref.RefSimulator(phys_b, cfg, B, dtype=torch.float64)
+    p64 = packed.cpu().double().requires_grad_(True)
+    ll_o, red_o = ref.stats_positions(rs, H.struct_from_packed(phys_b, p64), cx, cy, ex, ex)
+    (g_o,) = torch.autograd.grad(ll_o.sum(), p64)
+    assert np.allclose(ll_u.detach().cpu().numpy(), ll_o.detach().numpy(), rtol=1e-4)
+    g, go = pu.grad.cpu().numpy(), g_o.numpy()
+    scale = np.abs(go).max(axis=1, keepdims=True)
+    assert np.all(np.abs(g - go) <= 2e-3 * np.maximum(np.abs(go), 1e-2 * scale) + 1e-6), (np.abs(g - go) / scale).max()
+    # the fused log-prob with both likelihood terms (tf/model.py:126-162) off the same model
+    obs = (sim_b.simulate(packed)[0] + 0.3 * torch.randn(16, 16, device="cuda")).cpu().numpy()
+    pm2 = ForwardProbModel(prior, obs, 0.3, 100.0, centroids_x=cx, centroids_y=cy, centroids_errors_x=ex, centroids_errors_y=ex,
+                           include_pixels=True, include_positions=True)
+    z = pm2.bij.inverse(prior.sample(B, seed=2)).to("cuda")
+    zu, zb = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    lp_u, _ = pm2.log_prob(sim_u, zu)
+    lp_b, _ = pm2.log_prob(sim_b, zb)
+    lp_u.sum().backward()
+    lp_b.sum().backward()
+    assert torch.allclose(lp_u, lp_b, rtol=1e-4)
+    sc = zb.grad.abs().amax(dim=1, keepdim=True)
+    assert torch.all((zu.grad - zb.grad).abs() <= 2e-3 * torch.maximum(zb.grad.abs(), 1e-2 * sc) + 1e-5)

@@ -60,3 +60,30 @@ def test_member_loop_bodies_of_populations_compile_without_a_gpu():
     assert pop._generic and not pop.hip_body
     with pytest.raises(_native.NativeLibraryError, match="NFW.*SIS"):
         pop._component()
+
+
+def test_mass_bodies_compile_for_the_point_kernels_without_a_gpu():
+    """The image-position likelihood and the lens maps evaluate a user-written lens on NESTED duals (gld::Dual<float, 2>,
+    gld::Dual<gld::Dual<float, 1>, 2>, csrc/gl_dual.h): the body's vocabulary -- arithmetic with plain numbers, comparisons, value(),
+    the math functions -- must resolve on those types too."""
+    import numpy as np
+    from gigalens_amd.profiles.mass.nfw import NFW
+    from gigalens_amd.profiles.mass.scaling_relation import ScalingRelation
+    _native.user_points_check(SIS_BODY, 3)
+    cat = dict(lum=np.array([0.5, 2.0], np.float32), center_x=np.array([0.1, -0.4], np.float32), center_y=np.array([0.3, 0.2], np.float32),
+               alpha_Rs=np.array([0.5, 0.6], np.float32))
+    _native.user_points_check(ScalingRelation(NFW(), ["Rs"], 1.0, {"Rs": 0.4}, cat).hip_body, 1)
+    everything = """
+    template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) {
+      R dx = x - p[1], dy = 2.f * (y - p[2]) / 2.f;
+      R r = sqrt(dx * dx + dy * dy) + 1e-3f;
+      R a = p[0] * (exp(-r) + log(1.f + r) + pow(r, 1.5f) + pow(r, p[3]) + pow(2.f, -r) + sin(r) * cos(r) + tan(0.1f * r) + atan(r) +
+                    atan2(dy, dx + 3.f) + sinh(0.1f * r) + cosh(0.1f * r) + tanh(r) + atanh(0.1f * tanh(r)) + abs(dx) + fmin(r, p[0]) + fmax(r, p[0]));
+      if (value(r) > 2.f || dx < 0.f || 0.5f >= dy || r == p[0]) a += 1.f;
+      a *= 0.5f;  a -= 0.1f;  a /= 1.5f;  a += r;  a = -a;  a = +a;
+      fx = a * dx / r;  fy = a * dy / r;
+    }"""
+    _native.user_profile_check(everything, False, 4)
+    _native.user_points_check(everything, 4)
+    with pytest.raises(_native.NativeLibraryError, match="does not compile"):
+        _native.user_points_check("template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) { fx = nope; }", 1)
