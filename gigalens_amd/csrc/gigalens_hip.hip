@@ -387,6 +387,7 @@ bool launch_corr(const gl_model::CorrPlan& pl, int B, const float* in, float* ou
   // forward at supersample 2 with kernels up to 28 taps wide: 16 outputs per thread and 8 wavefronts per tile (two 75 KB tiles per
   // CU); everything else 8 outputs per thread
   const bool wide = pl.ST == 2 && a.ncj == 1 && pl.KWP <= 28 && pl.max_KH <= 28 && corr_wide;
+  // (16 outputs per thread in the transpose at supersample 2 as well: 62.7 us against 47.6 -- half the workgroups, 1.56 rounds)
   const int ox = wide ? 16 : CORR_OX, ks = wide ? 8 : pl.ST == 2 ? 4 : 2;
   const int TR = (CORR_TR - 1) * pl.ST + pl.max_KH, TC = corr_tile_width((CORR_TCG * ox - 1) * pl.ST + pl.KWP) | 1;
   const size_t sh = std::max((size_t)TR * TC * sizeof(float2), (size_t)(ks - 1) * a.ncj * ox * CORR_GT * sizeof(float2) +
