@@ -10,8 +10,25 @@ _BASE_KINDS = (6, 7, 8)  # dPIS, dPIE, dPIEP
 
 # Member bodies of built-in kinds, in the form of a user-written `hip_body` (profile.py): what a population of such members is
 # compiled from when it sits inside a PhysicalModel (`_member_loop_body` below).  Restated from the reference's formulas:
-# tf/profiles/mass/sis.py:13-18, nfw.py:15-51 (acosh(1/x) = log((1 + sqrt(1 - x^2)) / x), acos(1/x) = atan(sqrt(x^2 - 1))).
+# tf/profiles/mass/sis.py:13-18, sie.py:14-50 (s_scale = 0), nfw.py:15-51 (acosh(1/x) = log((1 + sqrt(1 - x^2)) / x),
+# acos(1/x) = atan(sqrt(x^2 - 1))).
 _MEMBER_BODIES = {
+    "SIE": """
+template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) {
+  const R e1 = p[1], e2 = p[2];
+  const R phi = atan2(e2, e1) * 0.5f;
+  R c = sqrt(e1 * e1 + e2 * e2);
+  if (value(c) > 0.9999f) c = R(0.9999f);
+  const R q = (1.f - c) / (1.f + c), q2 = q * q;
+  const R b = p[0] / sqrt((1.f + q2) / (2.f * q)) * sqrt((1.f + q2) * 0.5f);
+  const R cs = cos(phi), sn = sin(phi);
+  const R dx = x - p[3], dy = y - p[4];
+  const R xr = dx * cs + dy * sn, yr = dy * cs - dx * sn;
+  const R psi = sqrt(q2 * xr * xr + yr * yr), sq = sqrt(1.f - q2);
+  const R ax = b / sq * atan(sq * xr / psi), ay = b / sq * atanh(sq * yr / psi);
+  fx = ax * cs - ay * sn;  fy = ax * sn + ay * cs;
+}
+""",
     "SIS": """
 template <class R> __device__ void deriv(R x, R y, const R* p, R& fx, R& fy) {
   const R dx = x - p[1], dy = y - p[2];
@@ -65,7 +82,7 @@ class ScalingRelation(MassProfile):
     kind, other scaling parameters, a user-written ``hip_body`` -- is served at the plugin level the way the reference does it
     (:61-83): ``deriv`` / ``hessian`` evaluate the base profile on ``chunk_size`` galaxies at a time and sum.  Inside a
     ``PhysicalModel`` such a population becomes ONE run-time compiled lens (csrc/gl_user.hip): the member loop around the base
-    profile's body -- its own ``hip_body``, or the restated body of a built-in kind (``_MEMBER_BODIES``: SIS, NFW) -- with the
+    profile's body -- its own ``hip_body``, or the restated body of a built-in kind (``_MEMBER_BODIES``: SIS, SIE, NFW) -- with the
     catalogue as constants of the program and the gradient with respect to the scales from forward-mode duals.
     """
 

@@ -387,7 +387,7 @@ def test_linear_amplitude_solve_with_a_user_written_light(gl):
     assert torch.allclose(im_u, im_b, rtol=2e-4, atol=2e-5 * float(im_b.abs().max()))
 
 
-@pytest.mark.parametrize("base", ["NFW", "SIS", "USER_SIS"])
+@pytest.mark.parametrize("base", ["NFW", "SIS", "SIE", "USER_SIS"])
 def test_population_over_any_base_profile_inside_a_model(gl, base):
     """scaling_relation.py:8-19 wraps ANY MassProfile, and a PhysicalModel may hold the population.  Outside the dPIE family the
     population becomes one run-time compiled lens: the member loop around the base profile's body (its own `hip_body`, or the
@@ -412,6 +412,12 @@ def test_population_over_any_base_profile_inside_a_model(gl, base):
     if base == "NFW":
         pop = ScalingRelation(NFW(), ["Rs", "alpha_Rs"], 1.2, {"Rs": 0.4, "alpha_Rs": 0.6}, cat)
         scales = dict(Rs=t(r.uniform(0.3, 0.6, B)), alpha_Rs=t(r.uniform(0.05, 0.12, B)))
+        twin = None
+    elif base == "SIE":
+        from gigalens_amd.profiles.mass.sie import SIE
+        cat = dict(cat, e1=r.normal(0, 0.15, G).astype(np.float32), e2=r.normal(0, 0.15, G).astype(np.float32))
+        pop = ScalingRelation(SIE(), ["theta_E"], 1.2, {"theta_E": 0.5}, cat)
+        scales = dict(theta_E=t(r.uniform(0.04, 0.08, B)))
         twin = None
     else:
         pop = ScalingRelation(UserSIS() if base == "USER_SIS" else SIS(), ["theta_E"], 1.2, {"theta_E": 0.5}, cat)

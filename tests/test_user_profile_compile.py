@@ -49,7 +49,10 @@ def test_member_loop_bodies_of_populations_compile_without_a_gpu():
     cat = dict(lum=np.array([0.5, 1.0, 2.0], np.float32), center_x=np.array([0.1, -0.4, 0.9], np.float32),
                center_y=np.array([0.3, 0.2, -0.7], np.float32), alpha_Rs=np.array([0.5, 0.6, 0.7], np.float32),
                r_trunc=np.ones(3, np.float32))
+    from gigalens_amd.profiles.mass.sie import SIE
+    cat = dict(cat, e1=np.array([0.1, -0.2, 0.05], np.float32), e2=np.array([0.0, 0.1, -0.1], np.float32))
     for pop in (ScalingRelation(NFW(), ["Rs", "alpha_Rs"], 1.0, {"Rs": 0.4, "alpha_Rs": 0.5}, cat),
+                ScalingRelation(SIE(), ["theta_E"], 1.0, {"theta_E": 0.5}, cat),
                 ScalingRelation(SIS(), ["theta_E"], 1.0, {"theta_E": 0.5}, cat),
                 ScalingRelation(UserSIS(), ["theta_E"], 1.0, {"theta_E": 0.5}, cat)):
         assert pop._generic and "sr_member_deriv" in pop.hip_body and "sr_cat[3]" in pop.hip_body
@@ -58,7 +61,7 @@ def test_member_loop_bodies_of_populations_compile_without_a_gpu():
     # a base with neither a fused kernel nor a member body: plugin level only, and the message says what is served
     pop = ScalingRelation(TNFW(), ["Rs"], 1.0, {"Rs": 0.5}, cat)
     assert pop._generic and not pop.hip_body
-    with pytest.raises(_native.NativeLibraryError, match="NFW.*SIS"):
+    with pytest.raises(_native.NativeLibraryError, match="NFW.*SIE.*SIS"):
         pop._component()
 
 
