@@ -342,10 +342,19 @@ class ForwardProbModel(ProbabilisticModel):
                                         self._n_eff(simulator) if bit == 1 else 1.0, bit)
         return lp, ll, grad
 
-    def log_prob_and_grad(self, simulator, z):
+    def log_prob_and_grad(self, simulator, z, graph=False):
         """``(log_prob, red_chi2, d log_prob / d z)`` from ONE native launch sequence and no autograd graph --
-        what one MAP / HMC-leapfrog step of the reference computes with ``tf.GradientTape`` (tf/inference.py:33-39)."""
+        what one MAP / HMC-leapfrog step of the reference computes with ``tf.GradientTape`` (tf/inference.py:33-39).
+
+        ``graph=True`` (small problems, where the three to seven short launches of a step are host-issue bound -- BASELINE
+        configs[0], one 64 x 64 sample: 7 us of kernels in a 21 us step): the launch sequence is captured once per
+        (simulator, shape of ``z``) in a HIP graph and replayed.  The contract is that of torch's CUDA graphs: the three returned
+        tensors are the graph's STATIC outputs, overwritten by the next call with ``graph=True`` on the same simulator; ``z`` is
+        copied into the graph's static input unless it already IS that tensor (``graph_input(simulator, z)`` hands it out, for loops
+        that update ``z`` in place)."""
         z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        if graph and z.is_cuda and self._fused_ok(simulator):
+            return self._log_prob_and_grad_graph(simulator, z)
         if self._fused_ok(simulator):
             model = self._bind_prior(simulator)
             if self.include_positions:
@@ -358,6 +367,35 @@ class ForwardProbModel(ProbabilisticModel):
         lp, red = self.log_prob_unfused(simulator, zz)
         (g,) = torch.autograd.grad(lp.sum(), zz)
         return lp.detach(), red.detach(), g
+
+    def _log_prob_and_grad_graph(self, simulator, z):
+        key = (id(self), tuple(z.shape))
+        cache = simulator.__dict__.setdefault("_lp_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            z_static = z.detach().clone().contiguous()
+            side = torch.cuda.Stream(device=z.device)
+            side.wait_stream(torch.cuda.current_stream(z.device))
+            with torch.cuda.stream(side):  # warm-up off the default stream: binds the prior, sizes the workspaces
+                for _ in range(2):
+                    self.log_prob_and_grad(simulator, z_static)
+            torch.cuda.current_stream(z.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = self.log_prob_and_grad(simulator, z_static)
+            ent = cache[key] = (g, z_static, outs, self)  # (self: keeps id(self) from being reused while the entry lives)
+        g, z_static, outs, _ = ent
+        if z.data_ptr() != z_static.data_ptr():
+            z_static.copy_(z.detach())
+        g.replay()
+        return outs
+
+    def graph_input(self, simulator, z):
+        """The static input tensor of ``log_prob_and_grad(..., graph=True)`` for this shape of ``z`` (created, and the graph
+        captured, on first use), initialised with ``z``: update it in place and pass it back to skip the copy."""
+        z = torch.as_tensor(z, dtype=torch.float32, device=self.device)
+        self._log_prob_and_grad_graph(simulator, z)
+        return simulator._lp_graphs[(id(self), tuple(z.shape))][1]
 
     def _n_eff(self, simulator):
         n = getattr(simulator, "_n_eff", None)
