@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int kind = LK::kinds[i];
-      if constexpr (kind == K_EPL) epl_fwd_v<V, GRAD>(dL[i], gder + comps[i].d_off, x, y, bx, by, est[i]);
+      if constexpr (kind == K_EPL) epl_fwd_v<V, GRAD, gptr4>(dL[i], (gptr4)(gder + comps[i].d_off), x, y, bx, by, est[i]);  // (constant address space: gl_vec.hip.h)
       else if constexpr (kind == K_SIE) sie_fwd_v<V>(dL[i], x, y, bx, by);
       else if constexpr (kind == K_SHEAR) shear_fwd_v<V>(dL[i], x, y, bx, by);
       else sis_fwd_v<V>(dL[i], x, y, bx, by);
@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int kind = LK::kinds[i];
-      if constexpr (kind == K_EPL) epl_fwd_v<V, false>(dL[i], gder + comps[i].d_off, x, y, bx, by, est);
+      if constexpr (kind == K_EPL) epl_fwd_v<V, false, gptr4>(dL[i], (gptr4)(gder + comps[i].d_off), x, y, bx, by, est);
       else if constexpr (kind == K_SIE) sie_fwd_v<V>(dL[i], x, y, bx, by);
       else if constexpr (kind == K_SHEAR) shear_fwd_v<V>(dL[i], x, y, bx, by);
       else sis_fwd_v<V>(dL[i], x, y, bx, by);

@@ -66,9 +66,23 @@ template <class V> struct EplStateV {
   V f0, f1, t0, t1;  // Clenshaw tails (b_0, b_1) of the d/df and d/dt series
 };
 
-template <class V, bool GRAD>
-__device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restrict__ gd, V x, V y, V& bx, V& by,
+// Pointer to the sample's constants in GLOBAL memory, in two flavours: plain, and in the constant address space.  A wave-uniform
+// read through the plain one becomes a scalar load only while the compiler can prove nothing writes memory in between -- one
+// `asm volatile` in the kernel (the shapelet kernels order their LDS row reads with one, the cluster kernel its steps) and every
+// such read turns into a VECTOR load of 64 identical addresses: ~500 cycles of L1 latency per four-term trip of the EPL series
+// in round 3's table-mode shapelet kernel, found in round 4 from its 28 vector reads per wave-tile where 8 were expected.  Reads
+// through the constant address space stay scalar whatever else the kernel holds.
+typedef const float __attribute__((address_space(4)))* gptr4;
+typedef float vf4 __attribute__((ext_vector_type(4)));
+template <class T, class P> struct gl_rebind;
+template <class T> struct gl_rebind<T, const float*> { using type = const T*; };
+template <class T> struct gl_rebind<T, gptr4> { using type = const T __attribute__((address_space(4)))*; };
+
+template <class V, bool GRAD, class P = const float*>
+__device__ __forceinline__ void epl_fwd_v(const float* d, const P gd, V x, V y, V& bx, V& by,
                                           EplStateV<V>& st) {
+  using PInt = typename gl_rebind<int, P>::type;
+  using PRow = typename gl_rebind<vf4, P>::type;
   const float c = d[EPL_C], s = d[EPL_S], q = d[EPL_Q];
   V dx = x - d[EPL_CX], dy = y - d[EPL_CY];
   st.xr = dx * c + dy * s;
@@ -86,17 +100,17 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   st.invc = (iRc == r) ? r : V(0.f);  // clip_by_value passes gradient only inside the clamp
   V twoc = (st.Cs * st.Cs - st.Ss * st.Ss) * 2.f;
   // scalar-loaded trip count and coefficients (wave-uniform address): SGPR operands, scalar loop control
-  const int K = reinterpret_cast<const int*>(gd)[EPL_KI];
-  const float4* __restrict__ gtab = reinterpret_cast<const float4*>(gd + EPL_TAB);  // rows (c_n, (2n+1) c_n, dc_n/df, dc_n/dt)
+  const int K = ((PInt)gd)[EPL_KI];
+  const PRow gtab = (PRow)(gd + EPL_TAB);  // rows (c_n, (2n+1) c_n, dc_n/df, dc_n/dt)
   V o1, o2, f1 = V(0.f), f2 = V(0.f), t1 = V(0.f), t2 = V(0.f);  // b_{k+1}, b_{k+2}: set by the first trip (the tails of the two gradient series only with GRAD)
-  auto term = [&](const float4 ck, V& b1, V& b2, V& g1, V& g2, V& h1, V& h2) {  // b_k written over b_{k+2}
+  auto term = [&](const vf4 ck, V& b1, V& b2, V& g1, V& g2, V& h1, V& h2) {  // b_k written over b_{k+2}
     b2 = __builtin_elementwise_fma(twoc, b1, V(ck.x)) - b2;
     if (GRAD) {
       g2 = __builtin_elementwise_fma(twoc, g1, V(ck.z)) - g2;
       h2 = __builtin_elementwise_fma(twoc, h1, V(ck.w)) - h2;
     }
   };
-  auto four = [&](const float4 r0, const float4 r1, const float4 r2, const float4 r3) {  // rows k..k+3, highest first
+  auto four = [&](const vf4 r0, const vf4 r1, const vf4 r2, const vf4 r3) {  // rows k..k+3, highest first
     term(r3, o1, o2, f1, f2, t1, t2);
     term(r2, o2, o1, f2, f1, t2, t1);
     term(r1, o1, o2, f1, f2, t1, t2);
@@ -108,7 +122,7 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   // means "all of them": one request in flight at a time).
   // The FIRST trip starts from b = 0: its top term is the (wave-uniform) coefficient itself and its second has no b_{k+2} --
   // 6 instead of 8 packed instructions per series, and no zero-fill of the six tails (12 instructions per pixel pair less).
-  auto four_first = [&](const float4 r0, const float4 r1, const float4 r2, const float4 r3) {
+  auto four_first = [&](const vf4 r0, const vf4 r1, const vf4 r2, const vf4 r3) {
     o1 = __builtin_elementwise_fma(twoc, V(r3.x), V(r2.x));           // b_{k+2} = twoc c_{k+3} + c_{k+2}
     o2 = __builtin_elementwise_fma(twoc, o1, V(r1.x)) - V(r3.x);       // b_{k+1}
     o1 = __builtin_elementwise_fma(twoc, o2, V(r0.x)) - o1;            // b_k      (written over b_{k+2})
@@ -123,11 +137,11 @@ __device__ __forceinline__ void epl_fwd_v(const float* d, const float* __restric
   };
   int trips = (K + 4) >> 2;  // ceil((K + 1) / 4)
   int row = 4 * trips - 4;   // first row of the current trip
-  const float4* __restrict__ p = gtab + row;
-  float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+  PRow p = gtab + row;
+  vf4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
   row = row >= 4 ? row - 4 : 0;  // the request made by the LAST trip is clamped to rows 0..3: inside the table, never used
   p = gtab + row;
-  float4 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+  vf4 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
   four_first(a0, a1, a2, a3);
   if (--trips != 0) {
     while (true) {
