@@ -221,7 +221,7 @@ def epl_series_stats(wl, x_struct):
 _ISA_CACHE = {}
 
 
-def isa_account(kernel_symbol, series, p_live=None):
+def isa_account(kernel_symbol, series, p_live=None, p_lens=None):
     """ISA-counted fp32 flops and VALU wave-instructions per pixel of the dispatched kernel (tools/isa_flops.py)."""
     if os.path.join(ROOT, "tools") not in sys.path:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -236,7 +236,7 @@ def isa_account(kernel_symbol, series, p_live=None):
     md = meta[name]
     out = {"kernel": name, "vgpr_count": md["vgpr_count"], "vgpr_spill_count": md["vgpr_spill_count"],
            "sgpr_spill_count": md["sgpr_spill_count"], "scratch_bytes": md["scratch_bytes"]}
-    model = isa.execution_model(co, name, md, series, p_live)
+    model = isa.execution_model(co, name, md, series, p_live, p_lens)
     if model is not None:
         out.update(model)
     return out
@@ -294,7 +294,7 @@ def roofline_of(model, wl, sim, x, kernel_ms, ms_per_step, err, stride):
             "algorithmic_bytes_per_sim_B1": bytes_b1, "algorithmic_bytes_per_sim_B2": round(bytes_b2, 1),
             "kernel_sims_per_s": round(B / (k_mean * 1e-3), 1)}
     series = epl_series_stats(wl, x)
-    p_live = None
+    p_live = p_lens = None
     try:
         symbol = model.last_main_kernel()
     except Exception:  # evidence only: a model whose kernel has no name to report still gets its line
@@ -304,14 +304,18 @@ def roofline_of(model, wl, sim, x, kernel_ms, ms_per_step, err, stride):
         # and runs ceil(live / 64) rounds of one chain per lane: 0, 1 or 2; direct mode always 2) -- as a share of the two chains
         # per lane a tile without compaction runs, which is how the ISA model weights the chain blocks
         rows = model.partial_rows(B)
-        seen = float(rows[:, :, 3].sum())
+        packed = rows[:, :, 3].double()  # wave-tiles seen + 4096 x wave-tiles that ran the lens (gl_shp.hip.h: the others were
+        seen = float(torch.remainder(packed, 4096.0).sum())  # provably outside the shapelet table and skipped it)
+        lensed = float(torch.floor(packed / 4096.0).sum())
         p_live = 0.5 * float(rows[:, :, 2].sum()) / seen if seen > 0 else 1.0
         roof["shapelet_live_wave_tile_share"] = round(p_live, 4)
         roof["shapelet_chain_rounds_per_wave_tile"] = round(2.0 * p_live, 4)
+        p_lens = lensed / seen if seen > 0 else 1.0
+        roof["shapelet_wave_tiles_running_the_lens"] = round(p_lens, 4)
     n_members = sum(int(getattr(l, "n_galaxy", 0)) for l in wl.phys_model.lenses)  # galaxy catalogues (ScalingRelation / DPIESubhalo)
     try:
         # (the steady-state tile of the likelihood kernels is compiled once per variance model: tell the ISA model which ran)
-        acct = isa_account(symbol, dict(series or {}, error_map=err is not None, **({"n_members": n_members} if n_members else {})), p_live)
+        acct = isa_account(symbol, dict(series or {}, error_map=err is not None, **({"n_members": n_members} if n_members else {})), p_live, p_lens)
     except Exception as exc:  # the accounting is evidence, never a reason to lose the line
         acct = {"error": repr(exc)}
     if acct:
@@ -571,6 +575,7 @@ def measure_extra_configs(dev, steps_cap=200):
                         "valu_insts_per_pixel": roof.get("isa", {}).get("valu_insts_per_pixel"),
                         "flops_per_pixel": roof.get("isa", {}).get("flops_per_pixel"),
                         "shapelet_live_wave_tile_share": roof.get("shapelet_live_wave_tile_share"),
+                        "shapelet_wave_tiles_running_the_lens": roof.get("shapelet_wave_tiles_running_the_lens"),
                         "epl_series": series, "oracle_spot_check": check})
             if wl.batch * sim._model.N <= 300_000:
                 # host-issue bound sizes: the same call with graph=True (opt-in: the launch sequence replayed from a HIP graph,

@@ -184,6 +184,7 @@ MainArgs base_args(const gl_model* m, const Workspace& w, int chunk) {
   a.shp_tab = m->d_shp_tab;
   a.nfw_tab = m->d_nfw_tab;
   a.neutral = m->d_nfw_tab ? m->d_nfw_tab + 2 * glh::kNfwNodes : nullptr;
+  a.grid_rmax = m->shp_cull ? m->grid_rmax : -1.f;  // (negative: the culling test of the table-mode shapelet kernels is off)
   a.dbg = m->dbg_flags;
   a.shp_stride = m->shp_stride;
   a.parts = 7u;
@@ -769,6 +770,7 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
     }
   }
 #endif
+  m->shp_cull = env_int("GIGALENS_HIP_SHP_CULL", 1);
   m->corr_max_pairs = env_int("GIGALENS_HIP_CORR_MAXPAIRS", 0);  // tests: force the slicing of the PSF launches (read once)
   m->corr_wide = env_int("GIGALENS_HIP_CORR_WIDE", 1);           // 0: 8 outputs per thread in the stride-2 forward correlation as well
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;
@@ -786,6 +788,7 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
   if (n_comp) ok = ok && up((void**)&m->d_comps, m->comps.data(), sizeof(CompDesc) * n_comp);
   else ok = ok && (hipMalloc((void**)&m->d_comps, sizeof(CompDesc)) == hipSuccess);
   ok = ok && up((void**)&m->d_gx, grid->grid_x, sizeof(float) * m->N);
+  for (int i = 0; i < m->N; ++i) m->grid_rmax = std::max(m->grid_rmax, std::hypot(grid->grid_x[i], grid->grid_y[i]));
   ok = ok && up((void**)&m->d_gy, grid->grid_y, sizeof(float) * m->N);
   if (!m->lin_cols.empty()) ok = ok && up((void**)&m->d_lin_cols, m->lin_cols.data(), sizeof(int) * m->lin_cols.size());
   if (grid->pix_index) {

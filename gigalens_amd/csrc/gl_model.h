@@ -77,6 +77,8 @@ struct gl_model {
   float* d_nfw_tab = nullptr;  // models with NFW lenses: h(X) = g(X) / X^2 on the float format's own grid (gl_host_tables.h)
   int chunk_px_override = 0;  // -DGL_EXPERIMENTS builds only
   int dbg_flags = 0;          // -DGL_EXPERIMENTS builds only
+  float grid_rmax = 0.f;      // max |(x, y)| over the pixel grid
+  int shp_cull = 1;           // GIGALENS_HIP_SHP_CULL: wave-tiles provably outside the shapelet table skip the lens (gl_shp.hip.h)
   int corr_max_pairs = 0;     // GIGALENS_HIP_CORR_MAXPAIRS, read once at gl_model_create
   int corr_wide = 1;          // GIGALENS_HIP_CORR_WIDE, read once at gl_model_create
   bool has_nfw = false;

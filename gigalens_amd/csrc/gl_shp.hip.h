@@ -138,7 +138,7 @@ __device__ __forceinline__ float shp_pixel_fwd(const float* d, const v2f* __rest
   // derived from order n1 (left alone, the compiler issues all 72 reads first and the kernel no longer fits its registers).
   auto load_row = [&](int n1, float dep, v2f (&row)[NP]) {
     int z = 0;
-    if constexpr (INTERP) asm volatile("v_and_b32 %0, 0, %1" : "=v"(z) : "v"(dep));  // (direct mode: the compiler's own order fits)
+    if constexpr (INTERP) asm("v_and_b32 %0, 0, %1" : "=v"(z) : "v"(dep));  // (direct mode: the compiler's own order fits)
     const v2f* __restrict__ p = reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(gA) + z) + n1 * NP;
 #pragma unroll
     for (int j = 0; 2 * j + n1 < NO - 1; ++j) row[j] = p[j];
@@ -178,6 +178,76 @@ __device__ __forceinline__ float shp_pixel_fwd(const float* d, const v2f* __rest
   st.S = S;
   if (GRAD) { st.Su = Su; st.Sv = Sv; }
   return st.fac * st.S;
+}
+
+// ---- table mode: pixels PROVABLY outside the shapelet table, decided before the lens is evaluated -----------------------------
+// The table's support is |u|, |v| <= 5 with (u, v) = (beta - c) / beta_s: a pixel whose source-plane position is further than
+// 5 sqrt(2) beta_s from the source centre renders exactly zero with zero slopes, and nothing of its lens evaluation reaches any
+// output (image value 0, cotangent 0).  beta = x - alpha(x), so |beta - c| >= |x - c| - |alpha(x)|, and |alpha| has a bound that
+// needs no series:
+//   EPL   alpha = P Omega,  P = 2b/(1+q) (b/R)^(t-1),  |Omega| <= sum |c_n| <= 1/(1 - f) = (1+q)/(2q)  (|c_n| <= f^n for 0 < t < 2)
+//         t >= 1:  (b/R)^(t-1) <= 1 where the elliptical radius R >= b, which |x - c_lens| >= b/q guarantees:  |alpha| <= b/q;
+//         t <  1:  (R/b)^(1-t) <= (D/b)^(1-t) with D the largest distance of a pixel from the lens centre:   |alpha| <= (b/q)(D/b)^(1-t)
+//   Shear |alpha| = |gamma| |x| <= |gamma| r_max;   SIS |alpha| = theta_E;   SIE |alpha| <= A hypot(pi/2, atanh(sqrt(1-q^2)))
+// (r_max: MainArgs.grid_rmax).  A wave-tile ALL of whose 128 pixels pass  |x - c|^2 > (1.001 (5 sqrt2 beta_s + sum of bounds))^2
+// skips the lens, the chains and the VJPs: on the C3 prior (theta_E ~ 1.25", beta_s ~ 0.1", an 8.3" field, a wave-tile = one image
+// row) that is every row further than ~2.5" from the source centre, 40 % of the wave-tiles.  Parameters outside the ranges the
+// bounds assume (q, b, t, beta_s; NaN) switch the test off for the sample.
+template <int NL> struct ShpCull {
+  float T2, cx, cy;                                        // threshold^2 (+inf: off), source centre
+  float lx[NL > 0 ? NL : 1], ly[NL > 0 ? NL : 1], rb2[NL > 0 ? NL : 1];  // per lens: centre and the squared radius its bound holds outside of (0: everywhere)
+  __device__ __forceinline__ bool tile_outside(v2f x, v2f y) const {
+    const v2f dx = x - cx, dy = y - cy, d2 = dx * dx + dy * dy;
+    bool far = d2.x > T2 && d2.y > T2;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const v2f ex = x - lx[i], ey = y - ly[i], e2 = ex * ex + ey * ey;
+      far = far && e2.x >= rb2[i] && e2.y >= rb2[i];
+    }
+    return __builtin_amdgcn_ballot_w64(!far) == 0ull;
+  }
+};
+template <class LK, bool INTERP, int NL = LK::n>
+__device__ __forceinline__ ShpCull<NL> shp_cull_setup(const float* const* dL, const float* dS, float r_max) {
+  ShpCull<NL> c;
+  c.T2 = __builtin_inff();
+  c.cx = c.cy = 0.f;
+#pragma unroll
+  for (int i = 0; i < (NL > 0 ? NL : 1); ++i) c.lx[i] = c.ly[i] = c.rb2[i] = 0.f;
+  if constexpr (INTERP) {
+    const float ib = dS[SHP_IB];
+    bool ok = r_max >= 0.f && ib > 0.f;
+    float A = 0.f;
+    static_for([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int kind = LK::kinds[i];
+      const float* d = dL[i];
+      if constexpr (kind == K_EPL) {
+        const float q = d[EPL_Q], b = d[EPL_B], tm1 = d[EPL_TM1];
+        ok = ok && q > 0.f && q <= 1.f && b > 0.f && tm1 > -1.f && tm1 < 1.f;
+        const float bq = b / q, D = r_max + __builtin_sqrtf(d[EPL_CX] * d[EPL_CX] + d[EPL_CY] * d[EPL_CY]);
+        const float grow = tm1 < 0.f ? exp2_(-tm1 * log2_(__builtin_fmaxf(D / b, 1.f))) : 1.f;
+        A += bq * grow;
+        c.lx[i] = d[EPL_CX];
+        c.ly[i] = d[EPL_CY];
+        c.rb2[i] = tm1 > 0.f ? 1.002f * bq * bq : 0.f;
+      } else if constexpr (kind == K_SHEAR) {
+        A += __builtin_sqrtf(d[SHR_G1] * d[SHR_G1] + d[SHR_G2] * d[SHR_G2]) * r_max;
+      } else if constexpr (kind == K_SIE) {
+        const float sq = d[SIE_SQ];
+        ok = ok && sq >= 0.f && sq < 1.f;
+        const float ah = 0.5f * __builtin_logf((1.f + sq) / (1.f - sq));
+        A += __builtin_fabsf(d[SIE_A]) * __builtin_sqrtf(2.4674011f + ah * ah);
+      } else {
+        A += __builtin_fabsf(d[SIS_TE]);
+      }
+    }, std::make_integer_sequence<int, NL>{});
+    const float T = 1.001f * (7.0710678f / ib + A);
+    if (ok && T > 0.f && T < 1e15f) c.T2 = T * T;
+    c.cx = dS[SHP_CX];
+    c.cy = dS[SHP_CY];
+  }
+  return c;
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------------------------
@@ -222,6 +292,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
   // read is a broadcast (as 72 vector registers filled by global loads it was a third of the kernel's L1 traffic)
   const v2f* __restrict__ gA = INTERP ? reinterpret_cast<const v2f*>(dS + SHP_SQ) : reinterpret_cast<const v2f*>(gder + shp.d_off + SHP_SQ);
   const bool has_err = a.err != nullptr, has_mask = a.mask != nullptr, has_pix = a.pix != nullptr;
+  const ShpCull<NL> cull = shp_cull_setup<LK, INTERP>(dL, dS, a.grid_rmax);
   // exchange planes of this wave: plane n = (X_n, Y_n) of each pixel; a lane parks pixel slot w at pixel index 64 w + lane
   float* xw = s_x + wave * shp_exchange_floats(NP);
   float* wr_xy = xw + 2 * lane;
@@ -235,9 +306,12 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
 
   const int p0 = chunk * a.chunk;
   const int p1 = min(p0 + a.chunk, a.N);
-  int n_tiles = 0, n_live = 0;  // wave-tiles seen / not skipped (wave-uniform): a measurement aid in the row's two pad slots
-  auto tile = [&](int base, auto check_tag) {
+  int n_tiles = 0, n_live = 0, n_lensed = 0;  // wave-tiles seen / chain rounds run / tiles that ran the lens (wave-uniform): a measurement aid in the row's two pad slots
+  // (x_pre, y_pre: the tile's grid coordinates, requested while the previous tile was being worked on -- steady-state tiles only.
+  // With two waves per SIMD nothing hides the round trip of a tile's first loads: ~600 of a dead tile's ~1500 cycles.)
+  auto tile = [&](int base, auto check_tag, auto pre_tag, V x_pre, V y_pre) {
     constexpr bool CHECK = decltype(check_tag)::value;
+    constexpr bool PRE = decltype(pre_tag)::value;
     unsigned jj[2], pidx[2];
     bool valid[2];
     V vmask = V(1.f);
@@ -251,10 +325,20 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     // 32-bit byte offsets from the scalar plane bases (one shift per pixel serves grid, observation and error planes)
     const unsigned jo0 = jj[0] << 2, jo1 = jj[1] << 2, po0 = pidx[0] << 2, po1 = pidx[1] << 2;
     auto ldf = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
-    const V x = V{ldf(a.gx, jo0), ldf(a.gx, jo1)}, y = V{ldf(a.gy, jo0), ldf(a.gy, jo1)};
+    const V x = PRE ? x_pre : V{ldf(a.gx, jo0), ldf(a.gx, jo1)}, y = PRE ? y_pre : V{ldf(a.gy, jo0), ldf(a.gy, jo1)};
+    // the likelihood's planes are requested here, ahead of the lens and the chains that do not need them
+    // (table mode only, like the coordinate prefetch: the direct-mode kernel is at its register limit and measured 2 % slower with them)
+    V o_pre = V(0.f), e_pre = V(1.f);
+    if constexpr (INTERP && (MODE == LL_FWD || MODE == LL_GRAD)) {
+      o_pre = V{ldf(a.obs, po0), ldf(a.obs, po1)};
+      if (has_err) e_pre = V{ldf(a.err, po0), ldf(a.err, po1)};
+    }
     if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
     V bx = x, by = y, m = V(0.f);
     EplStateV<V> est[NL > 0 ? NL : 1];
+    // (table mode) a wave-tile every pixel of which is PROVABLY outside the shapelet table skips the lens altogether: shp_cull_setup
+    const bool culled = INTERP && cull.tile_outside(x, y);
+    if (!culled)
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int kind = LK::kinds[i];
@@ -271,6 +355,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     ShpPix<NP> ps0, ps1;
     shp_pixel_coords<NP>(dS, bx.x, by.x, ps0);
     shp_pixel_coords<NP>(dS, bx.y, by.y, ps1);
+    if (culled) ps0.u = ps1.u = 100.f;  // outside the table whatever beta would have been
+    n_lensed += culled ? 0 : 1;
     // Table mode: a pixel whose u OR v lies outside the table's support renders exactly zero with zero slopes (fill 0 / 0,
     // shapelets.py:58-60).  Round 3 skipped the wave-tiles none of whose 128 pixels is inside (54 % on the C3 prior) and ran both
     // chains of every lane on the others -- but on a lensed field the support is a band along the arcs, and a live wave-tile
@@ -343,9 +429,12 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       const V g = V{row[pidx[0]], row[pidx[1]]};
       gm = nanp ? V(0.f) : (CHECK ? g * vmask : g) * a.out_scale;
     } else {
-      V o = V{ldf(a.obs, po0), ldf(a.obs, po1)}, w = vmask, e = V(1.f);
+      V o = o_pre, w = vmask, e = e_pre;
+      if constexpr (!INTERP) {
+        o = V{ldf(a.obs, po0), ldf(a.obs, po1)};
+        if (has_err) e = V{ldf(a.err, po0), ldf(a.err, po1)};
+      }
       if (CHECK && has_mask) w = w * V{ldf(a.mask, po0), ldf(a.mask, po1)};
-      if (has_err) e = V{ldf(a.err, po0), ldf(a.err, po1)};
       V dmo = m - o;  // tf/model.py:92-99; sigma^2 = bg^2 + m/t (no clip: negative -> NaN like the sqrt of a negative)
       V s2 = has_err ? e * e : m * a.inv_t + a.bg2;
       V is2 = rcp(s2);
@@ -461,13 +550,33 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
   };
   {
     int base = p0;
+    // whole tiles without a pixel list: the coordinates of tile k + 1 are requested before tile k is worked on (the request past
+    // the last whole tile re-reads that tile's: inside the planes, never used)
+    auto whole_tiles = [&]() {
+      if constexpr (!INTERP) {
+        for (; base + WG * 2 <= p1; base += WG * 2) tile(base, std::false_type{}, std::false_type{}, V(0.f), V(0.f));
+        return;
+      }
+      if (base + WG * 2 > p1) return;
+      auto coords = [&](int bs, V& xo, V& yo) {
+        const float* gx = a.gx + bs + tid;
+        const float* gy = a.gy + bs + tid;
+        xo = V{gx[0], gx[WG]};
+        yo = V{gy[0], gy[WG]};
+      };
+      V xn, yn;
+      coords(base, xn, yn);
+      for (; base + WG * 2 <= p1; base += WG * 2) {
+        const V xc = xn, yc = yn;
+        coords(base + WG * 4 <= p1 ? base + WG * 2 : base, xn, yn);
+        tile(base, std::false_type{}, std::true_type{}, xc, yc);
+      }
+    };
     if constexpr (!RAGGED) {
-      for (; base + WG * 2 <= p1; base += WG * 2) tile(base, std::false_type{});
+      whole_tiles();
     } else {
-      const bool plain = !has_mask && !has_pix;
-      if (plain)
-        for (; base + WG * 2 <= p1; base += WG * 2) tile(base, std::false_type{});
-      for (; base < p1; base += WG * 2) tile(base, std::true_type{});
+      if (!has_mask && !has_pix) whole_tiles();
+      for (; base < p1; base += WG * 2) tile(base, std::true_type{}, std::false_type{}, V(0.f), V(0.f));
     }
   }
   if (MODE == IMG_FWD) return;
@@ -493,7 +602,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     vals[0] = (MODE == LL_GRAD) ? hsum(st0) : 0.f;
     vals[1] = (MODE == LL_GRAD) ? hsum(st1) : 0.f;
     vals[2] = lane == 0 ? (float)n_live : 0.f;   // pad slots of the row (finalize does not read them): rounds of the shapelet
-    vals[3] = lane == 0 ? (float)n_tiles : 0.f;  // chains this wave ran (0-2 per tile) and its tiles -- bench.py's work model
+    vals[3] = lane == 0 ? (float)(n_tiles + 4096 * n_lensed) : 0.f;  // chains this wave ran (0-2 per tile), its tiles and (x 4096) those of them that ran the lens -- bench.py's work model
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int kind = LK::kinds[i];

@@ -307,7 +307,7 @@ def _hot_loops(cfg, min_valu=100):
     return sorted([l for l in cfg.loops if l.parent is None and cfg.tally(l.blocks)["valu"] >= min_valu], key=lambda l: l.header)
 
 
-def shp_model(cfg, mean_series_pairs, p_live, W=2):
+def shp_model(cfg, mean_series_pairs, p_live, W=2, p_lens=1.0):
     """gl_shp_kernel (csrc/gl_shp.hip.h), gradient / likelihood modes.  The steady-state tile loop is the first hot top-level
     loop; per trip (two pixels per lane):
       * blocks that dominate the latch run once,
@@ -315,7 +315,10 @@ def shp_model(cfg, mean_series_pairs, p_live, W=2):
       * the blocks behind the wave-uniform "any pixel inside the shapelet table" branch -- recognised by what only they hold:
         the table gathers' packed interpolation / contraction (>= 8 packed instructions) or the MFMAs -- run with probability
         `p_live`, the share of wave-tiles the kernel itself counted as live (pad slots of its partial rows),
-      * the remaining conditional blocks (optional plane loads, the few moves of the skip path) are counted as executed."""
+      * the remaining conditional blocks (optional plane loads, the few moves of the skip path) are counted as executed.
+    Round 4 (table mode): wave-tiles provably outside the shapelet table skip the lens forward -- the EPL series loop and the
+    conditional blocks on its side of that branch (the lens preamble, which dominates the series loop's header, and what it
+    dominates) run with probability `p_lens`, the share of wave-tiles the kernel counted as having run the lens."""
     tile = _hot_loops(cfg)[0]
     inner = sorted(tile.children, key=lambda l: l.header)
     inner_blocks = set().union(*[c.blocks for c in inner]) if inner else set()
@@ -333,19 +336,25 @@ def shp_model(cfg, mean_series_pairs, p_live, W=2):
         # pixels (0, 1 or 2 per tile): loops with a large packed body or MFMAs; mean trips = 2 p_live (p_live is handed over as
         # the share of the two chains per lane a tile would run without compaction).  The other inner loop is the EPL series.
         rounds_loop = t["mfma"] > 0 or t["packed"] >= 60
-        trips = 2.0 * p_live if rounds_loop else mean_series_pairs
+        trips = 2.0 * p_live if rounds_loop else mean_series_pairs * p_lens
         for k in out:
             out[k] += t[k] * trips
         detail["inner"].append(dict(header=hex(c.header), per_trip=t, trips=trips, what="chain / MFMA rounds" if rounds_loop else "EPL series"))
+    series_headers = [c.header for c in inner if not (cfg.tally(c.blocks)["mfma"] > 0 or cfg.tally(c.blocks)["packed"] >= 60)]
+    # the lens side of the cull branch: the conditional blocks that dominate the series loop (the lens preamble) and everything
+    # they dominate up to the join (the series may run zero trips of its loop, so its header does not dominate the lens tail)
+    anchors = {b for b in own - mandatory if any(b in cfg.dom[h] for h in series_headers)}
     for b in sorted(own - mandatory):
         t = cfg.tally([b])
         live = t["packed"] >= 8 or t["mfma"] > 0
-        prob = p_live if live else 1.0
+        lens_side = p_lens < 1.0 and (b in anchors or any(an in cfg.dom[b] for an in anchors))
+        prob = p_lens if lens_side else (p_live if live else 1.0)
         for k in out:
             out[k] += t[k] * prob
         if t["valu"] or t["mfma"]:
             detail["conditional"].append(dict(block=hex(b), per_trip={k: v for k, v in t.items() if v}, probability=prob,
-                                              what="shapelet chains of a live wave-tile" if live else "counted as executed"))
+                                              what="lens forward of a tile not culled" if lens_side else
+                                              ("shapelet chains of a live wave-tile" if live else "counted as executed")))
     per_pixel = {k: v / W for k, v in out.items()}
     detail["per_pixel"] = per_pixel
     return per_pixel, detail
@@ -392,7 +401,7 @@ def cluster_model(cfg, W=2, min_valu=1000):
     return per_pixel, detail
 
 
-def execution_model(co, name, md, series, p_live=None):
+def execution_model(co, name, md, series, p_live=None, p_lens=None):
     """Dynamic per-pixel counts of a kernel this tool has an execution model for (the specialised pair / static kernels in a
     likelihood or gradient mode), else None.  `series`: dict(mean_pair_trips, frac_odd[, frac_short]) of the batch, or None
     for models without EPL."""
@@ -406,7 +415,8 @@ def execution_model(co, name, md, series, p_live=None):
         cfg = CFG(disassemble(md["co"], md["symbol"]))
         s_ = series or {}
         if ms:
-            per_pixel, detail = shp_model(cfg, float(s_.get("mean_pair_trips", 0.0)), 1.0 if p_live is None else float(p_live))
+            per_pixel, detail = shp_model(cfg, float(s_.get("mean_pair_trips", 0.0)), 1.0 if p_live is None else float(p_live),
+                                          p_lens=1.0 if p_lens is None else float(p_lens))
         elif mw:
             # gl_clusterw_kernel (csrc/gl_clusterw.hip.h): the four waves of a workgroup walk the SAME 128 pixels of a step (64
             # lanes x one pixel pair each), every wave with a quarter of the components -- a pixel is served by one lane of each
