@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
   int n_tiles = 0, n_live = 0, n_lensed = 0;  // wave-tiles seen / chain rounds run / tiles that ran the lens (wave-uniform): a measurement aid in the row's two pad slots
   // (x_pre, y_pre: the tile's grid coordinates, requested while the previous tile was being worked on -- steady-state tiles only.
   // With two waves per SIMD nothing hides the round trip of a tile's first loads: ~600 of a dead tile's ~1500 cycles.)
-  auto tile = [&](int base, auto check_tag, auto pre_tag, V x_pre, V y_pre) {
+  auto tile = [&](int base, auto check_tag, auto pre_tag, V x_pre, V y_pre, V obs_pre, V err_pre) {
     constexpr bool CHECK = decltype(check_tag)::value;
     constexpr bool PRE = decltype(pre_tag)::value;
     unsigned jj[2], pidx[2];
@@ -328,16 +328,16 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     const V x = PRE ? x_pre : V{ldf(a.gx, jo0), ldf(a.gx, jo1)}, y = PRE ? y_pre : V{ldf(a.gy, jo0), ldf(a.gy, jo1)};
     // the likelihood's planes are requested here, ahead of the lens and the chains that do not need them
     // (table mode only, like the coordinate prefetch: the direct-mode kernel is at its register limit and measured 2 % slower with them)
-    V o_pre = V(0.f), e_pre = V(1.f);
-    if constexpr (INTERP && (MODE == LL_FWD || MODE == LL_GRAD)) {
+    V o_pre = obs_pre, e_pre = err_pre;
+    if constexpr (INTERP && !PRE && (MODE == LL_FWD || MODE == LL_GRAD)) {
       o_pre = V{ldf(a.obs, po0), ldf(a.obs, po1)};
-      if (has_err) e_pre = V{ldf(a.err, po0), ldf(a.err, po1)};
+      e_pre = has_err ? V{ldf(a.err, po0), ldf(a.err, po1)} : V(1.f);
     }
     if (CHECK) vmask = V{valid[0] ? 1.f : 0.f, valid[1] ? 1.f : 0.f};
     V bx = x, by = y, m = V(0.f);
     EplStateV<V> est[NL > 0 ? NL : 1];
     // (table mode) a wave-tile every pixel of which is PROVABLY outside the shapelet table skips the lens altogether: shp_cull_setup
-    const bool culled = INTERP && cull.tile_outside(x, y);
+    const bool culled = (INTERP && cull.tile_outside(x, y)) || GL_DBG(a.dbg, 1024);  // (dissection builds: 1024 no lens at all)
     if (!culled)
     static_for([&](auto I) {
       constexpr int i = decltype(I)::value;
@@ -376,8 +376,8 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       const int c0 = __builtin_popcountll(m0), count = c0 + __builtin_popcountll(m1);
       r0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
       r1 = c0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
-      rounds = (count + 63) >> 6;
-      shp_live = count != 0;
+      rounds = GL_DBG(a.dbg, 128) ? 0 : (count + 63) >> 6;  // (dissection builds: 128 no chain rounds, 256 no matrix-pipe pass, 512 no VJPs of a live tile)
+      shp_live = count != 0 && !GL_DBG(a.dbg, 128);
       ps0.S = ps0.Su = ps0.Sv = 0.f; ps0.fac = 1.f;
       ps1.S = ps1.Su = ps1.Sv = 0.f; ps1.fac = 1.f;
       if (shp_live) {
@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       // A tile none of whose pixels is inside the shapelet support sends no cotangent to the lens (the image does not depend on
       // beta there: value 0, slope 0; a lens light is evaluated on the grid, not at beta): the lens VJPs of such a tile add exact
       // zeros and are skipped (wave-uniform; 54 % of the wave-tiles on the C3 prior).
-      if (shp_live)
+      if (shp_live && !GL_DBG(a.dbg, 512))
       static_for([&](auto I) {
         constexpr int i = decltype(I)::value;
         constexpr int kind = LK::kinds[i];
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
       }, std::make_integer_sequence<int, NL>{});
       // ---- G += (gS X)(Y)^T over the wave's 128 pixels: 32 MFMAs of four pixels each.  The planes are private to the wave and
       // LDS serves a wave's requests in order, so stores -> transposed loads need no barrier, only the compiler's ordering. ----
-      if (shp_live) {
+      if (shp_live && !GL_DBG(a.dbg, 256)) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -554,29 +554,38 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_kernel(MainArgs a) {
     // the last whole tile re-reads that tile's: inside the planes, never used)
     auto whole_tiles = [&]() {
       if constexpr (!INTERP) {
-        for (; base + WG * 2 <= p1; base += WG * 2) tile(base, std::false_type{}, std::false_type{}, V(0.f), V(0.f));
+        for (; base + WG * 2 <= p1; base += WG * 2) tile(base, std::false_type{}, std::false_type{}, V(0.f), V(0.f), V(0.f), V(1.f));
         return;
       }
       if (base + WG * 2 > p1) return;
-      auto coords = [&](int bs, V& xo, V& yo) {
+      // (the observation and error planes too: a tile that skips the lens has nothing else to wait behind -- dissected in round 4,
+      // the bare tile loop without lens or chains took 37 us of the kernel's 175, ~1400 cycles per wave-tile for ~60 instructions)
+      auto planes = [&](int bs, V& xo, V& yo, V& oo, V& eo) {
         const float* gx = a.gx + bs + tid;
         const float* gy = a.gy + bs + tid;
         xo = V{gx[0], gx[WG]};
         yo = V{gy[0], gy[WG]};
+        oo = V(0.f);
+        eo = V(1.f);
+        if constexpr (MODE == LL_FWD || MODE == LL_GRAD) {
+          const float* po = a.obs + bs + tid;
+          oo = V{po[0], po[WG]};
+          if (has_err) { const float* pe = a.err + bs + tid; eo = V{pe[0], pe[WG]}; }
+        }
       };
-      V xn, yn;
-      coords(base, xn, yn);
-      for (; base + WG * 2 <= p1; base += WG * 2) {
-        const V xc = xn, yc = yn;
-        coords(base + WG * 4 <= p1 ? base + WG * 2 : base, xn, yn);
-        tile(base, std::false_type{}, std::true_type{}, xc, yc);
+      V xn, yn, on, en;
+      planes(base, xn, yn, on, en);
+      for (; base + WG * 2 <= (GL_DBG(a.dbg, 2048) ? p0 : p1); base += WG * 2) {  // (dissection builds: 2048 no tiles)
+        const V xc = xn, yc = yn, oc = on, ec = en;
+        planes(base + WG * 4 <= p1 ? base + WG * 2 : base, xn, yn, on, en);
+        tile(base, std::false_type{}, std::true_type{}, xc, yc, oc, ec);
       }
     };
     if constexpr (!RAGGED) {
       whole_tiles();
     } else {
       if (!has_mask && !has_pix) whole_tiles();
-      for (; base < p1; base += WG * 2) tile(base, std::true_type{}, std::false_type{}, V(0.f), V(0.f));
+      for (; base < p1; base += WG * 2) tile(base, std::true_type{}, std::false_type{}, V(0.f), V(0.f), V(0.f), V(1.f));
     }
   }
   if (MODE == IMG_FWD) return;
