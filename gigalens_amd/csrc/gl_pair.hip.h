@@ -147,6 +147,9 @@ __global__ void __launch_bounds__(WG, WAVES) gl_pair_kernel(MainArgs a) {
   // no validity selects, no weights.  CHECK=true handles the ragged last tile and img_region weights.
   // err_tag: 0 no error map, 1 error map (both compile the variance and the cotangent of their own case: as a run-time choice the
   // two were computed side by side and selected, 10 instructions per pixel pair), 2 decided at run time (the ragged-end tile)
+  // (requesting the NEXT whole tile's planes -- grid, observation, error map -- while a tile is worked on was tried in round 4, after
+  // the shapelet kernel's dissection showed bare tile loads costing 1 400 cycles per wave-tile there: 147 VGPRs instead of 141 and
+  // 0.0823 against 0.0819 ms per C2 step -- at three waves per SIMD the other waves already cover a tile's opening loads.)
   auto tile = [&](int base, auto check_tag, auto err_tag) {
     constexpr bool CHECK = decltype(check_tag)::value;
     constexpr int ERR = decltype(err_tag)::value;
