@@ -950,3 +950,23 @@ def test_log_prob_and_grad_from_a_hip_graph_equals_stream_launches(gl):
     zs.copy_(z2)
     g4 = pm.log_prob_and_grad(sim, zs, graph=True)
     assert all(torch.equal(x, y) for x, y in zip(a2, g4))
+
+
+def test_shapelet_cull_changes_no_bit(gl, monkeypatch):
+    """Table-mode shapelet kernel: wave-tiles provably outside the table skip the lens (csrc/gl_shp.hip.h shp_cull_setup).  Nothing
+    of such a tile's lens evaluation reaches an output, so log-likelihood and gradient with the test on equal those with it off
+    bit for bit -- and the test does fire on this geometry (the kernel's own count of tiles that ran the lens)."""
+    wl = gl.workloads.make("C3", batch=6)
+    obs, err, _ = gl.workloads.synthetic_observation(wl, gl.LensSimulator)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GIGALENS_HIP_SHP_CULL", flag)
+        sim = gl.LensSimulator(wl.phys_model, wl.sim_config, bs=wl.batch)
+        packed = H.sample_packed(wl, sim, seed=3)
+        ll, chi, g = sim._model.loglike(packed, obs, err, None, wl.background_rms, wl.exp_time, True)
+        rows = sim._model.partial_rows(wl.batch)
+        pk = rows[:, :, 3].double()
+        out[flag] = (ll.clone(), chi.clone(), g.clone(), float(torch.remainder(pk, 4096.0).sum()), float(torch.floor(pk / 4096.0).sum()))
+    assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1]) and torch.equal(out["1"][2], out["0"][2])
+    assert out["0"][4] == out["0"][3]                     # test off: every wave-tile ran the lens
+    assert out["1"][3] == out["0"][3] and out["1"][4] < 0.9 * out["1"][3]  # test on: at least a tenth of them did not
