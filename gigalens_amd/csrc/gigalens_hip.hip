@@ -771,6 +771,7 @@ int gl_model_create_user(const gl_component* comps, int n_lens, int n_lens_light
   }
 #endif
   m->shp_cull = env_int("GIGALENS_HIP_SHP_CULL", 1);
+  m->shp_blocked = env_int("GIGALENS_HIP_SHP_BLOCKED", 1);
   m->corr_max_pairs = env_int("GIGALENS_HIP_CORR_MAXPAIRS", 0);  // tests: force the slicing of the PSF launches (read once)
   m->corr_wide = env_int("GIGALENS_HIP_CORR_WIDE", 1);           // 0: 8 outputs per thread in the stride-2 forward correlation as well
   m->wave_prep = env_int("GIGALENS_HIP_WAVE_PREP", 1) != 0;

@@ -106,6 +106,7 @@ struct MainArgs {
   const float* nfw_tab;  // models with NFW lenses: the shared h(X) table (gl_host_tables.h), [kNfwNodes][2]; else null
   const float* neutral;  // gl_clusterw_kernel: constant blocks of an unused component slot, [NFW (4) | Sersic (16)]; else null
   float grid_rmax;       // largest |(x, y)| of the pixel grid (gl_shp.hip.h: the bound on the shear's deflection)
+  int blk_w;             // table-mode shapelet kernel: image width when a wave-tile is an 8-row x 16-column BLOCK of the image (0: 128 consecutive pixels)
   int dbg;  // -DGL_EXPERIMENTS builds only (GIGALENS_HIP_DBGFLAGS): 1 skip the pixel tiles, 2 skip the epilogue reductions, 4 skip the constant staging
 };
 

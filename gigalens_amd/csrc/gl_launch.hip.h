@@ -55,10 +55,15 @@ bool launch_static(const gl_model* m, const MainArgs& a, dim3 grid, dim3 block, 
     const bool interp = (m->comps.back().flags & GL_FLAG_SHAPELETS_INTERPOLATE) != 0;
     // whole 512-pixel tiles, no mask, no pixel list: the instantiation without the ragged-end tile code
     const bool ragged = a.mask || a.pix || (a.N % (2 * WG)) != 0 || (a.chunk % (2 * WG)) != 0;
+    // table mode on a whole image: a wave-tile is an 8 x 16 BLOCK of the image instead of 128 consecutive pixels -- the live band
+    // of a lensed field is compact in two dimensions (gl_shp.hip.h: fewer live tiles, fewer chain rounds, more tiles culled)
+    MainArgs ab = a;
+    ab.blk_w = (interp && !ragged && m->shp_blocked && m->width % 16 == 0 && m->height % 8 == 0 &&
+                (long long)a.N == (long long)m->width * m->height) ? m->width : 0;
 #define GL_SHP2(LLK_, I_, R_)                                                                                 \
   do {                                                                                                        \
     m->last_main_fn = (const void*)&gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_, R_>;                     \
-    hipExtLaunchKernelGGL((gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_, R_>), grid, block, (std::uint32_t)(sh), stream, ev0, ev1, 0, a);   \
+    hipExtLaunchKernelGGL((gl_shp_kernel<MODE, 2, L_EplShear, LLK_, NPS, I_, R_>), grid, block, (std::uint32_t)(sh), stream, ev0, ev1, 0, ab);   \
   } while (0)
 #define GL_SHP(LLK_, I_) do { if (ragged) GL_SHP2(LLK_, I_, true); else GL_SHP2(LLK_, I_, false); } while (0)
     if (m->static_id == ST_EPLSHEAR_SHAPELETS) { if (interp) GL_SHP(C_None, true); else GL_SHP(C_None, false); }

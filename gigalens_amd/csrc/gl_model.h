@@ -78,6 +78,7 @@ struct gl_model {
   int chunk_px_override = 0;  // -DGL_EXPERIMENTS builds only
   int dbg_flags = 0;          // -DGL_EXPERIMENTS builds only
   float grid_rmax = 0.f;      // max |(x, y)| over the pixel grid
+  int shp_blocked = 1;        // GIGALENS_HIP_SHP_BLOCKED: wave-tiles of the table-mode shapelet kernel are 8 x 16 blocks of the image
   int shp_cull = 1;           // GIGALENS_HIP_SHP_CULL: wave-tiles provably outside the shapelet table skip the lens (gl_shp.hip.h)
   int corr_max_pairs = 0;     // GIGALENS_HIP_CORR_MAXPAIRS, read once at gl_model_create
   int corr_wide = 1;          // GIGALENS_HIP_CORR_WIDE, read once at gl_model_create
