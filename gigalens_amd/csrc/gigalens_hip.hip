@@ -1210,6 +1210,8 @@ int gl_lstsq_fwd(const gl_model* m, const float* params, const float* obs, const
     constexpr int NPS = SH_SQ / 2;
     ShpNormalArgs sn{obs, err, lw.partial, D, lw.Dp};
     MainArgs fa = a;
+    // (table mode on a whole image: 8 x 16 blocks of the image as wave-tiles, like gl_shp_kernel)
+    fa.blk_w = (interp && m->shp_blocked && m->width % 16 == 0 && m->height % 8 == 0 && (long long)a.N == (long long)m->width * m->height) ? m->width : 0;
     const int nt = (D + 1 + 15) / 16;
     const size_t red = (size_t)(nt * (nt + 1) / 2 * 256 + 8) * sizeof(float);
     const size_t sh = (size_t)((m->D + 3) & ~3) * sizeof(float) +

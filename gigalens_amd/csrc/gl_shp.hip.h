@@ -763,7 +763,12 @@ __global__ void __launch_bounds__(WG, WAVES) gl_shp_normal_kernel(MainArgs a, Sh
     bool valid[2];
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
-      const int j = base + w * WG + ((rot & 3) << 6) + lane;
+      int j = base + w * WG + ((rot & 3) << 6) + lane;
+      if (a.blk_w) {  // the wave's two 64-pixel runs are rows 4 w .. 4 w + 3 of the image's 8 x 16 block (base / 128) + (rot & 3)
+        const int nbx = a.blk_w >> 4, t = (base >> 7) + (rot & 3);
+        const int by = t / nbx, bx = t - by * nbx;
+        j = (by * 8 + 4 * w + (lane >> 4)) * a.blk_w + bx * 16 + (lane & 15);
+      }
       valid[w] = j < p1;
       jj[w] = (unsigned)(valid[w] ? j : p1 - 1);
     }
